@@ -1,0 +1,270 @@
+/* knaster_hip.h -- C ABI of the MI355X voice-bank engine for Knaster's UGen hot path.
+ *
+ * One `knh_bank` IS one UGen from the host graph's point of view
+ * (Inputs = U0, Outputs = U1|U2): it evaluates N independent voices that share
+ * one chain topology, fused into a single gfx950 kernel, and returns their
+ * mixed block.  A Rust shim implements `knaster_core::UGen` by forwarding to
+ * these entry points.  Every function cites the
+ * reference interface it replaces; paths are relative to the knaster repo.
+ *
+ * Conventions
+ *   - all entry points return a knh_status (0 = ok) and never throw or abort
+ *     across the ABI; the message of the last failure on a handle is available
+ *     from knh_last_error() (reference: "log and continue", never a Result on
+ *     the audio path -- knaster_core/src/ugen.rs:328,340).
+ *   - single caller, non-reentrant per handle (the reference calls init on the
+ *     control thread and everything else from the one audio thread:
+ *     knaster_graph/src/graph_gen.rs:110-200).  A handle may be destroyed from
+ *     a different thread than the one that processed with it.
+ *   - the library owns all device memory; `out` pointers are only used during
+ *     the call (knaster_graph/src/task.rs:26-29).
+ *   - plain C types only: no HIP or torch types appear in a signature; a HIP
+ *     stream is passed as `void*`.
+ */
+#ifndef KNASTER_HIP_H
+#define KNASTER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNH_ABI_VERSION 1
+
+typedef enum knh_status {
+  KNH_OK = 0,
+  KNH_ERR_INVALID_ARGUMENT = 1,  /* null handle, bad enum, wrong state            */
+  KNH_ERR_OUT_OF_RANGE = 2,      /* voice/stage/param index out of bounds: no-op  */
+  KNH_ERR_UNSUPPORTED_CHAIN = 3, /* no fused kernel exists for this chain         */
+  KNH_ERR_DEVICE = 4,            /* a HIP call failed; see knh_last_error          */
+  KNH_ERR_NOT_INITIALISED = 5,   /* process/param before knh_bank_init             */
+  KNH_ERR_NO_DEVICE = 6,         /* no gfx950 device visible: the product has no CPU path */
+  KNH_ERR_WRONG_VALUE_KIND = 7   /* e.g. Trigger sent to a Float parameter
+                                    (reference panics: knaster_macros/src/lib.rs:601-606) */
+} knh_status;
+
+/* Sample type F of the bank: knaster_primitives/src/float.rs:97-175 */
+typedef enum knh_sample_type { KNH_F32 = 0, KNH_F64 = 1 } knh_sample_type;
+
+/* ParameterValue kinds: knaster_core/src/parameters/types.rs:25-36 */
+typedef enum knh_value_kind {
+  KNH_VALUE_FLOAT = 0,
+  KNH_VALUE_TRIGGER = 1,
+  KNH_VALUE_INTEGER = 2,
+  KNH_VALUE_BOOL = 3
+} knh_value_kind;
+
+/* A voice chain is a short list of stages evaluated in order on one running
+ * signal `x` (one sample per frame).  Each stage stands for the reference
+ * nodes/wrappers listed beside it; parameter indices are the reference's own
+ * (#[param] declaration order, knaster_macros/src/lib.rs:594-613).
+ *
+ * kind                      reference construct                                   nodes  ctor args
+ * KNH_STAGE_SIN_WT          g.push(SinWt::new(freq))            osc.rs:97-168        1    freq
+ *     params: 0 freq, 1 phase_offset, 2 reset_phase(trigger)
+ *     with KNH_STAGE_FLAG_AR_FREQ: pushed as SinWt::new(freq).ar_params() and
+ *     `.link("freq", x)` -- the running signal drives param 0 every sample
+ *     (audio_rate.rs:42-57, graph_edit.rs:735-754); x is replaced by its output.
+ * KNH_STAGE_SIN_NUMERIC     g.push(SinNumeric::new(freq))       osc.rs:222-271       1    freq
+ *     params: 0 freq, 1 phase_offset, 2 reset_phase(trigger)
+ * KNH_STAGE_SVF             x >> SvfFilter::new(ty,cutoff,q,gain_db)  svf.rs:44-281  1    type, cutoff, q, gain_db
+ *     params: 0 cutoff_freq, 1 q, 2 gain, 3 filter(integer), 4 t_calculate_coefficients(trigger)
+ * KNH_STAGE_ONEPOLE_LPF     x >> OnePoleLpf::new(cutoff)        onepole.rs:111-140   1    cutoff
+ * KNH_STAGE_ONEPOLE_HPF     x >> OnePoleHpf::new()              onepole.rs:144-177   1    (none)
+ *     params: 0 cutoff_freq
+ * KNH_STAGE_MUL_ENV_ASR     x * g.push(EnvAsr::new(a, r))       envelopes.rs:19-163  2    attack_s, release_s
+ *     (EnvAsr node + MathUGen<_,U1,Mul>, math.rs:39-49,94-165)
+ *     params: 0 attack_time, 1 release_time, 2 t_release(trigger), 3 t_restart(trigger)
+ * KNH_STAGE_MUL_ENV_AR      x * g.push(EnvAr::new(a, r))        envelopes.rs:174-303 2    attack_s, release_s
+ *     params: 0 attack_time, 1 release_time, 2 t_restart(trigger)
+ * KNH_STAGE_MUL_CONST       x * c   (Constant + MathUGen Mul)   graph_edit.rs:1036-1066, util.rs:37-64   2   c
+ * KNH_STAGE_ADD_CONST       x + c   (Constant + MathUGen Add)                        2    c
+ * KNH_STAGE_SUB_CONST       x - c   (Constant + MathUGen Sub)                        2    c
+ * KNH_STAGE_DIV_CONST       x / c   (Constant + MathUGen Div)                        2    c
+ *     params: 0 value (the Constant's)
+ * KNH_STAGE_WR_MUL          previous_node.wr_mul(v)             wrappers_core/math.rs:15-113   0   v
+ * KNH_STAGE_WR_ADD          previous_node.wr_add(v)             wrappers_core/math.rs:116-191  0   v
+ * KNH_STAGE_WR_SUB          previous_node.wr_sub(v)             wrappers_core/math.rs:194-269  0   v
+ *     WrMul: params: 0 = the reference's "wr_mul" (index T::Parameters of the
+ *     wrapped node, math.rs:69-98).  WrAdd/WrSub add no parameter.
+ */
+typedef enum knh_stage_kind {
+  KNH_STAGE_SIN_WT = 0,
+  KNH_STAGE_SIN_NUMERIC = 1,
+  KNH_STAGE_SVF = 2,
+  KNH_STAGE_ONEPOLE_LPF = 3,
+  KNH_STAGE_ONEPOLE_HPF = 4,
+  KNH_STAGE_MUL_ENV_ASR = 5,
+  KNH_STAGE_MUL_ENV_AR = 6,
+  KNH_STAGE_MUL_CONST = 7,
+  KNH_STAGE_ADD_CONST = 8,
+  KNH_STAGE_SUB_CONST = 9,
+  KNH_STAGE_DIV_CONST = 10,
+  KNH_STAGE_WR_MUL = 11,
+  KNH_STAGE_WR_ADD = 12,
+  KNH_STAGE_WR_SUB = 13,
+  KNH_STAGE_KIND_COUNT = 14
+} knh_stage_kind;
+
+/* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,
+ * knaster_macros/src/lib.rs:44-47) */
+typedef enum knh_svf_type {
+  KNH_SVF_LOW = 0, KNH_SVF_HIGH = 1, KNH_SVF_BAND = 2, KNH_SVF_NOTCH = 3, KNH_SVF_PEAK = 4,
+  KNH_SVF_ALL = 5, KNH_SVF_BELL = 6, KNH_SVF_LOW_SHELF = 7, KNH_SVF_HIGH_SHELF = 8
+} knh_svf_type;
+
+enum {
+  /* SinWt pushed as .ar_params() with its "freq" linked to the running signal */
+  KNH_STAGE_FLAG_AR_FREQ = 1u << 0
+};
+
+typedef struct knh_stage_desc {
+  uint16_t kind;  /* knh_stage_kind */
+  uint16_t flags; /* KNH_STAGE_FLAG_* */
+  /* > 0: the stage's parameterised node is wrapped (outermost) in
+   * WrPreciseTiming<N, _> with N = this value, so set_delay_within_block
+   * takes effect (precise_timing.rs:14-149).  0: delays are ignored with a
+   * warning, exactly like an unwrapped reference UGen (ugen.rs:339-341). */
+  uint16_t delayed_changes_per_block;
+  uint16_t reserved;
+} knh_stage_desc;
+
+/* How the N per-voice signals are folded into the output block. */
+typedef enum knh_mix_mode {
+  /* Deterministic two-level fold: left fold over each wavefront's 64 voices in
+   * voice order, then a left fold over the wavefront partials in order.  Same
+   * result on every run; differs from the reference's single left fold only
+   * by f32 reassociation (bounded; see DESIGN.md "mixdown"). */
+  KNH_MIX_TREE = 0,
+  /* Bit-exact reference order ((v0+v1)+v2)+... in sample precision
+   * (knaster_graph/src/graph.rs:827-872).  Serial in the voice axis: slower. */
+  KNH_MIX_LEFT_FOLD = 1
+} knh_mix_mode;
+
+typedef struct knh_bank_desc {
+  uint32_t abi_version;  /* KNH_ABI_VERSION */
+  uint32_t n_voices;
+  uint32_t sample_type;  /* knh_sample_type */
+  uint32_t n_stages;
+  const knh_stage_desc* stages;
+  /* 1: mono signal -> graph out 0.  2: `.out([0,0]).to_graph_out()`, the same
+   * mono signal additively to out 0 and out 1 (graph_edit.rs:280-292,363-369). */
+  uint32_t out_channels;
+  uint32_t mix_mode;     /* knh_mix_mode */
+  int32_t device;        /* HIP device ordinal, -1 = current device */
+  /* 0 = exact: every a*b+c is two roundings, per-voice output bit-identical to
+   * the reference's scalar code.  1 = allow fused multiply-add (faster, last-bit
+   * differences). */
+  uint32_t allow_fma;
+} knh_bank_desc;
+
+typedef struct knh_bank knh_bank;
+
+/* Flags returned by process (summary of UGenFlags, knaster_core/src/ugen.rs:121-219) */
+enum {
+  KNH_FLAG_ANY_DONE = 1u << 0, /* some voice's envelope called mark_done this block */
+  KNH_FLAG_ALL_DONE = 1u << 1  /* every voice's last envelope is Stopped            */
+};
+
+/* Library / device discovery. */
+uint32_t knh_abi_version(void);
+/* Number of usable gfx950 devices (0 if none).  Never fails. */
+int32_t knh_device_count(void);
+/* Static message for a status code. */
+const char* knh_status_string(int32_t status);
+/* Message of the last failure on `bank` (or of the last failed create when
+ * bank == NULL).  Valid until the next call on that handle. */
+const char* knh_last_error(const knh_bank* bank);
+
+/* Number of reference UGen nodes one voice of this chain stands for (the
+ * "UGens" factor of the UGen-samples/s metric). */
+int32_t knh_chain_ugen_count(const knh_stage_desc* stages, uint32_t n_stages);
+
+/* Construction = the reference's `SomeUGen::new(args)` for every node of every
+ * voice (osc.rs:110, svf.rs:64, envelopes.rs:33,187, util.rs:43).  */
+int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank);
+/* Constructor arguments of stage `stage` for `count` voices starting at
+ * `first_voice`; `args` is [count][n_args] row-major, n_args as in the table
+ * above.  Must be called before knh_bank_init; unset stages use zeros. */
+int32_t knh_bank_set_ctor_args(knh_bank* bank, uint32_t stage, uint32_t first_voice, uint32_t count,
+                               const double* args, uint32_t n_args);
+/* UGen::init(sample_rate, block_size) -- knaster_core/src/ugen.rs:242-246; runs
+ * on the control thread, may allocate (graph.rs:462-475).  Uploads all state. */
+int32_t knh_bank_init(knh_bank* bank, uint32_t sample_rate, size_t block_size);
+void knh_bank_destroy(knh_bank* bank);
+
+/* UGen::inputs()/outputs()/parameters() of the bank node -- dynugen.rs:23-63 */
+uint16_t knh_bank_inputs(const knh_bank* bank);
+uint16_t knh_bank_outputs(const knh_bank* bank);
+/* Number of parameters of one stage (0 for unknown stage). */
+uint16_t knh_bank_stage_parameters(const knh_bank* bank, uint32_t stage);
+/* UGen::param_descriptions() of one stage; NULL when out of range. */
+const char* knh_bank_stage_param_description(const knh_bank* bank, uint32_t stage, uint32_t param);
+
+/* UGen::param_apply(ctx, index, value) -- knaster_core/src/ugen.rs:308 -- on
+ * the node of `stage` in `voice`.  Takes effect at the start of the next
+ * processed block, or at the armed in-block delay if the stage is wrapped in
+ * WrPreciseTiming and a delay is armed for that parameter
+ * (precise_timing.rs:126-135).  `fvalue` is used for FLOAT, `ivalue` for
+ * INTEGER/BOOL; TRIGGER uses neither. */
+int32_t knh_bank_param_apply(knh_bank* bank, uint32_t voice, uint32_t stage, uint32_t param,
+                             uint32_t kind, double fvalue, int64_t ivalue);
+/* UGen::set_delay_within_block_for_param(ctx, index, delay) -- ugen.rs:330-341,
+ * precise_timing.rs:146-148.  The armed delay stays armed for later changes of
+ * that parameter until re-armed (reference behaviour). */
+int32_t knh_bank_set_delay_within_block_for_param(knh_bank* bank, uint32_t voice, uint32_t stage,
+                                                  uint32_t param, uint16_t delay);
+/* The same two calls for many (voice, stage, param) at once, applied in array
+ * order: one SchedulingEvent each, as GraphGen::apply_parameter_change does
+ * (graph_gen.rs:269-305): if delays[i] > 0 the delay is armed first, then the
+ * value is applied.  `delays` may be NULL (all zero). */
+int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* voices,
+                                  const uint32_t* stages, const uint32_t* params,
+                                  const uint32_t* kinds, const double* fvalues,
+                                  const int64_t* ivalues, const uint16_t* delays);
+
+/* UGen::process_block(ctx, flags, input, output) -- knaster_core/src/ugen.rs:263-284
+ * as called by Task::run (knaster_graph/src/task.rs:25-31).
+ *   frames_to_process / block_start_offset / frame_clock = ctx.block (ugen.rs:57-112);
+ *   a top-level graph always passes (block_size, 0, clock).
+ *   out: host pointer, channel-major [out_channels][block_size] of F
+ *        (RawContiguousBlock, knaster_graph/src/block.rs:19-78); frames
+ *        [block_start_offset, block_start_offset+frames_to_process) are written.
+ *   out_flags: optional KNH_FLAG_* summary.
+ * Blocks until the block is on the host (non-realtime driver only). */
+int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t block_start_offset,
+                               uint64_t frame_clock, void* out, uint32_t* out_flags);
+/* Same, but the mixed block is left in device memory at `out_device`
+ * ([out_channels][block_size] of F) and the work is only enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the bank's own stream).  Used for the
+ * multi-GPU reduce and for back-to-back blocks without host round trips. */
+int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process,
+                                      size_t block_start_offset, uint64_t frame_clock,
+                                      void* out_device, void* hip_stream);
+/* Parity/debug: also materialise every voice's own signal,
+ * voices_out = host [n_voices][block_size] of F.  `out` may be NULL. */
+int32_t knh_bank_process_block_voices(knh_bank* bank, size_t frames_to_process,
+                                      size_t block_start_offset, uint64_t frame_clock, void* out,
+                                      void* voices_out, uint32_t* out_flags);
+/* Per-voice done frame of the last processed block (UGenFlags::done,
+ * ugen.rs:169-175): done_frames[v] = frame in block, or UINT32_MAX. */
+int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames);
+/* Wait for everything enqueued by *_device calls. */
+int32_t knh_bank_synchronize(knh_bank* bank);
+
+/* Measurement hooks (bench.py): device time in milliseconds and launch count
+ * of the voice kernel accumulated since the last reset, measured with HIP
+ * events on the stream the kernel runs on. */
+int32_t knh_bank_timing_reset(knh_bank* bank, int32_t enable);
+int32_t knh_bank_timing_read(knh_bank* bank, double* kernel_ms, uint64_t* launches);
+/* Algorithmic HBM bytes one voice moves per processed block (state read once,
+ * mutable state written once); see DESIGN.md. */
+int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_t* read_bytes,
+                                                   uint32_t* write_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNASTER_HIP_H */

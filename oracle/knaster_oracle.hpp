@@ -1,0 +1,1525 @@
+// knaster_oracle.hpp -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+//
+// A C++17 restatement of the Rust reference's per-sample / per-block UGen hot
+// path (ErikNatanael/knaster), written from the sources read as text.  Only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it;
+// nothing under knaster_amd/ links, includes or calls it.
+//
+// PINNING STATUS
+//   * Pinned by the reference's own known-answer tests (ported in
+//     oracle/oracle_kat.cpp, run by tests/test_oracle_kat.py): wrapper
+//     arithmetic, WrPreciseTiming sequences, MathUGen, graph plumbing,
+//     additive outputs, disconnect, bench asserts, Seconds conversions,
+//     the implement_a_gen sine check.
+//   * PARITY UNPINNED for the waveform-level output of SinWt, SinNumeric,
+//     SvfFilter, OnePole*, EnvAsr, EnvAr: no reference test or fixture pins
+//     those numbers and no Rust toolchain exists in the build image, so those
+//     are correct "by construction of the restatement" only.
+//
+// All citations are file:line under /root/reference/.
+// Arithmetic rules: built with -ffp-contract=off -fno-fast-math so every
+// a*b+c is two roundings, exactly as rustc emits it.
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <string>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+namespace kno {
+
+// ---------------------------------------------------------------------------
+// Float helpers -- knaster_primitives/src/float.rs:11-56,97-175
+// F::new(v) is a plain `as` cast through to_f32()/to_f64() (round to nearest).
+// ---------------------------------------------------------------------------
+using PFloat = double;  // knaster_primitives/src/parameters.rs:6
+
+template <typename F, typename V>
+inline F fnew(V v) {
+  return static_cast<F>(v);
+}
+template <typename F>
+struct FloatConst;
+template <>
+struct FloatConst<float> {
+  static constexpr float PI = 3.14159265358979323846f;   // f32::consts::PI
+  static constexpr float TAU = 6.28318530717958647692f;  // f32::consts::TAU
+};
+template <>
+struct FloatConst<double> {
+  static constexpr double PI = 3.14159265358979323846;
+  static constexpr double TAU = 6.28318530717958647692;
+};
+
+// Rust `as u32` from a float saturates: NaN -> 0, <0 -> 0, >MAX -> MAX.
+inline uint32_t sat_u32(double v) {
+  if (!(v > 0.0)) return 0u;  // also NaN
+  if (v >= 4294967295.0) return 0xFFFFFFFFu;
+  return static_cast<uint32_t>(v);
+}
+
+// ---------------------------------------------------------------------------
+// XOrShift32Rng -- knaster_core_dsp/src/dsp/xorrng.rs:9-50
+// ---------------------------------------------------------------------------
+struct XOrShift32Rng {
+  uint32_t fpd;
+  explicit XOrShift32Rng(uint32_t seed = 17) : fpd(seed == 0 ? 17u : seed) {}
+  uint32_t gen_u32() {
+    fpd ^= fpd << 13;
+    fpd ^= fpd >> 17;
+    fpd ^= fpd << 5;
+    return fpd;
+  }
+  float gen_f32() { return static_cast<float>(gen_u32()) / static_cast<float>(0xFFFFFFFFu); }
+  double gen_f64() { return static_cast<double>(gen_u32()) / static_cast<double>(0xFFFFFFFFu); }
+};
+
+// ---------------------------------------------------------------------------
+// Seconds -- knaster_primitives/src/time.rs:11-157
+// ---------------------------------------------------------------------------
+constexpr uint32_t SUBSECOND_TESIMALS_PER_SECOND = 282240000u;
+struct Seconds {
+  uint32_t seconds = 0;
+  uint32_t subsecond_tesimals = 0;
+  static Seconds zero() { return Seconds{0, 0}; }
+  static Seconds from_secs_f64(double s) {  // time.rs:58-63
+    Seconds r;
+    r.seconds = sat_u32(std::floor(s));
+    double fract = s - std::trunc(s);  // f64::fract
+    r.subsecond_tesimals = sat_u32(fract * static_cast<double>(SUBSECOND_TESIMALS_PER_SECOND));
+    return r;
+  }
+  static Seconds from_samples(uint64_t samples, uint64_t sample_rate) {  // time.rs:76-84
+    Seconds r;
+    r.seconds = static_cast<uint32_t>(samples / sample_rate);
+    r.subsecond_tesimals = static_cast<uint32_t>(
+        (samples % sample_rate) * static_cast<uint64_t>(SUBSECOND_TESIMALS_PER_SECOND) / sample_rate);
+    return r;
+  }
+  uint64_t to_samples(uint64_t sample_rate) const {  // time.rs:86-90
+    return static_cast<uint64_t>(seconds) * sample_rate +
+           (static_cast<uint64_t>(subsecond_tesimals) * sample_rate) /
+               static_cast<uint64_t>(SUBSECOND_TESIMALS_PER_SECOND);
+  }
+  bool operator==(const Seconds& o) const {
+    return seconds == o.seconds && subsecond_tesimals == o.subsecond_tesimals;
+  }
+  bool le(const Seconds& o) const {  // Ord, time.rs:149-157
+    if (seconds == o.seconds) return subsecond_tesimals <= o.subsecond_tesimals;
+    return seconds < o.seconds;
+  }
+  Seconds saturating_sub(const Seconds& rhs) const {  // time.rs:119-133
+    if (le(rhs)) return zero();
+    if (subsecond_tesimals >= rhs.subsecond_tesimals)
+      return Seconds{seconds - rhs.seconds, subsecond_tesimals - rhs.subsecond_tesimals};
+    return Seconds{seconds - rhs.seconds - 1,
+                   SUBSECOND_TESIMALS_PER_SECOND - (rhs.subsecond_tesimals - subsecond_tesimals)};
+  }
+  Seconds add(const Seconds& rhs) const {  // time.rs:158-171
+    uint32_t s = seconds + rhs.seconds;
+    uint32_t t = subsecond_tesimals + rhs.subsecond_tesimals;
+    while (t >= SUBSECOND_TESIMALS_PER_SECOND) {
+      s += 1;
+      t -= SUBSECOND_TESIMALS_PER_SECOND;
+    }
+    return Seconds{s, t};
+  }
+};
+
+// ---------------------------------------------------------------------------
+// AudioCtx / BlockMetadata / UGenFlags -- knaster_core/src/ugen.rs:8-219
+// ---------------------------------------------------------------------------
+struct BlockMetadata {
+  size_t block_start_offset = 0;
+  size_t frames_to_process = 0;
+  uint64_t frame_clock = 0;
+  BlockMetadata make_partial(size_t start_offset, size_t length) const {  // ugen.rs:87-93
+    BlockMetadata b;
+    b.block_start_offset = block_start_offset + start_offset;
+    b.frames_to_process = length;
+    b.frame_clock = frame_clock + start_offset;
+    return b;
+  }
+};
+struct AudioCtx {
+  uint32_t sample_rate_;
+  size_t block_size_;
+  BlockMetadata block;
+  std::vector<std::string> log;  // stands in for the rt_log! ring buffer
+  AudioCtx(uint32_t sr, size_t bs) : sample_rate_(sr), block_size_(bs) {
+    block.frames_to_process = bs;
+  }
+  uint32_t sample_rate() const { return sample_rate_; }
+  size_t block_size() const { return block_size_; }
+  size_t frames_to_process() const { return block.frames_to_process; }
+  size_t block_start_offset() const { return block.block_start_offset; }
+  uint64_t frame_clock() const { return block.frame_clock; }
+  void rt_log(const std::string& s) {
+    if (log.size() < 64) log.push_back(s);
+  }
+};
+struct UGenFlags {
+  bool remove_self_supported = false;
+  bool done_ = false;
+  uint32_t done_frame_in_block = 0xFFFFFFFFu;
+  bool remove_self_ = false;
+  bool remove_parent = false;
+  uint32_t remove_parent_from_frame_in_block = 0xFFFFFFFFu;
+  void mark_done(uint32_t frame) {  // ugen.rs:199-202
+    done_ = true;
+    done_frame_in_block = frame;
+  }
+  bool done(uint32_t* frame) const {
+    if (done_ && frame) *frame = done_frame_in_block;
+    return done_;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// ParameterValue -- knaster_core/src/parameters/types.rs:25-36
+// ---------------------------------------------------------------------------
+struct ParameterValue {
+  enum Kind : uint8_t { Float = 0, Trigger = 1, Integer = 2, Bool = 3, Smoothing = 4 } kind = Float;
+  PFloat f = 0.0;
+  uint64_t i = 0;
+  bool b = false;
+  static ParameterValue Flt(PFloat v) {
+    ParameterValue p;
+    p.kind = Float;
+    p.f = v;
+    return p;
+  }
+  static ParameterValue Trig() {
+    ParameterValue p;
+    p.kind = Trigger;
+    return p;
+  }
+  static ParameterValue Int(uint64_t v) {
+    ParameterValue p;
+    p.kind = Integer;
+    p.i = v;
+    return p;
+  }
+  // `.float().expect(..)` in macro-generated code (knaster_macros/src/lib.rs:601-606)
+  PFloat float_or_panic() const {
+    if (kind != Float) throw std::runtime_error("parameter value is expected to be a float");
+    return f;
+  }
+  uint64_t integer_or_panic() const {
+    if (kind != Integer) throw std::runtime_error("parameter value is expected to be an integer");
+    return i;
+  }
+};
+
+enum class ParameterError { Ok = 0, ParameterIndexOutOfBounds = 1, DescriptionNotFound = 2 };
+
+// ---------------------------------------------------------------------------
+// Blocks -- knaster_primitives/src/block.rs:33-339, knaster_graph/src/block.rs
+// Channel-major; a view is an array of per-channel pointers + a frame count.
+// A partial block is the same view advanced by `offset` frames.
+// ---------------------------------------------------------------------------
+template <typename F>
+struct BlockView {
+  std::vector<F*> ch;
+  size_t frames = 0;
+  BlockView() = default;
+  BlockView(F* contiguous, size_t channels, size_t block_size) : frames(block_size) {
+    for (size_t c = 0; c < channels; ++c) ch.push_back(contiguous + c * block_size);
+  }
+  size_t channels() const { return ch.size(); }
+  F read(size_t c, size_t f) const {
+    assert(c < ch.size() && f < frames);
+    return ch[c][f];
+  }
+  void write(F v, size_t c, size_t f) {
+    assert(c < ch.size() && f < frames);
+    ch[c][f] = v;
+  }
+  F* channel(size_t c) { return ch[c]; }
+  const F* channel(size_t c) const { return ch[c]; }
+  BlockView partial(size_t offset, size_t length) const {  // block.rs:269-339
+    assert(offset + length <= frames);
+    BlockView p;
+    p.frames = length;
+    for (F* c : ch) p.ch.push_back(c + offset);
+    return p;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// UGen -- knaster_core/src/ugen.rs:232-369 (object-safe form, as DynUGen in
+// knaster_graph/src/dynugen.rs:23-63)
+// ---------------------------------------------------------------------------
+template <typename F>
+struct UGen {
+  virtual ~UGen() = default;
+  virtual size_t inputs() const = 0;
+  virtual size_t outputs() const = 0;
+  virtual size_t parameters() const = 0;
+  virtual void init(uint32_t /*sample_rate*/, size_t /*block_size*/) {}
+  // in: inputs() samples, out: outputs() samples
+  virtual void process(AudioCtx& ctx, UGenFlags& flags, const F* in, F* out) = 0;
+  // Default = frame loop, ugen.rs:263-284
+  virtual void process_block(AudioCtx& ctx, UGenFlags& flags, const BlockView<F>& input,
+                             BlockView<F>& output) {
+    const size_t ni = inputs(), no = outputs();
+    F in_frame[16], out_frame[16];
+    assert(ni <= 16 && no <= 16);
+    for (size_t frame = 0; frame < ctx.block.frames_to_process; ++frame) {
+      for (size_t i = 0; i < ni; ++i) in_frame[i] = input.read(i, frame);
+      process(ctx, flags, in_frame, out_frame);
+      for (size_t i = 0; i < no; ++i) output.write(out_frame[i], i, frame);
+    }
+  }
+  virtual std::vector<std::string> param_descriptions() const { return {}; }
+  virtual void param_apply(AudioCtx& ctx, size_t index, ParameterValue value) = 0;
+  virtual void set_ar_param_buffer(AudioCtx& ctx, size_t /*index*/, const F* /*buffer*/) {
+    ctx.rt_log("Warning: Audio rate parameter buffer set, but did not reach a WrArParams");
+  }
+  virtual void set_delay_within_block_for_param(AudioCtx& ctx, size_t /*index*/, uint16_t /*delay*/) {
+    ctx.rt_log("Warning: Parameter delay set, but did not reach a WrHiResParams");
+  }
+  // ugen.rs:344-368
+  ParameterError param(AudioCtx& ctx, size_t index, ParameterValue value) {
+    if (index >= parameters()) return ParameterError::ParameterIndexOutOfBounds;
+    param_apply(ctx, index, value);
+    return ParameterError::Ok;
+  }
+  ParameterError param(AudioCtx& ctx, const std::string& desc, ParameterValue value) {
+    auto d = param_descriptions();
+    for (size_t i = 0; i < d.size(); ++i)
+      if (d[i] == desc) {
+        param_apply(ctx, i, value);
+        return ParameterError::Ok;
+      }
+    return ParameterError::DescriptionNotFound;
+  }
+};
+template <typename F>
+using UGenPtr = std::unique_ptr<UGen<F>>;
+
+// ---------------------------------------------------------------------------
+// Wavetable -- knaster_core_dsp/src/dsp/wavetable.rs:8-60,130-139,322-324
+// ---------------------------------------------------------------------------
+constexpr uint32_t TABLE_POWER = 14;
+constexpr size_t TABLE_SIZE = size_t(1) << TABLE_POWER;
+constexpr uint32_t TABLE_HIGH_MASK = uint32_t(TABLE_SIZE) - 1;
+constexpr uint32_t FRACTIONAL_PART = 65536;
+
+struct WavetablePhase {
+  uint32_t v = 0;
+  size_t integer_component() const { return (v >> 16) & TABLE_HIGH_MASK; }
+  void increase(uint32_t add) { v = v + add; }  // wrapping
+  WavetablePhase operator+(WavetablePhase o) const { return WavetablePhase{v + o.v}; }
+};
+
+// NonAaWavetable::<f32>::sine(): buf[i] = (f32) sin((i/16384) * PI * 2.0), f64 sin.
+inline const std::vector<float>& sine_wavetable_f32() {
+  static const std::vector<float> table = [] {
+    std::vector<float> t(TABLE_SIZE);
+    const double PI = 3.14159265358979323846;
+    for (size_t i = 0; i < TABLE_SIZE; ++i)
+      t[i] = static_cast<float>(
+          std::sin((static_cast<double>(i) / static_cast<double>(TABLE_SIZE)) * PI * 2.0));
+    return t;
+  }();
+  return table;
+}
+
+// ---------------------------------------------------------------------------
+// SinWt -- knaster_core_dsp/src/ugens/osc.rs:97-168
+// params: 0 freq, 1 phase_offset, 2 reset_phase (trigger)
+// ---------------------------------------------------------------------------
+template <typename F>
+struct SinWt : UGen<F> {
+  WavetablePhase phase, phase_offset_;
+  uint32_t phase_increment = 0;
+  double freq_to_phase_inc = 0.0;
+  F freq_;
+  const float* wavetable;
+  explicit SinWt(F freq) : freq_(freq), wavetable(sine_wavetable_f32().data()) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 3; }
+  std::vector<std::string> param_descriptions() const override {
+    return {"freq", "phase_offset", "reset_phase"};
+  }
+  void freq(PFloat f) {  // osc.rs:127-130
+    freq_ = fnew<F>(f);
+    phase_increment = sat_u32(static_cast<double>(freq_) * freq_to_phase_inc);
+  }
+  void phase_offset(PFloat o) {  // osc.rs:133-135
+    phase_offset_.v = sat_u32(o * static_cast<double>(FRACTIONAL_PART));
+  }
+  void reset_phase() { phase.v = 0; }
+  void init(uint32_t sample_rate, size_t) override {  // osc.rs:142-147
+    reset_phase();
+    freq_to_phase_inc = static_cast<double>(TABLE_SIZE) * static_cast<double>(FRACTIONAL_PART) *
+                        (1.0 / static_cast<double>(sample_rate));
+    freq(static_cast<double>(freq_));
+  }
+  F next_sample() {  // osc.rs:151-156
+    float s = wavetable[(phase + phase_offset_).integer_component()];
+    phase.increase(phase_increment);
+    return fnew<F>(s);
+  }
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override { out[0] = next_sample(); }
+  void process_block(AudioCtx& ctx, UGenFlags&, const BlockView<F>&, BlockView<F>& output) override {
+    (void)ctx;
+    F* o = output.channel(0);
+    for (size_t i = 0; i < output.frames; ++i) o[i] = next_sample();
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    switch (index) {
+      case 0: freq(v.float_or_panic()); break;
+      case 1: phase_offset(v.float_or_panic()); break;
+      case 2: reset_phase(); break;
+      default: ctx.rt_log("Unknown parameter set for SinWt");
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// SinNumeric -- osc.rs:222-271.  Only `process` (default frame loop).
+// ---------------------------------------------------------------------------
+template <typename F>
+struct SinNumeric : UGen<F> {
+  F phase, phase_offset_ = 0, phase_increment = 0;
+  explicit SinNumeric(F freq) : phase(freq) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 3; }
+  std::vector<std::string> param_descriptions() const override {
+    return {"freq", "phase_offset", "reset_phase"};
+  }
+  void init(uint32_t sample_rate, size_t) override {  // osc.rs:253-261
+    if (phase_increment == F(0)) phase_increment = phase / fnew<F>(static_cast<float>(sample_rate));
+    phase = F(0);
+  }
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override {  // osc.rs:263-270
+    out[0] = std::sin((phase + phase_offset_) * FloatConst<F>::TAU);
+    phase += phase_increment;
+    if (phase > F(1)) phase -= F(1);
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    switch (index) {
+      case 0:  // osc.rs:240-242
+        phase_increment =
+            fnew<F>(v.float_or_panic()) / fnew<F>(static_cast<float>(ctx.sample_rate()));
+        break;
+      case 1: phase_offset_ = fnew<F>(v.float_or_panic()); break;
+      case 2: phase = F(0); break;
+      default: ctx.rt_log("Unknown parameter set for SinNumeric");
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// SvfFilter -- knaster_core_dsp/src/ugens/svf.rs:19-281
+// params: 0 cutoff_freq, 1 q, 2 gain, 3 filter, 4 t_calculate_coefficients
+// ---------------------------------------------------------------------------
+enum SvfFilterType : uint8_t { Low = 0, High, Band, Notch, Peak, All, Bell, LowShelf, HighShelf };
+
+template <typename F>
+struct SvfCoeffs {
+  F a1 = 0, a2 = 0, a3 = 0, m0 = 0, m1 = 0, m2 = 0;
+};
+// svf.rs:146-242
+template <typename F>
+inline SvfCoeffs<F> svf_set_coeffs(SvfFilterType ty, F cutoff, F q, F gain_db, F sample_rate) {
+  const F PI = FloatConst<F>::PI, ONE = 1, ZERO = 0;
+  SvfCoeffs<F> c;
+  auto common = [&](F g, F k) {
+    c.a1 = ONE / (ONE + g * (g + k));
+    c.a2 = g * c.a1;
+    c.a3 = g * c.a2;
+  };
+  switch (ty) {
+    case Low: {
+      F g = std::tan((PI * cutoff) / sample_rate), k = ONE / q;
+      common(g, k);
+      c.m0 = ZERO; c.m1 = ZERO; c.m2 = ONE;
+    } break;
+    case Band: {
+      F g = std::tan((PI * cutoff) / sample_rate), k = ONE / q;
+      common(g, k);
+      c.m0 = ZERO; c.m1 = ONE; c.m2 = ZERO;
+    } break;
+    case High: {
+      F g = std::tan((PI * cutoff) / sample_rate), k = ONE / q;
+      common(g, k);
+      c.m0 = ONE; c.m1 = -k; c.m2 = -ONE;
+    } break;
+    case Notch: {
+      F g = std::tan((PI * cutoff) / sample_rate), k = ONE / q;
+      common(g, k);
+      c.m0 = ONE; c.m1 = -k; c.m2 = ZERO;
+    } break;
+    case Peak: {
+      F g = std::tan((PI * cutoff) / sample_rate), k = ONE / q;
+      common(g, k);
+      c.m0 = ONE; c.m1 = -k; c.m2 = -F(2);
+    } break;
+    case All: {
+      F g = std::tan((PI * cutoff) / sample_rate), k = ONE / q;
+      common(g, k);
+      c.m0 = ONE; c.m1 = -F(2) * k; c.m2 = ZERO;
+    } break;
+    case Bell: {
+      F amp = std::pow(F(10), gain_db / F(40));
+      F g = std::tan((PI * cutoff) / sample_rate) / std::sqrt(amp);
+      F k = ONE / (q * amp);
+      common(g, k);
+      c.m0 = ONE; c.m1 = k * (amp * amp - ONE); c.m2 = ZERO;
+    } break;
+    case LowShelf: {
+      F amp = std::pow(F(10), gain_db / F(40));
+      F g = std::tan((PI * cutoff) / sample_rate) / std::sqrt(amp);
+      F k = ONE / q;
+      common(g, k);
+      c.m0 = ONE; c.m1 = k * (amp - ONE); c.m2 = amp * amp - ONE;
+    } break;
+    case HighShelf: {
+      F amp = std::pow(F(10), gain_db / F(40));
+      F g = std::tan((PI * cutoff) / sample_rate) * std::sqrt(amp);
+      F k = ONE / q;
+      common(g, k);
+      c.m0 = amp * amp; c.m1 = k * (ONE - amp) * amp; c.m2 = ONE - amp * amp;
+    } break;
+  }
+  return c;
+}
+inline SvfFilterType svf_type_from_pinteger(uint64_t v) {  // knaster_macros/src/lib.rs:44-47
+  return v <= 8 ? static_cast<SvfFilterType>(v) : Low;
+}
+
+template <typename F>
+struct SvfFilter : UGen<F> {
+  SvfFilterType ty;
+  F cutoff_freq, q, gain_db;
+  F ic1eq = 0, ic2eq = 0;
+  SvfCoeffs<F> c;
+  SvfFilter(SvfFilterType ty_, F cutoff, F q_, F gain) : ty(ty_), cutoff_freq(cutoff), q(q_), gain_db(gain) {}
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 5; }
+  std::vector<std::string> param_descriptions() const override {
+    return {"cutoff_freq", "q", "gain", "filter", "t_calculate_coefficients"};
+  }
+  void recalc(uint32_t sr) {
+    c = svf_set_coeffs<F>(ty, cutoff_freq, q, gain_db, fnew<F>(static_cast<float>(sr)));
+  }
+  void init(uint32_t sample_rate, size_t) override { recalc(sample_rate); }
+  F process_sample(F v0) {  // svf.rs:272-278
+    F v3 = v0 - ic2eq;
+    F v1 = c.a1 * ic1eq + c.a2 * v3;
+    F v2 = ic2eq + c.a2 * ic1eq + c.a3 * v3;
+    ic1eq = F(2) * v1 - ic1eq;
+    ic2eq = F(2) * v2 - ic2eq;
+    return c.m0 * v0 + c.m1 * v1 + c.m2 * v2;
+  }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override { out[0] = process_sample(in[0]); }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    switch (index) {
+      case 0: cutoff_freq = fnew<F>(v.float_or_panic()); recalc(ctx.sample_rate()); break;
+      case 1: q = fnew<F>(v.float_or_panic()); recalc(ctx.sample_rate()); break;
+      case 2: gain_db = fnew<F>(v.float_or_panic()); recalc(ctx.sample_rate()); break;
+      case 3: ty = svf_type_from_pinteger(v.integer_or_panic()); recalc(ctx.sample_rate()); break;
+      case 4: recalc(ctx.sample_rate()); break;
+      default: ctx.rt_log("Unknown parameter set for SvfFilter");
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// OnePole / OnePoleLpf / OnePoleHpf -- knaster_core_dsp/src/ugens/onepole.rs
+// ---------------------------------------------------------------------------
+template <typename T>
+struct OnePole {
+  T last_output = T(0.0), a0 = T(1.0), b1 = T(0.0);
+  void set_freq_lowpass(T freq, T sample_rate) {  // onepole.rs:35-46
+    T f = freq / sample_rate;
+    T b_tmp = std::exp(T(-2.0) * FloatConst<T>::PI * f);
+    b1 = b_tmp;
+    a0 = T(1.0) - b1;
+  }
+  void set_freq_highpass(T freq, T sample_rate) { set_freq_lowpass(freq, sample_rate); }
+  T process_lp(T input) {  // onepole.rs:64-77
+    last_output = input * a0 + last_output * b1;
+    return last_output;
+  }
+  T process_hp(T input) {  // onepole.rs:80-92
+    last_output = input * a0 + last_output * b1;
+    return input - last_output;
+  }
+};
+template <typename F>
+struct OnePoleLpf : UGen<F> {
+  OnePole<F> op;
+  explicit OnePoleLpf(F cutoff) { op.b1 = cutoff; }  // onepole.rs:118-122
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"cutoff_freq"}; }
+  void init(uint32_t sample_rate, size_t) override {  // onepole.rs:123-129
+    if (op.a0 == F(1)) {
+      F freq = op.b1;
+      op.set_freq_lowpass(freq, fnew<F>(static_cast<float>(sample_rate)));
+    }
+  }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override { out[0] = op.process_lp(in[0]); }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    if (index == 0)
+      op.set_freq_lowpass(fnew<F>(v.float_or_panic()), static_cast<F>(ctx.sample_rate()));
+    else
+      ctx.rt_log("Unknown parameter set for OnePoleLpf");
+  }
+};
+template <typename F>
+struct OnePoleHpf : UGen<F> {
+  OnePole<F> op;
+  OnePoleHpf() = default;
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"cutoff_freq"}; }
+  void init(uint32_t sample_rate, size_t) override {  // onepole.rs:161-167
+    if (op.a0 == F(1)) {
+      F freq = op.b1;
+      op.set_freq_highpass(freq, fnew<F>(static_cast<float>(sample_rate)));
+    }
+  }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override { out[0] = op.process_hp(in[0]); }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    if (index == 0)
+      op.set_freq_highpass(fnew<F>(v.float_or_panic()), static_cast<F>(ctx.sample_rate()));
+    else
+      ctx.rt_log("Unknown parameter set for OnePoleHpf");
+  }
+};
+
+// ---------------------------------------------------------------------------
+// EnvAsr / EnvAr -- knaster_core_dsp/src/ugens/envelopes.rs:19-303
+// ---------------------------------------------------------------------------
+template <typename F>
+inline F powi3(F t) {  // num-traits powi(3): acc = t; base = t*t; acc = acc*base
+  return t * (t * t);
+}
+enum class AsrState : uint32_t { Stopped = 0, Attacking = 1, Sustaining = 2, Releasing = 3 };
+
+template <typename F>
+struct EnvAsr : UGen<F> {
+  AsrState state = AsrState::Stopped;
+  F t = 0, attack_seconds, attack_rate = 1, release_seconds, release_rate = 1, release_scale = 1;
+  EnvAsr(F attack_time, F release_time) : attack_seconds(attack_time), release_seconds(release_time) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 4; }
+  std::vector<std::string> param_descriptions() const override {
+    return {"attack_time", "release_time", "t_release", "t_restart"};
+  }
+  F next_sample(UGenFlags& flags, uint32_t sample_in_block) {  // envelopes.rs:52-81
+    F out;
+    switch (state) {
+      case AsrState::Stopped: out = F(0); break;
+      case AsrState::Attacking:
+        out = t;
+        t += attack_rate;
+        if (t >= F(1)) state = AsrState::Sustaining;
+        break;
+      case AsrState::Sustaining: out = F(1); break;
+      case AsrState::Releasing:
+      default:
+        out = powi3(t) * release_scale;
+        t -= release_rate;
+        if (t <= F(0)) {
+          state = AsrState::Stopped;
+          t = F(0);
+          flags.mark_done(sample_in_block);
+        }
+        break;
+    }
+    return out;
+  }
+  void init(uint32_t sample_rate, size_t) override {  // envelopes.rs:135-151
+    if (attack_rate == F(1)) {
+      if (attack_seconds == F(0)) attack_rate = F(1);
+      else attack_rate = F(1) / (attack_seconds * static_cast<F>(sample_rate));
+    }
+    if (release_rate == F(1)) {
+      if (release_seconds == F(0)) release_rate = F(1);
+      else release_rate = F(1) / (release_seconds * static_cast<F>(sample_rate));
+    }
+  }
+  void process(AudioCtx&, UGenFlags& flags, const F*, F* out) override { out[0] = next_sample(flags, 0); }
+  void process_block(AudioCtx&, UGenFlags& flags, const BlockView<F>&, BlockView<F>& output) override {
+    F* o = output.channel(0);
+    for (size_t i = 0; i < output.frames; ++i) o[i] = next_sample(flags, static_cast<uint32_t>(i));
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    switch (index) {
+      case 0: {  // envelopes.rs:85-96
+        F atk = fnew<F>(v.float_or_panic());
+        if (attack_seconds != atk) {
+          attack_seconds = atk;
+          if (atk == F(0)) attack_rate = F(1);
+          else attack_rate = F(1) / (attack_seconds * static_cast<F>(ctx.sample_rate()));
+        }
+      } break;
+      case 1: {  // envelopes.rs:99-110
+        F rel = fnew<F>(v.float_or_panic());
+        if (release_seconds != rel) {
+          release_seconds = rel;
+          if (rel == F(0)) release_rate = F(1);
+          else release_rate = F(1) / (release_seconds * static_cast<F>(ctx.sample_rate()));
+        }
+      } break;
+      case 2:  // t_release, envelopes.rs:113-128
+        switch (state) {
+          case AsrState::Stopped: break;
+          case AsrState::Attacking:
+            release_scale = t;
+            state = AsrState::Releasing;
+            t = F(1);
+            break;
+          case AsrState::Sustaining:
+            release_scale = F(1);
+            state = AsrState::Releasing;
+            t = F(1);
+            break;
+          case AsrState::Releasing: break;
+        }
+        break;
+      case 3: state = AsrState::Attacking; break;  // t_restart: t is NOT reset
+      default: ctx.rt_log("Unknown parameter set for EnvAsr");
+    }
+  }
+};
+
+enum class ArState : uint32_t { Stopped = 0, Attacking = 1, Releasing = 3 };
+template <typename F>
+struct EnvAr : UGen<F> {
+  ArState state = ArState::Stopped;
+  F t = 0, attack_seconds, attack_rate = 1, release_seconds, release_rate = 1, release_scale = 1;
+  EnvAr(F attack_time, F release_time) : attack_seconds(attack_time), release_seconds(release_time) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 3; }
+  std::vector<std::string> param_descriptions() const override {
+    return {"attack_time", "release_time", "t_restart"};
+  }
+  F next_sample(UGenFlags& flags, uint32_t sample_in_block) {  // envelopes.rs:205-233
+    F out;
+    switch (state) {
+      case ArState::Stopped: out = F(0); break;
+      case ArState::Attacking:
+        out = t;
+        t += attack_rate;
+        if (t >= F(1)) {
+          release_scale = F(1);
+          state = ArState::Releasing;
+          t = F(1);
+        }
+        break;
+      case ArState::Releasing:
+      default:
+        out = powi3(t) * release_scale;
+        t -= release_rate;
+        if (t <= F(0)) {
+          state = ArState::Stopped;
+          t = F(0);
+          flags.mark_done(sample_in_block);
+        }
+        break;
+    }
+    return out;
+  }
+  void init(uint32_t sample_rate, size_t) override {  // envelopes.rs:268-284
+    if (attack_rate == F(1)) {
+      if (attack_seconds == F(0)) attack_rate = F(1);
+      else attack_rate = F(1) / (attack_seconds * static_cast<F>(sample_rate));
+    }
+    if (release_rate == F(1)) {
+      if (release_seconds == F(0)) release_rate = F(1);
+      else release_rate = F(1) / (release_seconds * static_cast<F>(sample_rate));
+    }
+  }
+  void process(AudioCtx&, UGenFlags& flags, const F*, F* out) override { out[0] = next_sample(flags, 0); }
+  void process_block(AudioCtx&, UGenFlags& flags, const BlockView<F>&, BlockView<F>& output) override {
+    F* o = output.channel(0);
+    for (size_t i = 0; i < output.frames; ++i) o[i] = next_sample(flags, static_cast<uint32_t>(i));
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    switch (index) {
+      case 0: {
+        F atk = fnew<F>(v.float_or_panic());
+        if (attack_seconds != atk) {
+          attack_seconds = atk;
+          if (atk == F(0)) attack_rate = F(1);
+          else attack_rate = F(1) / (attack_seconds * static_cast<F>(ctx.sample_rate()));
+        }
+      } break;
+      case 1: {
+        F rel = fnew<F>(v.float_or_panic());
+        if (release_seconds != rel) {
+          release_seconds = rel;
+          if (rel == F(0)) release_rate = F(1);
+          else release_rate = F(1) / (release_seconds * static_cast<F>(ctx.sample_rate()));
+        }
+      } break;
+      case 2: state = ArState::Attacking; break;
+      default: ctx.rt_log("Unknown parameter set for EnvAr");
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Constant -- knaster_core_dsp/src/ugens/util.rs:37-64
+// ---------------------------------------------------------------------------
+template <typename F>
+struct Constant : UGen<F> {
+  F value;
+  explicit Constant(F v) : value(v) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"value"}; }
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override { out[0] = value; }
+  void process_block(AudioCtx&, UGenFlags&, const BlockView<F>&, BlockView<F>& output) override {
+    std::fill(output.channel(0), output.channel(0) + output.frames, value);
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    if (index == 0) value = fnew<F>(v.float_or_panic());
+    else ctx.rt_log("Unknown parameter set for Constant");
+  }
+};
+
+// ---------------------------------------------------------------------------
+// MathUGen -- knaster_core_dsp/src/ugens/math.rs:17-165
+// inputs a0..a{N-1}, b0..b{N-1}; out[ch] = a[ch] op b[ch]
+// ---------------------------------------------------------------------------
+enum class MathOp { Add, Sub, Mul, Div, Pow };
+template <typename F>
+inline F math_apply(MathOp op, F a, F b) {
+  switch (op) {
+    case MathOp::Add: return a + b;
+    case MathOp::Sub: return a - b;
+    case MathOp::Mul: return a * b;
+    case MathOp::Div: return a / b;
+    case MathOp::Pow: return std::pow(a, b);
+  }
+  return F(0);
+}
+template <typename F>
+struct MathUGen : UGen<F> {
+  size_t channels;
+  MathOp op;
+  MathUGen(size_t channels_, MathOp op_) : channels(channels_), op(op_) {}
+  size_t inputs() const override { return channels * 2; }
+  size_t outputs() const override { return channels; }
+  size_t parameters() const override { return 0; }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override {
+    for (size_t c = 0; c < channels; ++c) out[c] = math_apply(op, in[c], in[c + channels]);
+  }
+  void process_block(AudioCtx&, UGenFlags&, const BlockView<F>& input, BlockView<F>& output) override {
+    for (size_t c = 0; c < channels; ++c) {
+      const F* a = input.channel(c);
+      const F* b = input.channel(c + channels);
+      F* o = output.channel(c);
+      for (size_t i = 0; i < output.frames; ++i) o[i] = math_apply(op, a[i], b[i]);
+    }
+  }
+  void param_apply(AudioCtx&, size_t, ParameterValue) override {}
+};
+
+// ---------------------------------------------------------------------------
+// Test UGens -- knaster_core_dsp/src/test_utils.rs:8-86,
+// knaster_graph/src/tests/utils.rs:4-67
+// ---------------------------------------------------------------------------
+template <typename F>
+struct TestNumUGen : UGen<F> {
+  F number;
+  explicit TestNumUGen(F n) : number(n) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 0; }
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override { out[0] = number; }
+  void param_apply(AudioCtx&, size_t, ParameterValue) override {}
+};
+template <typename F>
+struct TestInPlusParamUGen : UGen<F> {
+  F number = 0;
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"number"}; }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override { out[0] = number + in[0]; }
+  void param_apply(AudioCtx&, size_t index, ParameterValue v) override {
+    if (index == 0) number = fnew<F>(v.float_or_panic());
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Math wrappers -- knaster_core_dsp/src/wrappers_core/math.rs:15-661
+// All run the inner UGen, then transform every output sample in place.
+// Only WrMul adds a parameter ("wr_mul", index = inner parameters()).
+// ---------------------------------------------------------------------------
+enum class WrOp { Mul, Add, Sub, VSub, Div, VDiv, Powf, Powi };
+template <typename F>
+struct WrMath : UGen<F> {
+  UGenPtr<F> ugen;
+  WrOp op;
+  F value;
+  int32_t ivalue = 0;
+  WrMath(UGenPtr<F> inner, WrOp op_, F v) : ugen(std::move(inner)), op(op_), value(v) {}
+  WrMath(UGenPtr<F> inner, int32_t exponent)
+      : ugen(std::move(inner)), op(WrOp::Powi), value(0), ivalue(exponent) {}
+  size_t inputs() const override { return ugen->inputs(); }
+  size_t outputs() const override { return ugen->outputs(); }
+  size_t parameters() const override { return ugen->parameters() + (op == WrOp::Mul ? 1 : 0); }
+  std::vector<std::string> param_descriptions() const override {
+    auto d = ugen->param_descriptions();
+    d.resize(ugen->parameters());
+    if (op == WrOp::Mul) d.push_back("wr_mul");
+    return d;
+  }
+  void init(uint32_t sr, size_t bs) override { ugen->init(sr, bs); }
+  F apply(F s) const {
+    switch (op) {
+      case WrOp::Mul: return s * value;
+      case WrOp::Add: return s + value;
+      case WrOp::Sub: return s - value;
+      case WrOp::VSub: return value - s;
+      case WrOp::Div: return s / value;
+      case WrOp::VDiv: return value / s;
+      case WrOp::Powf: return std::pow(s, value);
+      case WrOp::Powi: {  // num-traits pow by squaring
+        F base = s, acc = F(1);
+        int32_t n = ivalue < 0 ? -ivalue : ivalue;
+        bool first = true;
+        while (n > 0) {
+          if (n & 1) { acc = first ? base : acc * base; first = false; }
+          n >>= 1;
+          if (n) base = base * base;
+        }
+        return ivalue < 0 ? F(1) / acc : acc;
+      }
+    }
+    return s;
+  }
+  void process(AudioCtx& ctx, UGenFlags& flags, const F* in, F* out) override {
+    ugen->process(ctx, flags, in, out);
+    for (size_t i = 0; i < outputs(); ++i) out[i] = apply(out[i]);
+  }
+  void process_block(AudioCtx& ctx, UGenFlags& flags, const BlockView<F>& input, BlockView<F>& output) override {
+    ugen->process_block(ctx, flags, input, output);  // math.rs:62-67
+    for (size_t c = 0; c < output.channels(); ++c) {
+      F* o = output.channel(c);
+      for (size_t i = 0; i < output.frames; ++i) o[i] = apply(o[i]);
+    }
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    if (op == WrOp::Mul && index == ugen->parameters()) value = fnew<F>(v.float_or_panic());
+    else ugen->param_apply(ctx, index, v);
+  }
+  void set_ar_param_buffer(AudioCtx& ctx, size_t index, const F* buffer) override {
+    ugen->set_ar_param_buffer(ctx, index, buffer);
+  }
+  void set_delay_within_block_for_param(AudioCtx& ctx, size_t index, uint16_t delay) override {
+    ugen->set_delay_within_block_for_param(ctx, index, delay);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// WrArParams -- knaster_core_dsp/src/wrappers_core/audio_rate.rs:11-85
+// Only `process` is defined -> default frame loop -> inner runs per sample.
+// ---------------------------------------------------------------------------
+template <typename F>
+struct WrArParams : UGen<F> {
+  UGenPtr<F> ugen;
+  std::vector<const F*> buffers;
+  size_t block_index = 0;
+  explicit WrArParams(UGenPtr<F> inner) : ugen(std::move(inner)), buffers(ugen->parameters(), nullptr) {}
+  size_t inputs() const override { return ugen->inputs(); }
+  size_t outputs() const override { return ugen->outputs(); }
+  size_t parameters() const override { return ugen->parameters(); }
+  std::vector<std::string> param_descriptions() const override { return ugen->param_descriptions(); }
+  void init(uint32_t sr, size_t bs) override { ugen->init(sr, bs); }
+  void process(AudioCtx& ctx, UGenFlags& flags, const F* in, F* out) override {  // :42-57
+    for (size_t p = 0; p < buffers.size(); ++p)
+      if (buffers[p]) {
+        PFloat value = static_cast<double>(buffers[p][block_index]);
+        ugen->param_apply(ctx, p, ParameterValue::Flt(value));
+      }
+    block_index = (block_index + 1) % ctx.block_size();
+    ugen->process(ctx, flags, in, out);
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {  // :70-74
+    if (buffers[index] == nullptr) ugen->param_apply(ctx, index, v);
+  }
+  void set_ar_param_buffer(AudioCtx&, size_t index, const F* buffer) override {
+    assert(index < buffers.size());
+    buffers[index] = buffer;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// WrPreciseTiming -- knaster_core_dsp/src/wrappers_core/precise_timing.rs:14-149
+// ---------------------------------------------------------------------------
+template <typename F>
+struct WrPreciseTiming : UGen<F> {
+  struct Change {
+    bool some = false;
+    uint16_t delay = 0;
+    size_t index = 0;
+    ParameterValue value;
+  };
+  UGenPtr<F> ugen;
+  std::vector<Change> waiting_changes;  // capacity = DELAYED_CHANGES_PER_BLOCK
+  std::vector<uint16_t> next_delay;     // per parameter; NOT reset after a block
+  size_t next_delay_i = 0;
+  WrPreciseTiming(size_t delayed_changes_per_block, UGenPtr<F> inner)
+      : ugen(std::move(inner)), waiting_changes(delayed_changes_per_block), next_delay(ugen->parameters(), 0) {}
+  size_t inputs() const override { return ugen->inputs(); }
+  size_t outputs() const override { return ugen->outputs(); }
+  size_t parameters() const override { return ugen->parameters(); }
+  std::vector<std::string> param_descriptions() const override { return ugen->param_descriptions(); }
+  void init(uint32_t sr, size_t bs) override { ugen->init(sr, bs); }
+  void process(AudioCtx& ctx, UGenFlags& flags, const F* in, F* out) override {  // :50-64
+    for (auto& wc : waiting_changes)
+      if (wc.some) {
+        wc.some = false;
+        ugen->param_apply(ctx, wc.index, wc.value);
+      }
+    ugen->process(ctx, flags, in, out);
+  }
+  void process_block(AudioCtx& ctx, UGenFlags& flags, const BlockView<F>& input, BlockView<F>& output) override {
+    // precise_timing.rs:65-114
+    size_t block_i = 0, change_i = 0;
+    const BlockMetadata org_block = ctx.block;
+    const size_t num_changes_scheduled = next_delay_i;
+    for (;;) {
+      size_t local_frames_to_process = ctx.frames_to_process() - block_i;
+      while (change_i < num_changes_scheduled) {
+        Change& wc = waiting_changes[change_i];
+        if (wc.some) {
+          if (static_cast<size_t>(wc.delay) <= block_i + ctx.block_start_offset()) {
+            ugen->param_apply(ctx, wc.index, wc.value);
+            wc.some = false;
+          } else {
+            local_frames_to_process = std::min(
+                local_frames_to_process, static_cast<size_t>(wc.delay) - ctx.block_start_offset() - block_i);
+            break;
+          }
+        }
+        change_i += 1;
+      }
+      if (block_i >= ctx.frames_to_process()) break;
+      if (local_frames_to_process == ctx.frames_to_process()) {
+        ugen->process_block(ctx, flags, input, output);
+      } else {
+        BlockView<F> pin = input.partial(block_i, local_frames_to_process);
+        BlockView<F> pout = output.partial(block_i, local_frames_to_process);
+        ctx.block = org_block.make_partial(block_i, local_frames_to_process);
+        ugen->process_block(ctx, flags, pin, pout);
+        ctx.block = org_block;
+      }
+      block_i += local_frames_to_process;
+    }
+    ctx.block = org_block;
+    next_delay_i = 0;
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {  // :126-135
+    if (next_delay[index] == 0) {
+      ugen->param_apply(ctx, index, v);
+    } else if (next_delay_i < waiting_changes.size()) {
+      Change c;
+      c.some = true;
+      c.delay = next_delay[index];
+      c.index = index;
+      c.value = v;
+      waiting_changes[next_delay_i] = c;
+      next_delay_i += 1;
+    } else {
+      ctx.rt_log("Warning: Not enough space for scheduled changes in WrPreciseTiming, change ignored");
+    }
+  }
+  void set_ar_param_buffer(AudioCtx& ctx, size_t index, const F* buffer) override {
+    ugen->set_ar_param_buffer(ctx, index, buffer);
+  }
+  void set_delay_within_block_for_param(AudioCtx&, size_t index, uint16_t delay) override {
+    next_delay[index] = delay;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// BufferAllocator -- knaster_graph/src/buffer_allocator.rs:50-166
+// Works on offsets; the backing store is a std::vector owned by the Graph.
+// ---------------------------------------------------------------------------
+struct BufferAllocator {
+  struct AllocatedBlock {
+    size_t start_offset, len, outstanding_borrows;
+  };
+  size_t next_free_pos = 0;
+  std::vector<AllocatedBlock> allocated_blocks;
+  std::vector<size_t> return_order;
+  size_t virtual_allocation_size = 0;
+  size_t assign_new_block(size_t num_channels, size_t block_size, size_t num_borrows) {
+    if (next_free_pos + num_channels * block_size > virtual_allocation_size)
+      virtual_allocation_size = next_free_pos + num_channels * block_size;
+    size_t start = next_free_pos;
+    allocated_blocks.push_back({start, num_channels * block_size, num_borrows});
+    next_free_pos += num_channels * block_size;
+    return start;
+  }
+  void return_block(size_t start_offset) {
+    for (size_t i = 0; i < allocated_blocks.size(); ++i)
+      if (allocated_blocks[i].start_offset == start_offset) {
+        allocated_blocks[i].outstanding_borrows -= 1;
+        if (allocated_blocks[i].outstanding_borrows == 0) return_order.push_back(i);
+        break;
+      }
+  }
+  size_t get_block(size_t num_channels, size_t block_size, size_t num_borrows) {
+    size_t len = num_channels * block_size;
+    for (size_t k = 0; k < return_order.size(); ++k) {
+      size_t i = return_order.size() - (k + 1);
+      size_t index = return_order[i];
+      if (allocated_blocks[index].outstanding_borrows == 0 && allocated_blocks[index].len >= len) {
+        allocated_blocks[index].outstanding_borrows = num_borrows;
+        return_order.erase(return_order.begin() + static_cast<long>(i));
+        return allocated_blocks[index].start_offset;
+      }
+    }
+    return assign_new_block(num_channels, block_size, num_borrows);
+  }
+  void reset(size_t block_size) {
+    next_free_pos = 0;
+    virtual_allocation_size = 0;
+    allocated_blocks.clear();
+    return_order.clear();
+    get_block(1, block_size, SIZE_MAX);  // the shared zero channel at offset 0
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Scheduling -- knaster_graph/src/scheduling.rs:29-139
+// ---------------------------------------------------------------------------
+struct Time {
+  Seconds seconds;
+  bool absolute = false;
+  static Time at(Seconds s) { return Time{s, true}; }
+  static Time after(Seconds s) { return Time{s, false}; }
+  static Time asap() { return Time{Seconds::zero(), false}; }
+  uint64_t to_samples_until_due(uint64_t block_size, uint64_t sample_rate, uint64_t frame_clock) {
+    if (absolute) {
+      uint64_t t = seconds.to_samples(sample_rate);
+      return t >= frame_clock ? t - frame_clock : 0;  // saturating_sub
+    }
+    if (seconds == Seconds::zero()) return 0;
+    uint64_t samples = seconds.to_samples(sample_rate);
+    seconds = seconds.saturating_sub(Seconds::from_samples(block_size, sample_rate));
+    return samples;
+  }
+};
+using NodeKey = size_t;
+constexpr NodeKey GRAPH_KEY = SIZE_MAX;
+struct SchedulingEvent {
+  NodeKey node_key = 0;
+  size_t parameter = 0;
+  bool has_value = false;
+  ParameterValue value;
+  bool has_time = false;
+  Time time;
+};
+
+// ---------------------------------------------------------------------------
+// Graph + GraphGen + AudioProcessor
+//   knaster_graph/src/graph.rs:768-881 (additive connects), :1588-1704
+//   (allocate_node_buffers), :1938-2067 (node order), task.rs:17-32,
+//   graph_gen.rs:77-305, processor.rs:47-197.
+// Feedback edges, subgraphs, node freeing and the lock-free rings are out of
+// scope (control plane); commit() applies the new schedule synchronously.
+// ---------------------------------------------------------------------------
+struct Edge {
+  bool some = false;
+  NodeKey source = GRAPH_KEY;  // GRAPH_KEY = graph input
+  uint16_t channel_in_source = 0;
+};
+struct ParameterEdge {
+  NodeKey source;
+  uint16_t channel_in_source;
+  uint16_t parameter_index;
+};
+
+template <typename F>
+struct Task {
+  UGen<F>* ugen;
+  std::vector<const F*> in_buffers;
+  F* out_buffer;
+  size_t output_channels;
+  void run(AudioCtx& ctx, UGenFlags& flags) {  // task.rs:25-31
+    BlockView<F> input;
+    input.frames = ctx.block_size();
+    for (const F* p : in_buffers) input.ch.push_back(const_cast<F*>(p));
+    BlockView<F> output(out_buffer, output_channels, ctx.block_size());
+    ugen->process_block(ctx, flags, input, output);
+  }
+};
+
+template <typename F>
+class Graph {
+ public:
+  struct Node {
+    UGenPtr<F> ugen;
+    size_t inputs, outputs;
+    size_t num_output_dependents = 0;
+    size_t output_offset = 0;
+    bool auto_math_node = false;
+    bool alive = true;
+  };
+  Graph(size_t inputs, size_t outputs, size_t block_size, uint32_t sample_rate)
+      : num_inputs(inputs), num_outputs(outputs), block_size_(block_size), sample_rate_(sample_rate),
+        output_edges(outputs), ctx(sample_rate, block_size) {
+    blocks_to_keep_scheduled_changes = sample_rate / static_cast<uint32_t>(block_size);
+  }
+  // graph.rs:462-475: init() runs at push time
+  NodeKey push(UGenPtr<F> ugen) {
+    ugen->init(sample_rate_, block_size_);
+    Node n;
+    n.inputs = ugen->inputs();
+    n.outputs = ugen->outputs();
+    n.ugen = std::move(ugen);
+    nodes.push_back(std::move(n));
+    node_input_edges.emplace_back(nodes.back().inputs);
+    node_parameter_edges.emplace_back();
+    recalculation_required = true;
+    return nodes.size() - 1;
+  }
+  UGen<F>* ugen(NodeKey k) { return nodes[k].ugen.get(); }
+  // graph.rs:768-822
+  void connect_to_node(NodeKey source, uint16_t so_channel, uint16_t si_channel, NodeKey sink, bool additive) {
+    recalculation_required = true;
+    Edge e{true, source, so_channel};
+    if (!additive || !node_input_edges[sink][si_channel].some) {
+      node_input_edges[sink][si_channel] = e;
+      return;
+    }
+    Edge existing = node_input_edges[sink][si_channel];
+    NodeKey add_node = new_additive_node();
+    node_input_edges[add_node][0] = existing;
+    node_input_edges[add_node][1] = e;
+    node_input_edges[sink][si_channel] = Edge{true, add_node, 0};
+  }
+  // graph.rs:827-872
+  void connect_to_output(NodeKey source, uint16_t so_channel, uint16_t si_channel, bool additive) {
+    recalculation_required = true;
+    Edge e{true, source, so_channel};
+    if (!additive || !output_edges[si_channel].some) {
+      output_edges[si_channel] = e;
+      return;
+    }
+    Edge existing = output_edges[si_channel];
+    NodeKey add_node = new_additive_node();
+    node_input_edges[add_node][0] = existing;
+    node_input_edges[add_node][1] = e;
+    output_edges[si_channel] = Edge{true, add_node, 0};
+  }
+  // graph.rs:629-726 (replace form): audio-rate parameter edge
+  void connect_to_parameter(NodeKey source, uint16_t so_channel, uint16_t parameter, NodeKey sink) {
+    recalculation_required = true;
+    auto& pe = node_parameter_edges[sink];
+    for (auto& e : pe)
+      if (e.parameter_index == parameter) {
+        e.source = source;
+        e.channel_in_source = so_channel;
+        return;
+      }
+    pe.push_back(ParameterEdge{source, so_channel, parameter});
+  }
+  void disconnect_output_from_source(NodeKey source, uint16_t so_channel) {
+    recalculation_required = true;
+    for (auto& edges : node_input_edges)
+      for (auto& e : edges)
+        if (e.some && e.source == source && e.channel_in_source == so_channel) e.some = false;
+    for (auto& e : output_edges)
+      if (e.some && e.source == source && e.channel_in_source == so_channel) e.some = false;
+  }
+  void disconnect_input_to_sink(uint16_t si_channel, NodeKey sink) {
+    recalculation_required = true;
+    node_input_edges[sink][si_channel].some = false;
+  }
+  // `sig * c` / `sig + c`: graph_edit.rs:1036-1066 pushes Constant first, then the MathUGen,
+  // connects ch0 <- sig, ch1 <- constant.
+  NodeKey math_with_constant(NodeKey sig, uint16_t sig_channel, MathOp op, F c) {
+    NodeKey cn = push(std::make_unique<Constant<F>>(c));
+    NodeKey m = push(std::make_unique<MathUGen<F>>(1, op));
+    connect_to_node(sig, sig_channel, 0, m, false);
+    connect_to_node(cn, 0, 1, m, false);
+    return m;
+  }
+  // `a * b` between two single-channel sources (graph_edit.rs:936-971)
+  NodeKey math_nodes(NodeKey a, uint16_t a_ch, MathOp op, NodeKey b, uint16_t b_ch) {
+    NodeKey m = push(std::make_unique<MathUGen<F>>(1, op));
+    connect_to_node(a, a_ch, 0, m, false);
+    connect_to_node(b, b_ch, 1, m, false);
+    return m;
+  }
+
+  // param.set(v) / set_at(v, t): graph_edit.rs:1708-1753
+  void schedule(const SchedulingEvent& ev) { scheduling_queue.push_back(ev); }
+  void set(NodeKey node, size_t param, ParameterValue v) {
+    SchedulingEvent ev;
+    ev.node_key = node;
+    ev.parameter = param;
+    ev.has_value = true;
+    ev.value = v;
+    schedule(ev);
+  }
+  void set_at(NodeKey node, size_t param, ParameterValue v, Time t) {
+    SchedulingEvent ev;
+    ev.node_key = node;
+    ev.parameter = param;
+    ev.has_value = true;
+    ev.value = v;
+    ev.has_time = true;
+    ev.time = t;
+    schedule(ev);
+  }
+
+  // graph.rs:1707-1726
+  void commit_changes() {
+    if (!recalculation_required) return;
+    calculate_node_order();
+    allocate_node_buffers();
+    generate_tasks();
+    recalculation_required = false;
+  }
+
+  // AudioProcessor::run_raw_ptr_inputs, processor.rs:142-179 + GraphGen::process_block
+  void run(const std::vector<const F*>& input_pointers, F* output /* [outputs][block_size] */) {
+    assert(input_pointers.size() == num_inputs);
+    ctx.block = BlockMetadata{};
+    ctx.block.frames_to_process = block_size_;
+    ctx.block.frame_clock = frame_clock;
+    // (ii) parameter changes, graph_gen.rs:110-166
+    size_t n_waiting = waiting_parameter_changes.size();
+    for (size_t i = 0; i < n_waiting; ++i) {
+      auto [event, num_blocks_waiting] = waiting_parameter_changes.front();
+      waiting_parameter_changes.pop_front();
+      if (num_blocks_waiting > blocks_to_keep_scheduled_changes) continue;
+      SchedulingEvent un;
+      if (!apply_parameter_change(event, &un)) waiting_parameter_changes.emplace_back(un, num_blocks_waiting + 1);
+    }
+    for (auto& ev : scheduling_queue) {
+      SchedulingEvent un;
+      if (!apply_parameter_change(ev, &un)) waiting_parameter_changes.emplace_back(un, 0);
+    }
+    scheduling_queue.clear();
+    // (iii) patch graph-input pointers, graph_gen.rs:187-194
+    for (auto& [task_index, pairs] : graph_input_channels_to_nodes)
+      for (auto& [graph_input, node_input] : pairs) tasks[task_index].in_buffers[node_input] = input_pointers[graph_input];
+    // (iv) HOT LOOP graph_gen.rs:196-200
+    UGenFlags new_flags;
+    for (auto& task : tasks) task.run(ctx, new_flags);
+    last_flags = new_flags;
+    // (v) outputs graph_gen.rs:202-224
+    for (size_t c = 0; c < num_outputs; ++c) {
+      F* out_channel = output + c * block_size_;
+      const Edge& e = output_edges[c];
+      if (e.some) {
+        const F* src = e.source == GRAPH_KEY ? input_pointers[e.channel_in_source]
+                                             : buffer.data() + nodes[e.source].output_offset +
+                                                   static_cast<size_t>(e.channel_in_source) * block_size_;
+        std::memcpy(out_channel, src, block_size_ * sizeof(F));
+      } else {
+        std::fill(out_channel, out_channel + block_size_, F(0));
+      }
+    }
+    frame_clock += block_size_;
+  }
+  const std::vector<NodeKey>& order() const { return node_order; }
+  size_t buffer_len() const { return buffer.size(); }
+  size_t num_tasks() const { return tasks.size(); }
+  AudioCtx& audio_ctx() { return ctx; }
+  UGenFlags last_flags;
+  uint64_t frame_clock = 0;
+
+ private:
+  NodeKey new_additive_node() {  // graph.rs:874-881
+    NodeKey k = push(std::make_unique<MathUGen<F>>(1, MathOp::Add));
+    nodes[k].auto_math_node = true;
+    return k;
+  }
+  // graph.rs:1938-1980
+  std::vector<NodeKey> depth_first_search(std::unordered_set<NodeKey>& visited, std::vector<NodeKey>& nodes_to_process) {
+    std::vector<NodeKey> order;
+    while (!nodes_to_process.empty()) {
+      NodeKey node_key = nodes_to_process.back();
+      bool found_unvisited = false;
+      for (const Edge& e : node_input_edges[node_key]) {
+        if (!e.some) continue;
+        if (e.source != GRAPH_KEY && !visited.count(e.source)) {
+          nodes_to_process.push_back(e.source);
+          visited.insert(e.source);
+          found_unvisited = true;
+          break;
+        }
+      }
+      if (!found_unvisited) {
+        for (const ParameterEdge& e : node_parameter_edges[node_key]) {
+          if (!visited.count(e.source)) {
+            nodes_to_process.push_back(e.source);
+            visited.insert(e.source);
+            found_unvisited = true;
+            break;
+          }
+        }
+      }
+      if (!found_unvisited) {
+        order.push_back(nodes_to_process.back());
+        nodes_to_process.pop_back();
+      }
+    }
+    return order;
+  }
+  // graph.rs:1984-2018
+  NodeKey get_deepest_output_node(NodeKey start_node, const std::unordered_set<NodeKey>& visited) {
+    NodeKey last_connected = start_node, last_connected_output = start_node;
+    for (;;) {
+      bool found_later = false;
+      for (NodeKey key = 0; key < node_input_edges.size() && !found_later; ++key) {
+        for (const Edge& ie : node_input_edges[key]) {
+          if (!ie.some || ie.source == GRAPH_KEY) continue;
+          if (ie.source == last_connected && !visited.count(ie.source)) {
+            last_connected = key;
+            found_later = true;
+            for (const Edge& oe : output_edges)
+              if (oe.some && oe.source != GRAPH_KEY && oe.source == last_connected) last_connected_output = last_connected;
+            break;
+          }
+        }
+      }
+      if (!found_later) break;
+    }
+    return last_connected_output;
+  }
+  // graph.rs:2022-2067
+  void calculate_node_order() {
+    node_order.clear();
+    std::unordered_set<NodeKey> visited;
+    std::vector<NodeKey> nodes_to_process;
+    for (const Edge& e : output_edges) {
+      if (!e.some || e.source == GRAPH_KEY) continue;
+      NodeKey deepest = get_deepest_output_node(e.source, visited);
+      if (!visited.count(deepest)) {
+        nodes_to_process.push_back(deepest);
+        visited.insert(deepest);
+      }
+    }
+    auto stack = depth_first_search(visited, nodes_to_process);
+    node_order.insert(node_order.end(), stack.begin(), stack.end());
+    for (NodeKey k = 0; k < nodes.size(); ++k)
+      if (!visited.count(k)) node_order.push_back(k);
+  }
+  // graph.rs:1588-1704
+  void allocate_node_buffers() {
+    for (auto& n : nodes) n.num_output_dependents = 0;
+    for (auto& edges : node_input_edges)
+      for (const Edge& e : edges)
+        if (e.some && e.source != GRAPH_KEY) nodes[e.source].num_output_dependents += 1;
+    for (auto& edges : node_parameter_edges)
+      for (const ParameterEdge& e : edges) nodes[e.source].num_output_dependents += 1;
+    graph_input_channels_to_nodes.clear();
+    allocator.reset(block_size_);
+    for (size_t order_index = 0; order_index < node_order.size(); ++order_index) {
+      NodeKey key = node_order[order_index];
+      size_t offset = allocator.get_block(nodes[key].outputs, block_size_, nodes[key].num_output_dependents);
+      nodes[key].output_offset = offset;
+      std::vector<std::pair<size_t, size_t>> from_graph;
+      for (size_t ch = 0; ch < node_input_edges[key].size(); ++ch) {
+        const Edge& e = node_input_edges[key][ch];
+        if (!e.some) continue;
+        if (e.source != GRAPH_KEY) allocator.return_block(nodes[e.source].output_offset);
+        else from_graph.emplace_back(e.channel_in_source, ch);
+      }
+      for (const ParameterEdge& e : node_parameter_edges[key]) allocator.return_block(nodes[e.source].output_offset);
+      if (!from_graph.empty()) graph_input_channels_to_nodes.emplace_back(order_index, from_graph);
+    }
+    if (allocator.virtual_allocation_size > buffer.size()) buffer.assign(allocator.virtual_allocation_size, F(0));
+    // offset 0..block_size is the shared zero channel: keep it cleared
+    std::fill(buffer.begin(), buffer.begin() + static_cast<long>(block_size_), F(0));
+  }
+  // graph.rs:1497-1562 generate_tasks + generate_ar_parameter_changes; task.rs:101-131
+  void generate_tasks() {
+    tasks.clear();
+    for (NodeKey key : node_order) {
+      Task<F> t;
+      t.ugen = nodes[key].ugen.get();
+      t.out_buffer = buffer.data() + nodes[key].output_offset;
+      t.output_channels = nodes[key].outputs;
+      t.in_buffers.assign(nodes[key].inputs, buffer.data());  // zero channel by default
+      for (size_t ch = 0; ch < node_input_edges[key].size(); ++ch) {
+        const Edge& e = node_input_edges[key][ch];
+        if (e.some && e.source != GRAPH_KEY)
+          t.in_buffers[ch] = buffer.data() + nodes[e.source].output_offset +
+                             static_cast<size_t>(e.channel_in_source) * block_size_;
+      }
+      tasks.push_back(std::move(t));
+    }
+    for (NodeKey key = 0; key < nodes.size(); ++key)
+      for (const ParameterEdge& e : node_parameter_edges[key]) {
+        const F* buf = buffer.data() + nodes[e.source].output_offset +
+                       static_cast<size_t>(e.channel_in_source) * block_size_;
+        nodes[key].ugen->set_ar_param_buffer(ctx, e.parameter_index, buf);
+      }
+  }
+  // graph_gen.rs:269-305.  Returns true if applied.
+  bool apply_parameter_change(SchedulingEvent event, SchedulingEvent* unapplied) {
+    bool ready = true;
+    uint64_t delay_in_block = 0;
+    if (event.has_time) {
+      delay_in_block = event.time.to_samples_until_due(block_size_, sample_rate_, ctx.frame_clock());
+      ready = ready && (delay_in_block < block_size_);
+    }
+    if (ready) {
+      for (NodeKey key : node_order) {
+        if (key == event.node_key) {
+          UGen<F>* g = nodes[key].ugen.get();
+          if (delay_in_block > 0)
+            g->set_delay_within_block_for_param(ctx, event.parameter, static_cast<uint16_t>(delay_in_block));
+          if (event.has_value) g->param_apply(ctx, event.parameter, event.value);
+          return true;
+        }
+      }
+    }
+    *unapplied = event;
+    return false;
+  }
+
+  size_t num_inputs, num_outputs, block_size_;
+  uint32_t sample_rate_;
+  std::vector<Node> nodes;
+  std::vector<std::vector<Edge>> node_input_edges;
+  std::vector<std::vector<ParameterEdge>> node_parameter_edges;
+  std::vector<Edge> output_edges;
+  std::vector<NodeKey> node_order;
+  BufferAllocator allocator;
+  std::vector<F> buffer;
+  std::vector<Task<F>> tasks;
+  std::vector<std::pair<size_t, std::vector<std::pair<size_t, size_t>>>> graph_input_channels_to_nodes;
+  std::vector<SchedulingEvent> scheduling_queue;
+  std::deque<std::pair<SchedulingEvent, uint32_t>> waiting_parameter_changes;
+  uint32_t blocks_to_keep_scheduled_changes;
+  bool recalculation_required = true;
+  AudioCtx ctx;
+};
+
+}  // namespace kno

@@ -1,0 +1,240 @@
+// oracle_bank.hpp -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+//
+// Builds, for a voice-chain descriptor of include/knaster_hip.h, the UNFUSED
+// node graph the reference would run for it: one node per UGen, operator nodes
+// (Constant + MathUGen) exactly as graph_edit.rs:1036-1066 creates them, and a
+// linear chain of MathUGen<Add> for the additive graph output
+// (knaster_graph/src/graph.rs:827-872).  Parity status: see knaster_oracle.hpp.
+#pragma once
+#include <stdexcept>
+#include <thread>
+
+#include "../include/knaster_hip.h"
+#include "knaster_oracle.hpp"
+
+namespace kno {
+
+inline int stage_n_ctor_args(uint16_t kind) {
+  switch (kind) {
+    case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: return 1;
+    case KNH_STAGE_SVF: return 4;
+    case KNH_STAGE_ONEPOLE_LPF: return 1;
+    case KNH_STAGE_ONEPOLE_HPF: return 0;
+    case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: return 2;
+    case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: return 1;
+    case KNH_STAGE_WR_MUL: case KNH_STAGE_WR_ADD: case KNH_STAGE_WR_SUB: return 1;
+  }
+  return 0;
+}
+inline bool stage_is_wrapper(uint16_t kind) {
+  return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB;
+}
+
+// Where a (voice, stage) parameter lives in a built graph.
+struct ParamTarget {
+  NodeKey node = 0;
+  size_t index_offset = 0;  // added to the stage-local parameter index
+  size_t n_params = 0;
+};
+
+template <typename F>
+struct VoiceChainBuilder {
+  const std::vector<knh_stage_desc>& stages;
+  explicit VoiceChainBuilder(const std::vector<knh_stage_desc>& s) : stages(s) {}
+
+  // Builds one voice in `g`, returns the node producing the voice's signal and
+  // fills targets[stage].  args[stage] = ctor args of this voice.
+  NodeKey build(Graph<F>& g, const std::vector<std::vector<double>>& args, std::vector<ParamTarget>& targets) {
+    targets.assign(stages.size(), ParamTarget{});
+    bool have_x = false;
+    NodeKey x = 0;
+    for (size_t s = 0; s < stages.size(); ++s) {
+      const knh_stage_desc& st = stages[s];
+      if (stage_is_wrapper(st.kind)) throw std::runtime_error("wrapper stage without a node to wrap");
+      const std::vector<double>& a = args[s];
+      // Core UGen of the stage (the parameterised node).
+      UGenPtr<F> core;
+      switch (st.kind) {
+        case KNH_STAGE_SIN_WT: core = std::make_unique<SinWt<F>>(fnew<F>(a[0])); break;
+        case KNH_STAGE_SIN_NUMERIC: core = std::make_unique<SinNumeric<F>>(fnew<F>(a[0])); break;
+        case KNH_STAGE_SVF:
+          core = std::make_unique<SvfFilter<F>>(svf_type_from_pinteger(static_cast<uint64_t>(a[0])), fnew<F>(a[1]),
+                                                fnew<F>(a[2]), fnew<F>(a[3]));
+          break;
+        case KNH_STAGE_ONEPOLE_LPF: core = std::make_unique<OnePoleLpf<F>>(fnew<F>(a[0])); break;
+        case KNH_STAGE_ONEPOLE_HPF: core = std::make_unique<OnePoleHpf<F>>(); break;
+        case KNH_STAGE_MUL_ENV_ASR: core = std::make_unique<EnvAsr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
+        case KNH_STAGE_MUL_ENV_AR: core = std::make_unique<EnvAr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
+        case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST:
+          core = std::make_unique<Constant<F>>(fnew<F>(a[0]));
+          break;
+        default: throw std::runtime_error("unknown stage kind");
+      }
+      const bool two_node = st.kind >= KNH_STAGE_MUL_ENV_ASR && st.kind <= KNH_STAGE_DIV_CONST;
+      targets[s].n_params = core->parameters();
+      if (st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ)) core = std::make_unique<WrArParams<F>>(std::move(core));
+      // Wrapper stages that follow wrap the node producing x.  For single-node
+      // stages that is `core`; for two-node stages it is the MathUGen.
+      UGenPtr<F> math;
+      if (two_node) {
+        MathOp op = MathOp::Mul;
+        if (st.kind == KNH_STAGE_ADD_CONST) op = MathOp::Add;
+        if (st.kind == KNH_STAGE_SUB_CONST) op = MathOp::Sub;
+        if (st.kind == KNH_STAGE_DIV_CONST) op = MathOp::Div;
+        math = std::make_unique<MathUGen<F>>(1, op);
+      }
+      UGenPtr<F>& wrapped = two_node ? math : core;
+      size_t s2 = s + 1;
+      std::vector<std::pair<size_t, size_t>> wr_targets;  // (stage, param offset)
+      while (s2 < stages.size() && stage_is_wrapper(stages[s2].kind)) {
+        size_t off = wrapped->parameters();
+        WrOp op = stages[s2].kind == KNH_STAGE_WR_MUL ? WrOp::Mul : stages[s2].kind == KNH_STAGE_WR_ADD ? WrOp::Add : WrOp::Sub;
+        wrapped = std::make_unique<WrMath<F>>(std::move(wrapped), op, fnew<F>(args[s2][0]));
+        wr_targets.emplace_back(s2, off);
+        ++s2;
+      }
+      // WrPreciseTiming is outermost (precise_timing.rs:13).
+      if (st.delayed_changes_per_block > 0) core = std::make_unique<WrPreciseTiming<F>>(st.delayed_changes_per_block, std::move(core));
+      if (two_node && !wr_targets.empty() && stages[s2 - 1].delayed_changes_per_block > 0)
+        math = std::make_unique<WrPreciseTiming<F>>(stages[s2 - 1].delayed_changes_per_block, std::move(math));
+
+      const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC;
+      const bool ar = st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ);
+      NodeKey core_key = g.push(std::move(core));
+      targets[s].node = core_key;
+      NodeKey out_key = core_key;
+      if (is_source) {
+        if (ar) {
+          if (!have_x) throw std::runtime_error("AR_FREQ stage needs a preceding signal");
+          g.connect_to_parameter(x, 0, 0, core_key);
+        } else if (have_x) {
+          throw std::runtime_error("a source stage must be first in the chain");
+        }
+      } else if (!two_node) {
+        if (!have_x) throw std::runtime_error("processor stage needs a preceding signal");
+        g.connect_to_node(x, 0, 0, core_key, false);
+      } else {
+        if (!have_x) throw std::runtime_error("math stage needs a preceding signal");
+        NodeKey m = g.push(std::move(math));
+        g.connect_to_node(x, 0, 0, m, false);
+        g.connect_to_node(core_key, 0, 1, m, false);
+        out_key = m;
+      }
+      for (auto& [ws, off] : wr_targets) {
+        targets[ws].node = out_key;
+        targets[ws].index_offset = off;
+        targets[ws].n_params = stages[ws].kind == KNH_STAGE_WR_MUL ? 1 : 0;
+      }
+      x = out_key;
+      have_x = true;
+      s = s2 - 1;
+    }
+    if (!have_x) throw std::runtime_error("empty chain");
+    return x;
+  }
+};
+
+// An oracle voice bank: the reference-shaped graph for the mix, and (optionally)
+// one single-voice graph per voice to observe each voice's own signal.
+template <typename F>
+struct OracleBank {
+  std::vector<knh_stage_desc> stages;
+  uint32_t n_voices, out_channels;
+  std::vector<std::vector<std::vector<double>>> ctor;  // [voice][stage][arg]
+  bool want_mix, want_voices;
+  uint32_t sample_rate = 0;
+  size_t block_size = 0;
+  std::unique_ptr<Graph<F>> mix_graph;
+  std::vector<std::vector<ParamTarget>> mix_targets;
+  std::vector<std::unique_ptr<Graph<F>>> voice_graphs;
+  std::vector<std::vector<ParamTarget>> voice_targets;
+  std::vector<F> voice_block;  // [n_voices][block_size], last processed block
+  std::vector<uint32_t> done_frames;
+
+  OracleBank(const knh_stage_desc* st, uint32_t n_stages, uint32_t nv, uint32_t oc, bool mix, bool voices)
+      : stages(st, st + n_stages), n_voices(nv), out_channels(oc), want_mix(mix), want_voices(voices) {
+    ctor.assign(nv, std::vector<std::vector<double>>(n_stages));
+    for (uint32_t v = 0; v < nv; ++v)
+      for (uint32_t s = 0; s < n_stages; ++s) ctor[v][s].assign(static_cast<size_t>(stage_n_ctor_args(stages[s].kind)), 0.0);
+  }
+  void init(uint32_t sr, size_t bs) {
+    sample_rate = sr;
+    block_size = bs;
+    VoiceChainBuilder<F> b(stages);
+    if (want_mix) {
+      mix_graph = std::make_unique<Graph<F>>(0, out_channels, bs, sr);
+      mix_targets.resize(n_voices);
+      for (uint32_t v = 0; v < n_voices; ++v) {
+        NodeKey x = b.build(*mix_graph, ctor[v], mix_targets[v]);
+        for (uint32_t c = 0; c < out_channels; ++c) mix_graph->connect_to_output(x, 0, static_cast<uint16_t>(c), true);
+      }
+      mix_graph->commit_changes();
+    }
+    if (want_voices) {
+      voice_targets.resize(n_voices);
+      for (uint32_t v = 0; v < n_voices; ++v) {
+        voice_graphs.push_back(std::make_unique<Graph<F>>(0, 1, bs, sr));
+        NodeKey x = b.build(*voice_graphs[v], ctor[v], voice_targets[v]);
+        voice_graphs[v]->connect_to_output(x, 0, 0, true);
+        voice_graphs[v]->commit_changes();
+      }
+      voice_block.assign(static_cast<size_t>(n_voices) * bs, F(0));
+      done_frames.assign(n_voices, 0xFFFFFFFFu);
+    }
+  }
+  template <typename Fn>
+  void for_targets(uint32_t voice, uint32_t stage, Fn&& fn) {
+    if (want_mix) fn(*mix_graph, mix_targets[voice][stage]);
+    if (want_voices) fn(*voice_graphs[voice], voice_targets[voice][stage]);
+  }
+  int param_apply(uint32_t voice, uint32_t stage, uint32_t param, ParameterValue v) {
+    if (voice >= n_voices || stage >= stages.size()) return KNH_ERR_OUT_OF_RANGE;
+    int rc = KNH_OK;
+    for_targets(voice, stage, [&](Graph<F>& g, const ParamTarget& t) {
+      if (param >= t.n_params) { rc = KNH_ERR_OUT_OF_RANGE; return; }
+      g.ugen(t.node)->param_apply(g.audio_ctx(), t.index_offset + param, v);
+    });
+    return rc;
+  }
+  int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) {
+    if (voice >= n_voices || stage >= stages.size()) return KNH_ERR_OUT_OF_RANGE;
+    int rc = KNH_OK;
+    for_targets(voice, stage, [&](Graph<F>& g, const ParamTarget& t) {
+      if (param >= t.n_params) { rc = KNH_ERR_OUT_OF_RANGE; return; }
+      g.ugen(t.node)->set_delay_within_block_for_param(g.audio_ctx(), t.index_offset + param, delay);
+    });
+    return rc;
+  }
+  // Through GraphGen's event path with a Time (graph_gen.rs:269-305).
+  int schedule(uint32_t voice, uint32_t stage, uint32_t param, ParameterValue v, bool has_time, Time t) {
+    if (voice >= n_voices || stage >= stages.size()) return KNH_ERR_OUT_OF_RANGE;
+    int rc = KNH_OK;
+    for_targets(voice, stage, [&](Graph<F>& g, const ParamTarget& tg) {
+      if (param >= tg.n_params) { rc = KNH_ERR_OUT_OF_RANGE; return; }
+      if (has_time) g.set_at(tg.node, tg.index_offset + param, v, t);
+      else g.set(tg.node, tg.index_offset + param, v);
+    });
+    return rc;
+  }
+  // out: [out_channels][block_size] (may be null).  Returns KNH_FLAG_*.
+  uint32_t process_block(F* out) {
+    uint32_t flags = 0;
+    if (want_mix) {
+      std::vector<F> tmp;
+      if (!out) { tmp.resize(out_channels * block_size); out = tmp.data(); }
+      mix_graph->run({}, out);
+      if (mix_graph->last_flags.done_) flags |= KNH_FLAG_ANY_DONE;
+    }
+    if (want_voices) {
+      for (uint32_t v = 0; v < n_voices; ++v) {
+        voice_graphs[v]->run({}, voice_block.data() + static_cast<size_t>(v) * block_size);
+        uint32_t f = 0xFFFFFFFFu;
+        done_frames[v] = voice_graphs[v]->last_flags.done(&f) ? f : 0xFFFFFFFFu;
+        if (done_frames[v] != 0xFFFFFFFFu) flags |= KNH_FLAG_ANY_DONE;
+      }
+    }
+    return flags;
+  }
+};
+
+}  // namespace kno
