@@ -1,0 +1,195 @@
+"""VoiceBank: a numpy-friendly handle on one `knh_bank` (include/knaster_hip.h).
+
+Mirrors the reference's UGen surface for the bank node -- init / param_apply /
+set_delay_within_block_for_param / process_block (knaster_core/src/ugen.rs:232-369) --
+and adds nothing of its own: every method is one C-ABI call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+TRIGGER = object()  # PTrigger
+
+
+@dataclass(frozen=True)
+class Stage:
+    kind: int
+    flags: int = 0
+    delayed_changes_per_block: int = 0  # > 0: wrapped in WrPreciseTiming<N, _>
+
+
+def _stage_array(stages: Sequence[Stage]):
+    arr = (L.StageDesc * len(stages))()
+    for i, s in enumerate(stages):
+        arr[i].kind = s.kind
+        arr[i].flags = s.flags
+        arr[i].delayed_changes_per_block = s.delayed_changes_per_block
+    return arr
+
+
+def chain_ugen_count(stages: Sequence[Stage]) -> int:
+    return int(L.load().knh_chain_ugen_count(_stage_array(stages), len(stages)))
+
+
+class VoiceBank:
+    def __init__(self, stages: Sequence[Stage], n_voices: int, sample_type: int = L.F32, out_channels: int = 2,
+                 mix_mode: int = L.MIX_TREE, device: int = -1, allow_fma: bool = False):
+        self._lib = L.load()
+        self.stages = list(stages)
+        self.n_voices = int(n_voices)
+        self.sample_type = sample_type
+        self.dtype = np.float64 if sample_type == L.F64 else np.float32
+        self.out_channels = out_channels
+        self._stage_arr = _stage_array(self.stages)
+        desc = L.BankDesc(L.KNH_ABI_VERSION, self.n_voices, sample_type, len(self.stages), self._stage_arr,
+                          out_channels, mix_mode, device, 1 if allow_fma else 0)
+        h = C.c_void_p()
+        rc = self._lib.knh_bank_create(C.byref(desc), C.byref(h))
+        if rc != L.OK:
+            raise L.KnasterHipError(rc, (self._lib.knh_last_error(None) or b"").decode())
+        self._h = h
+        self.block_size = 0
+        self.sample_rate = 0
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.knh_bank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != L.OK:
+            raise L.KnasterHipError(rc, (self._lib.knh_last_error(self._h) or b"").decode())
+
+    # -- construction -----------------------------------------------------------------------
+    def set_ctor_args(self, stage: int, args, first_voice: int = 0):
+        """args: [count, n_args] constructor arguments (e.g. SinWt::new(freq)) for consecutive voices."""
+        a = np.ascontiguousarray(np.asarray(args, dtype=np.float64))
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        self._check(self._lib.knh_bank_set_ctor_args(self._h, stage, first_voice, a.shape[0],
+                                                     a.ctypes.data_as(C.c_void_p), a.shape[1]))
+
+    def init(self, sample_rate: int, block_size: int):
+        self._check(self._lib.knh_bank_init(self._h, sample_rate, block_size))
+        self.sample_rate, self.block_size = sample_rate, block_size
+
+    # -- UGen surface -----------------------------------------------------------------------
+    def inputs(self) -> int:
+        return int(self._lib.knh_bank_inputs(self._h))
+
+    def outputs(self) -> int:
+        return int(self._lib.knh_bank_outputs(self._h))
+
+    def stage_parameters(self, stage: int) -> int:
+        return int(self._lib.knh_bank_stage_parameters(self._h, stage))
+
+    def stage_param_descriptions(self, stage: int):
+        out = []
+        for p in range(self.stage_parameters(stage)):
+            d = self._lib.knh_bank_stage_param_description(self._h, stage, p)
+            out.append(d.decode() if d else None)
+        return out
+
+    @staticmethod
+    def _value(value):
+        if value is TRIGGER:
+            return L.VALUE_TRIGGER, 0.0, 0
+        if isinstance(value, (bool, np.bool_)):
+            return L.VALUE_BOOL, 0.0, int(value)
+        if isinstance(value, (int, np.integer)):
+            return L.VALUE_INTEGER, 0.0, int(value)
+        return L.VALUE_FLOAT, float(value), 0
+
+    def param_apply(self, voice: int, stage: int, param: int, value):
+        kind, f, i = self._value(value)
+        self._check(self._lib.knh_bank_param_apply(self._h, voice, stage, param, kind, f, i))
+
+    def param(self, voice: int, stage: int, param, value):
+        """UGen::param: index or description -> param_apply (ugen.rs:344-368)."""
+        if isinstance(param, str):
+            descs = self.stage_param_descriptions(stage)
+            if param not in descs:
+                raise KeyError(f"DescriptionNotFound({param!r})")
+            param = descs.index(param)
+        self.param_apply(voice, stage, param, value)
+
+    def set_delay_within_block_for_param(self, voice: int, stage: int, param: int, delay: int):
+        self._check(self._lib.knh_bank_set_delay_within_block_for_param(self._h, voice, stage, param, delay))
+
+    def param_apply_many(self, voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None):
+        v = np.ascontiguousarray(voices, dtype=np.uint32)
+        n = v.shape[0]
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(stages, dtype=np.uint32), (n,)))
+        p = np.ascontiguousarray(np.broadcast_to(np.asarray(params, dtype=np.uint32), (n,)))
+        k = np.ascontiguousarray(np.broadcast_to(np.asarray(kinds, dtype=np.uint32), (n,)))
+        f = None if fvalues is None else np.ascontiguousarray(np.broadcast_to(np.asarray(fvalues, dtype=np.float64), (n,)))
+        i = None if ivalues is None else np.ascontiguousarray(np.broadcast_to(np.asarray(ivalues, dtype=np.int64), (n,)))
+        d = None if delays is None else np.ascontiguousarray(np.broadcast_to(np.asarray(delays, dtype=np.uint16), (n,)))
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.knh_bank_param_apply_many(self._h, n, ptr(v), ptr(s), ptr(p), ptr(k), ptr(f), ptr(i), ptr(d)))
+
+    def process_block(self, frames_to_process: Optional[int] = None, block_start_offset: int = 0, frame_clock: int = 0,
+                      out: Optional[np.ndarray] = None):
+        ftp = self.block_size if frames_to_process is None else frames_to_process
+        if out is None:
+            out = np.zeros((self.out_channels, self.block_size), dtype=self.dtype)
+        flags = C.c_uint32(0)
+        self._check(self._lib.knh_bank_process_block(self._h, ftp, block_start_offset, frame_clock,
+                                                     out.ctypes.data_as(C.c_void_p), C.byref(flags)))
+        return out, int(flags.value)
+
+    def process_block_voices(self, frames_to_process: Optional[int] = None, block_start_offset: int = 0, frame_clock: int = 0):
+        ftp = self.block_size if frames_to_process is None else frames_to_process
+        out = np.zeros((self.out_channels, self.block_size), dtype=self.dtype)
+        voices = np.zeros((self.n_voices, self.block_size), dtype=self.dtype)
+        flags = C.c_uint32(0)
+        self._check(self._lib.knh_bank_process_block_voices(self._h, ftp, block_start_offset, frame_clock,
+                                                            out.ctypes.data_as(C.c_void_p),
+                                                            voices.ctypes.data_as(C.c_void_p), C.byref(flags)))
+        return out, voices, int(flags.value)
+
+    def process_block_device(self, out_device_ptr: int = 0, hip_stream: int = 0, frames_to_process: Optional[int] = None,
+                             block_start_offset: int = 0, frame_clock: int = 0):
+        ftp = self.block_size if frames_to_process is None else frames_to_process
+        self._check(self._lib.knh_bank_process_block_device(self._h, ftp, block_start_offset, frame_clock,
+                                                            C.c_void_p(out_device_ptr or None), C.c_void_p(hip_stream or None)))
+
+    def read_done_frames(self) -> np.ndarray:
+        d = np.zeros(self.n_voices, dtype=np.uint32)
+        self._check(self._lib.knh_bank_read_done_frames(self._h, d.ctypes.data_as(C.c_void_p)))
+        return d
+
+    def synchronize(self):
+        self._check(self._lib.knh_bank_synchronize(self._h))
+
+    def timing_reset(self, enable: bool = True):
+        self._check(self._lib.knh_bank_timing_reset(self._h, 1 if enable else 0))
+
+    def timing_read(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._check(self._lib.knh_bank_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def algorithmic_bytes_per_voice_block(self):
+        r, w = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.knh_bank_algorithmic_bytes_per_voice_block(self._h, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)

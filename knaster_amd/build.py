@@ -1,0 +1,62 @@
+"""Builds the gfx950 shared library (hipcc, in-tree) -- `python -m knaster_amd.build`.
+
+The library is built with -ffp-contract=off: the compiler never contracts a*b+c
+on its own, which is what makes the exact (allow_fma = 0) kernels bit-identical
+to the reference's scalar code.  The FMA kernels fuse explicitly.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libknaster_hip.so")
+SOURCES = ["kernels.hip", "bank.hip"]
+HEADERS = ["voice_chain.hpp", "kernel_registry.hpp", os.path.join("..", "..", "include", "knaster_hip.h")]
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fPIC",
+    "-shared",
+    "-Wall",
+    "-Wno-unused-value",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP source for gfx950 into csrc/libknaster_hip.so; returns its path."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), *FLAGS, "-o", LIB + ".tmp", *SOURCES]
+    if verbose:
+        print("[knaster_amd.build]", " ".join(cmd), flush=True)
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed building libknaster_hip.so")
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

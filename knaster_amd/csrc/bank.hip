@@ -1,0 +1,894 @@
+// bank.hip -- host side of the voice-bank UGen and the extern "C" boundary (include/knaster_hip.h).
+//
+// The host keeps a shadow of every *parameter-derived* quantity (never of
+// audio-evolving state) and turns each UGen::param_apply into device state
+// patches.  All transcendental work (tan/pow/sqrt/exp for filter coefficients,
+// the f64 phase-increment product) happens here, with the same libm the
+// reference's std-backed num-traits would call, so the device only does + - * and
+// one table gather per sample.  Citations are file:line in the knaster repo.
+//
+// There is no CPU processing path: without a gfx950 device every compute entry
+// point fails with KNH_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/knaster_hip.h"
+#include "kernel_registry.hpp"
+
+using knh_dev::Event;
+using knh_dev::VoiceKernelArgs;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Static description of the stage kinds
+// ---------------------------------------------------------------------------
+struct KindInfo {
+  int n_slots, n_params, n_ctor, n_nodes;
+  char sig;
+  const char* params[5];
+};
+const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
+    /* SIN_WT      */ {3, 3, 1, 1, 'W', {"freq", "phase_offset", "reset_phase"}},
+    /* SIN_NUMERIC */ {3, 3, 1, 1, 'N', {"freq", "phase_offset", "reset_phase"}},
+    /* SVF         */ {8, 5, 4, 1, 'S', {"cutoff_freq", "q", "gain", "filter", "t_calculate_coefficients"}},
+    /* ONEPOLE_LPF */ {3, 1, 1, 1, 'L', {"cutoff_freq"}},
+    /* ONEPOLE_HPF */ {3, 1, 0, 1, 'H', {"cutoff_freq"}},
+    /* MUL_ENV_ASR */ {5, 4, 2, 2, 'A', {"attack_time", "release_time", "t_release", "t_restart"}},
+    /* MUL_ENV_AR  */ {5, 3, 2, 2, 'E', {"attack_time", "release_time", "t_restart"}},
+    /* MUL_CONST   */ {1, 1, 1, 2, 'm', {"value"}},
+    /* ADD_CONST   */ {1, 1, 1, 2, 'a', {"value"}},
+    /* SUB_CONST   */ {1, 1, 1, 2, 's', {"value"}},
+    /* DIV_CONST   */ {1, 1, 1, 2, 'd', {"value"}},
+    /* WR_MUL      */ {1, 1, 1, 0, 'm', {"wr_mul"}},
+    /* WR_ADD      */ {1, 0, 1, 0, 'a', {nullptr}},
+    /* WR_SUB      */ {1, 0, 1, 0, 's', {nullptr}},
+};
+
+// 0 float, 1 trigger, 2 integer : expected ParameterValue kind per (stage kind, param)
+int expected_value_kind(uint16_t kind, uint32_t param) {
+  switch (kind) {
+    case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: return param == 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
+    case KNH_STAGE_SVF: return param == 3 ? KNH_VALUE_INTEGER : param == 4 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
+    case KNH_STAGE_MUL_ENV_ASR: return param >= 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
+    case KNH_STAGE_MUL_ENV_AR: return param == 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
+    default: return KNH_VALUE_FLOAT;
+  }
+}
+
+std::string g_create_error;  // last failed knh_bank_create
+
+// Rust `as u32` from f64 (saturating; NaN -> 0).  osc.rs:129,134
+inline uint32_t sat_u32(double v) {
+  if (!(v > 0.0)) return 0u;
+  if (v >= 4294967295.0) return 0xFFFFFFFFu;
+  return static_cast<uint32_t>(v);
+}
+
+template <typename F> struct Consts;
+template <> struct Consts<float> { static constexpr float PI = 3.14159265358979323846f; };
+template <> struct Consts<double> { static constexpr double PI = 3.14159265358979323846; };
+
+// SvfFilter::set_coeffs -- knaster_core_dsp/src/ugens/svf.rs:146-242.  F-precision libm calls.
+template <typename F>
+void svf_coeffs(uint32_t ty, F cutoff, F q, F gain_db, F sr, F out[6]) {
+  const F one = 1;
+  F g = std::tan((Consts<F>::PI * cutoff) / sr);
+  F k = one / q;
+  F m0 = 0, m1 = 0, m2 = 0;
+  F amp = 0;
+  if (ty >= KNH_SVF_BELL && ty <= KNH_SVF_HIGH_SHELF) amp = std::pow(F(10), gain_db / F(40));
+  switch (ty) {
+    default:
+    case KNH_SVF_LOW: m0 = 0; m1 = 0; m2 = one; break;
+    case KNH_SVF_BAND: m0 = 0; m1 = one; m2 = 0; break;
+    case KNH_SVF_HIGH: m0 = one; m1 = -k; m2 = -one; break;
+    case KNH_SVF_NOTCH: m0 = one; m1 = -k; m2 = 0; break;
+    case KNH_SVF_PEAK: m0 = one; m1 = -k; m2 = -F(2); break;
+    case KNH_SVF_ALL: m0 = one; m1 = -F(2) * k; m2 = 0; break;
+    case KNH_SVF_BELL:
+      g = g / std::sqrt(amp);
+      k = one / (q * amp);
+      m0 = one; m1 = k * (amp * amp - one); m2 = 0;
+      break;
+    case KNH_SVF_LOW_SHELF:
+      g = g / std::sqrt(amp);
+      m0 = one; m1 = k * (amp - one); m2 = amp * amp - one;
+      break;
+    case KNH_SVF_HIGH_SHELF:
+      g = g * std::sqrt(amp);
+      m0 = amp * amp; m1 = k * (one - amp) * amp; m2 = one - amp * amp;
+      break;
+  }
+  const F a1 = one / (one + g * (g + k));
+  const F a2 = g * a1;
+  const F a3 = g * a2;
+  out[0] = a1; out[1] = a2; out[2] = a3; out[3] = m0; out[4] = m1; out[5] = m2;
+}
+
+inline uint64_t to_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline uint64_t to_bits(double f) { uint64_t u; std::memcpy(&u, &f, 8); return u; }
+
+struct StageInfo {
+  uint16_t kind, flags, dcpb;
+  int slot_base, n_slots, n_params, n_ctor;
+  int param_base;  // index of this stage's first parameter in the flat per-voice parameter table
+};
+
+struct HostEvent {
+  uint32_t voice;
+  uint32_t frame;
+  uint32_t op;
+  uint32_t slot;
+  uint64_t bits;
+};
+struct QueuedChange {  // WrPreciseTiming::waiting_changes entry, precise_timing.rs:17
+  uint16_t delay;
+  uint32_t param, kind;
+  double f;
+  int64_t i;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// The bank
+// ---------------------------------------------------------------------------
+struct knh_bank {
+  virtual ~knh_bank() = default;
+  std::string err;
+  std::vector<std::string> warnings;
+  knh_bank_desc desc{};
+  std::vector<StageInfo> stages;
+  int n_slots = 0, n_params_total = 0;
+  bool initialised = false;
+  uint32_t sample_rate = 0;
+  size_t block_size = 0;
+  int device = 0;
+
+  virtual int set_ctor(uint32_t stage, uint32_t first, uint32_t count, const double* args, uint32_t n_args) = 0;
+  virtual int init(uint32_t sr, size_t bs) = 0;
+  virtual int param_apply(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i) = 0;
+  virtual int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) = 0;
+  virtual int process(size_t ftp, size_t offset, uint64_t clock, void* out_host, void* out_device, void* voices_host,
+                      uint32_t* out_flags, void* stream, bool sync) = 0;
+  virtual int read_done_frames(uint32_t* out) = 0;
+  virtual int synchronize() = 0;
+  virtual int timing_reset(int enable) = 0;
+  virtual int timing_read(double* ms, uint64_t* launches) = 0;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+  void warn(const std::string& msg) {
+    if (warnings.size() < 32) warnings.push_back(msg);
+  }
+};
+
+namespace {
+
+#define KNH_HIP(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return fail(KNH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+  } while (0)
+
+template <typename F>
+struct Bank final : knh_bank {
+  typedef typename knh_dev::WordOf<F>::type W;
+  const knh::KernelEntry* entry = nullptr;
+  uint32_t nv = 0;
+  long stride = 0;
+
+  // construction-time values
+  std::vector<std::vector<double>> ctor;  // [stage][voice * n_ctor + a]
+  // parameter shadows (only what a later setter needs to read back)
+  struct Shadow {
+    std::vector<F> a, b, c;        // SinWt: a=freq | Svf: a=cutoff b=q c=gain_db | Env: a=attack_s b=release_s
+    std::vector<uint8_t> ty;       // Svf filter type
+  };
+  std::vector<Shadow> shadow;
+  double f2pi = 0.0;
+  // WrPreciseTiming state: next_delay per (param, voice) for wrapped stages; queues keyed by voice*n_stages+stage
+  std::vector<uint16_t> next_delay;  // [n_params_total][nv], allocated only if some stage is wrapped
+  std::unordered_map<uint64_t, std::vector<QueuedChange>> queues;
+  std::vector<HostEvent> immediate;  // patches for the start of the next processed block, arrival order
+  std::vector<HostEvent> resolved;   // scratch
+
+  // device
+  hipStream_t own_stream = nullptr;
+  W* d_state = nullptr;
+  float* d_sine = nullptr;
+  uint32_t* d_ev_start = nullptr;
+  Event* d_events = nullptr;
+  size_t d_events_cap = 0;
+  F* d_partials = nullptr;
+  F* d_out = nullptr;
+  F* d_voices = nullptr;
+  uint32_t* d_done = nullptr;
+  uint32_t* d_flags = nullptr;
+  // pinned host staging
+  uint32_t* h_ev_start = nullptr;
+  Event* h_events = nullptr;
+  size_t h_events_cap = 0;
+  F* h_out = nullptr;  // [channels][block] then 2 x u32 flags
+  hipEvent_t staging_free = nullptr;
+  bool staging_in_flight = false;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_pool;
+  size_t timing_used = 0;
+  double timing_ms = 0.0;
+  uint64_t timing_launches = 0;
+
+  ~Bank() override {
+    if (device >= 0) (void)hipSetDevice(device);
+    if (own_stream) (void)hipStreamSynchronize(own_stream);
+    void* dev_ptrs[] = {d_state, d_sine, d_ev_start, d_events, d_partials, d_out, d_voices, d_done, d_flags};
+    for (void* p : dev_ptrs)
+      if (p) (void)hipFree(p);
+    void* host_ptrs[] = {h_ev_start, h_events, h_out};
+    for (void* p : host_ptrs)
+      if (p) (void)hipHostFree(p);
+    if (staging_free) (void)hipEventDestroy(staging_free);
+    for (auto& p : timing_pool) {
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+
+  int set_ctor(uint32_t stage, uint32_t first, uint32_t count, const double* args, uint32_t n_args) override {
+    if (initialised) return fail(KNH_ERR_INVALID_ARGUMENT, "constructor arguments must be set before init");
+    if (stage >= stages.size()) return fail(KNH_ERR_OUT_OF_RANGE, "stage out of range");
+    if (static_cast<uint64_t>(first) + count > nv) return fail(KNH_ERR_OUT_OF_RANGE, "voice range out of range");
+    if (static_cast<int>(n_args) != stages[stage].n_ctor) return fail(KNH_ERR_INVALID_ARGUMENT, "wrong number of constructor arguments");
+    if (n_args && !args) return fail(KNH_ERR_INVALID_ARGUMENT, "null args");
+    std::copy(args, args + static_cast<size_t>(count) * n_args, ctor[stage].begin() + static_cast<size_t>(first) * n_args);
+    return KNH_OK;
+  }
+
+  // ---- UGen::init for every node of every voice --------------------------------------
+  int init(uint32_t sr, size_t bs) override {
+    if (initialised) return fail(KNH_ERR_INVALID_ARGUMENT, "already initialised");
+    if (sr == 0 || bs == 0 || bs > 65535) return fail(KNH_ERR_INVALID_ARGUMENT, "sample_rate/block_size out of range (block_size <= 65535)");
+    int ndev = knh_device_count();
+    if (ndev <= 0) return fail(KNH_ERR_NO_DEVICE, "no gfx950 device visible; this engine has no CPU path");
+    if (desc.device >= 0) device = desc.device;
+    else KNH_HIP(hipGetDevice(&device));
+    KNH_HIP(hipSetDevice(device));
+    sample_rate = sr;
+    block_size = bs;
+    stride = (static_cast<long>(nv) + 63) / 64 * 64;
+    // osc.rs:144-145
+    f2pi = 16384.0 * 65536.0 * (1.0 / static_cast<double>(sr));
+    const F sr_as_f32 = static_cast<F>(static_cast<float>(sr));  // F::new(sample_rate as f32)
+
+    std::vector<W> st(static_cast<size_t>(n_slots) * stride, W(0));
+    auto slot = [&](int s, uint32_t v) -> W& { return st[static_cast<size_t>(s) * stride + v]; };
+    auto fw = [](F x) { return static_cast<W>(to_bits(x)); };
+    shadow.assign(stages.size(), Shadow{});
+    for (size_t si = 0; si < stages.size(); ++si) {
+      const StageInfo& S = stages[si];
+      const double* ca = ctor[si].data();
+      Shadow& sh = shadow[si];
+      for (uint32_t v = 0; v < nv; ++v) {
+        const double* a = ca + static_cast<size_t>(v) * S.n_ctor;
+        switch (S.kind) {
+          case KNH_STAGE_SIN_WT: {  // osc.rs:110-123,142-147
+            if (v == 0) sh.a.resize(nv);
+            F freq = static_cast<F>(a[0]);
+            sh.a[v] = freq;
+            slot(S.slot_base + 0, v) = 0;
+            slot(S.slot_base + 1, v) = 0;
+            slot(S.slot_base + 2, v) = sat_u32(static_cast<double>(freq) * f2pi);
+          } break;
+          case KNH_STAGE_SIN_NUMERIC: {  // osc.rs:231-236,253-261
+            F freq = static_cast<F>(a[0]);
+            slot(S.slot_base + 0, v) = fw(F(0));
+            slot(S.slot_base + 1, v) = fw(F(0));
+            slot(S.slot_base + 2, v) = fw(freq / sr_as_f32);
+          } break;
+          case KNH_STAGE_SVF: {  // svf.rs:64-79,134-141
+            if (v == 0) { sh.a.resize(nv); sh.b.resize(nv); sh.c.resize(nv); sh.ty.resize(nv); }
+            double tyd = a[0];
+            uint32_t ty = (tyd >= 0 && tyd <= 8) ? static_cast<uint32_t>(tyd) : 0u;
+            sh.ty[v] = static_cast<uint8_t>(ty);
+            sh.a[v] = static_cast<F>(a[1]); sh.b[v] = static_cast<F>(a[2]); sh.c[v] = static_cast<F>(a[3]);
+            F co[6];
+            svf_coeffs<F>(ty, sh.a[v], sh.b[v], sh.c[v], sr_as_f32, co);
+            slot(S.slot_base + 0, v) = fw(F(0));
+            slot(S.slot_base + 1, v) = fw(F(0));
+            for (int k = 0; k < 6; ++k) slot(S.slot_base + 2 + k, v) = fw(co[k]);
+          } break;
+          case KNH_STAGE_ONEPOLE_LPF:    // onepole.rs:118-129
+          case KNH_STAGE_ONEPOLE_HPF: {  // onepole.rs:157-167 (b1 = 0 -> exp(0) = 1)
+            F freq = S.kind == KNH_STAGE_ONEPOLE_LPF ? static_cast<F>(a[0]) : F(0);
+            F f = freq / sr_as_f32;
+            F b1 = std::exp(F(-2.0) * Consts<F>::PI * f);
+            F a0 = F(1.0) - b1;
+            slot(S.slot_base + 0, v) = fw(F(0));
+            slot(S.slot_base + 1, v) = fw(a0);
+            slot(S.slot_base + 2, v) = fw(b1);
+          } break;
+          case KNH_STAGE_MUL_ENV_ASR:
+          case KNH_STAGE_MUL_ENV_AR: {  // envelopes.rs:33-43,135-151 / :187-197,268-284
+            if (v == 0) { sh.a.resize(nv); sh.b.resize(nv); }
+            F atk = static_cast<F>(a[0]), rel = static_cast<F>(a[1]);
+            sh.a[v] = atk; sh.b[v] = rel;
+            F ar = atk == F(0) ? F(1) : F(1) / (atk * static_cast<F>(sr));
+            F rr = rel == F(0) ? F(1) : F(1) / (rel * static_cast<F>(sr));
+            slot(S.slot_base + 0, v) = 0;          // Stopped
+            slot(S.slot_base + 1, v) = fw(F(0));   // t
+            slot(S.slot_base + 2, v) = fw(ar);
+            slot(S.slot_base + 3, v) = fw(rr);
+            slot(S.slot_base + 4, v) = fw(F(1));   // release_scale
+          } break;
+          default:  // Constant / wrapper value: util.rs:43-45, wrappers_core/math.rs:21-23
+            slot(S.slot_base, v) = fw(static_cast<F>(a[0]));
+            break;
+        }
+      }
+    }
+    // device allocations
+    KNH_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    KNH_HIP(hipMalloc(&d_state, st.size() * sizeof(W)));
+    KNH_HIP(hipMemcpy(d_state, st.data(), st.size() * sizeof(W), hipMemcpyHostToDevice));
+    {  // NonAaWavetable::sine(), wavetable.rs:130-139: f64 sin, rounded to f32
+      std::vector<float> table(16384);
+      const double PI = 3.14159265358979323846;
+      for (int i = 0; i < 16384; ++i) table[i] = static_cast<float>(std::sin((static_cast<double>(i) / 16384.0) * PI * 2.0));
+      KNH_HIP(hipMalloc(&d_sine, 16384 * sizeof(float)));
+      KNH_HIP(hipMemcpy(d_sine, table.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    const size_t n_waves = (nv + 63) / 64;
+    KNH_HIP(hipMalloc(&d_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
+    KNH_HIP(hipMalloc(&d_partials, n_waves * bs * sizeof(F)));
+    KNH_HIP(hipMalloc(&d_out, desc.out_channels * bs * sizeof(F)));
+    KNH_HIP(hipMemset(d_out, 0, desc.out_channels * bs * sizeof(F)));
+    KNH_HIP(hipMalloc(&d_done, static_cast<size_t>(nv) * sizeof(uint32_t)));
+    KNH_HIP(hipMemset(d_done, 0xFF, static_cast<size_t>(nv) * sizeof(uint32_t)));
+    KNH_HIP(hipMalloc(&d_flags, 2 * sizeof(uint32_t)));
+    KNH_HIP(hipHostMalloc(&h_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
+    KNH_HIP(hipHostMalloc(&h_out, desc.out_channels * bs * sizeof(F) + 2 * sizeof(uint32_t)));
+    KNH_HIP(hipEventCreateWithFlags(&staging_free, hipEventDisableTiming));
+    if (desc.mix_mode == KNH_MIX_LEFT_FOLD) KNH_HIP(ensure_voices());
+    bool any_wrapped = false;
+    for (auto& S : stages) any_wrapped = any_wrapped || S.dcpb > 0;
+    if (any_wrapped) next_delay.assign(static_cast<size_t>(n_params_total) * nv, 0);
+    initialised = true;
+    return KNH_OK;
+  }
+  hipError_t ensure_voices() {
+    if (d_voices) return hipSuccess;
+    return hipMalloc(&d_voices, static_cast<size_t>(nv) * block_size * sizeof(F));
+  }
+
+  // ---- parameter changes ----------------------------------------------------------------
+  int check_target(uint32_t voice, uint32_t stage, uint32_t param) {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    if (voice >= nv) return fail(KNH_ERR_OUT_OF_RANGE, "voice out of range");
+    if (stage >= stages.size()) return fail(KNH_ERR_OUT_OF_RANGE, "stage out of range");
+    if (param >= static_cast<uint32_t>(stages[stage].n_params)) return fail(KNH_ERR_OUT_OF_RANGE, "parameter index out of range");
+    return KNH_OK;
+  }
+  int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) override {
+    int rc = check_target(voice, stage, param);
+    if (rc != KNH_OK) return rc;
+    const StageInfo& S = stages[stage];
+    if (S.dcpb == 0) {  // ugen.rs:339-341
+      warn("Parameter delay set, but the stage is not wrapped in WrPreciseTiming; no effect");
+      return KNH_OK;
+    }
+    next_delay[static_cast<size_t>(S.param_base + param) * nv + voice] = delay;  // precise_timing.rs:146-148
+    return KNH_OK;
+  }
+  int param_apply(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i) override {
+    int rc = check_target(voice, stage, param);
+    if (rc != KNH_OK) return rc;
+    const StageInfo& S = stages[stage];
+    if (static_cast<int>(kind) != expected_value_kind(S.kind, param))
+      return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
+    if (S.dcpb > 0) {  // WrPreciseTiming::param_apply, precise_timing.rs:126-135
+      uint16_t d = next_delay[static_cast<size_t>(S.param_base + param) * nv + voice];
+      if (d != 0) {
+        auto& q = queues[static_cast<uint64_t>(voice) * stages.size() + stage];
+        if (q.size() < S.dcpb) q.push_back(QueuedChange{d, param, kind, f, i});
+        else warn("Not enough space for scheduled changes in WrPreciseTiming, change ignored");
+        return KNH_OK;
+      }
+    }
+    apply_now(voice, stage, param, f, i, 0, immediate);
+    return KNH_OK;
+  }
+
+  // The parameter setters of each UGen, restated as "new shadow value -> device patches".
+  void apply_now(uint32_t v, uint32_t stage, uint32_t param, double f, int64_t iv, uint32_t frame, std::vector<HostEvent>& out) {
+    const StageInfo& S = stages[stage];
+    Shadow& sh = shadow[stage];
+    auto set = [&](int rel, uint64_t bits) { out.push_back(HostEvent{v, frame, knh_dev::EV_SET, static_cast<uint32_t>(S.slot_base + rel), bits}); };
+    const F sr_as_f32 = static_cast<F>(static_cast<float>(sample_rate));
+    switch (S.kind) {
+      case KNH_STAGE_SIN_WT:
+        if (param == 0) {  // osc.rs:127-130; ignored while an audio-rate buffer drives it (audio_rate.rs:70-74)
+          if (S.flags & KNH_STAGE_FLAG_AR_FREQ) return;
+          F freq = static_cast<F>(f);
+          sh.a[v] = freq;
+          set(2, sat_u32(static_cast<double>(freq) * f2pi));
+        } else if (param == 1) {  // osc.rs:133-135
+          set(1, sat_u32(f * 65536.0));
+        } else {
+          set(0, 0);  // reset_phase
+        }
+        break;
+      case KNH_STAGE_SIN_NUMERIC:
+        if (param == 0) set(2, to_bits(static_cast<F>(f) / sr_as_f32));  // osc.rs:240-242
+        else if (param == 1) set(1, to_bits(static_cast<F>(f)));
+        else set(0, to_bits(F(0)));
+        break;
+      case KNH_STAGE_SVF: {  // svf.rs:81-133: every setter recomputes the coefficients
+        if (param == 0) sh.a[v] = static_cast<F>(f);
+        else if (param == 1) sh.b[v] = static_cast<F>(f);
+        else if (param == 2) sh.c[v] = static_cast<F>(f);
+        else if (param == 3) sh.ty[v] = (iv >= 0 && iv <= 8) ? static_cast<uint8_t>(iv) : 0;  // knaster_macros/src/lib.rs:44-47
+        F co[6];
+        svf_coeffs<F>(sh.ty[v], sh.a[v], sh.b[v], sh.c[v], sr_as_f32, co);
+        for (int k = 0; k < 6; ++k) set(2 + k, to_bits(co[k]));
+      } break;
+      case KNH_STAGE_ONEPOLE_LPF:
+      case KNH_STAGE_ONEPOLE_HPF: {  // onepole.rs:135-139,172-176 -> :35-46
+        F fr = static_cast<F>(f) / static_cast<F>(sample_rate);
+        F b1 = std::exp(F(-2.0) * Consts<F>::PI * fr);
+        set(2, to_bits(b1));
+        set(1, to_bits(F(1.0) - b1));
+      } break;
+      case KNH_STAGE_MUL_ENV_ASR:
+      case KNH_STAGE_MUL_ENV_AR:
+        if (param == 0 || param == 1) {  // envelopes.rs:85-110 / :236-261 (skip when unchanged)
+          std::vector<F>& secs = param == 0 ? sh.a : sh.b;
+          F s = static_cast<F>(f);
+          if (secs[v] != s) {
+            secs[v] = s;
+            F rate = s == F(0) ? F(1) : F(1) / (s * static_cast<F>(sample_rate));
+            set(param == 0 ? 2 : 3, to_bits(rate));
+          }
+        } else if (S.kind == KNH_STAGE_MUL_ENV_ASR && param == 2) {  // t_release needs the live state: device op
+          out.push_back(HostEvent{v, frame, knh_dev::EV_ENV_ASR_RELEASE, static_cast<uint32_t>(S.slot_base), 0});
+        } else {
+          set(0, 1);  // t_restart: state = Attacking, t untouched (envelopes.rs:47-49,131-133)
+        }
+        break;
+      default:  // Constant::value (util.rs:47-50) / WrMul "wr_mul" (wrappers_core/math.rs:92-98)
+        set(0, to_bits(static_cast<F>(f)));
+        break;
+    }
+  }
+
+  // WrPreciseTiming::process_block's change loop (precise_timing.rs:65-114) for every wrapped node
+  // with queued changes: FIFO with head-of-line blocking, changes past the processed range are lost.
+  void resolve_queues(uint32_t frame_begin, uint32_t frame_end) {
+    for (auto& kv : queues) {
+      std::vector<QueuedChange>& q = kv.second;
+      if (q.empty()) continue;
+      const uint32_t voice = static_cast<uint32_t>(kv.first / stages.size());
+      const uint32_t stage = static_cast<uint32_t>(kv.first % stages.size());
+      uint32_t at = frame_begin;
+      for (const QueuedChange& c : q) {
+        uint32_t due = std::max<uint32_t>(c.delay, at);
+        if (due > frame_end) break;
+        at = due;
+        const size_t first = resolved.size();
+        apply_now(voice, stage, c.param, c.f, c.i, due, resolved);
+        // a queued change splits the node's block at `due` (precise_timing.rs:104-110)
+        if (due > frame_begin) {
+          if (resolved.size() == first)  // the setter emitted no patch (value unchanged): still a split
+            resolved.push_back(HostEvent{voice, due, knh_dev::EV_NOP, static_cast<uint32_t>(stages[stage].slot_base), 0});
+          for (size_t k = first; k < resolved.size(); ++k) resolved[k].op |= knh_dev::EV_SPLIT;
+        }
+      }
+      q.clear();
+    }
+    queues.clear();
+  }
+
+  // ---- processing ---------------------------------------------------------------------------
+  int upload_events(hipStream_t s, bool* have_events) {
+    *have_events = false;
+    const size_t total = immediate.size() + resolved.size();
+    if (total == 0) return KNH_OK;
+    if (staging_in_flight) {  // the previous upload must have left the pinned staging buffers
+      KNH_HIP(hipEventSynchronize(staging_free));
+      staging_in_flight = false;
+    }
+    if (total > h_events_cap) {
+      size_t cap = std::max<size_t>(total, 1024) * 2;
+      if (h_events) KNH_HIP(hipHostFree(h_events));
+      h_events = nullptr;
+      KNH_HIP(hipHostMalloc(&h_events, cap * sizeof(Event)));
+      h_events_cap = cap;
+    }
+    if (total > d_events_cap) {
+      KNH_HIP(hipStreamSynchronize(s));
+      KNH_HIP(hipFree(d_events));
+      d_events = nullptr;
+      KNH_HIP(hipMalloc(&d_events, h_events_cap * sizeof(Event)));
+      d_events_cap = h_events_cap;
+    }
+    // counting sort by voice (stable), then order each voice's few events by frame (stable)
+    std::fill(h_ev_start, h_ev_start + nv + 1, 0u);
+    for (const HostEvent& e : immediate) h_ev_start[e.voice + 1]++;
+    for (const HostEvent& e : resolved) h_ev_start[e.voice + 1]++;
+    for (uint32_t v = 0; v < nv; ++v) h_ev_start[v + 1] += h_ev_start[v];
+    std::vector<uint32_t> cursor(h_ev_start, h_ev_start + nv);
+    auto put = [&](const HostEvent& e) {
+      Event& d = h_events[cursor[e.voice]++];
+      d.frame_op = (e.frame & 0xFFFFu) | (e.op << 16);
+      d.slot = e.slot;
+      d.bits = e.bits;
+    };
+    for (const HostEvent& e : immediate) put(e);
+    for (const HostEvent& e : resolved) put(e);
+    if (!resolved.empty()) {
+      for (uint32_t v = 0; v < nv; ++v) {
+        Event* b = h_events + h_ev_start[v];
+        Event* e = h_events + h_ev_start[v + 1];
+        if (e - b > 1)
+          std::stable_sort(b, e, [](const Event& x, const Event& y) { return (x.frame_op & 0xFFFFu) < (y.frame_op & 0xFFFFu); });
+      }
+    }
+    KNH_HIP(hipMemcpyAsync(d_ev_start, h_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    KNH_HIP(hipMemcpyAsync(d_events, h_events, total * sizeof(Event), hipMemcpyHostToDevice, s));
+    KNH_HIP(hipEventRecord(staging_free, s));
+    staging_in_flight = true;
+    immediate.clear();
+    resolved.clear();
+    *have_events = true;
+    return KNH_OK;
+  }
+
+  int process(size_t ftp, size_t offset, uint64_t /*clock*/, void* out_host, void* out_device, void* voices_host,
+              uint32_t* out_flags, void* stream, bool sync) override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    if (offset + ftp > block_size) return fail(KNH_ERR_INVALID_ARGUMENT, "block_start_offset + frames_to_process exceeds block_size");
+    KNH_HIP(hipSetDevice(device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : own_stream;
+    const uint32_t fb = static_cast<uint32_t>(offset), fe = static_cast<uint32_t>(offset + ftp);
+    resolve_queues(fb, fe);
+    bool have_events = false;
+    int rc = upload_events(s, &have_events);
+    if (rc != KNH_OK) return rc;
+    const bool want_voices = voices_host != nullptr || desc.mix_mode == KNH_MIX_LEFT_FOLD;
+    if (want_voices) KNH_HIP(ensure_voices());
+
+    KNH_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), s));
+    VoiceKernelArgs<F> a;
+    a.state = d_state;
+    a.stride = stride;
+    a.n_voices = nv;
+    a.block_size = static_cast<uint32_t>(block_size);
+    a.frame_begin = fb;
+    a.frame_end = fe;
+    a.sine_table = d_sine;
+    a.f2pi = f2pi;
+    a.ev_start = have_events ? d_ev_start : nullptr;
+    a.events = d_events;
+    a.partials = d_partials;
+    a.voices_out = want_voices ? d_voices : nullptr;
+    a.done_frames = d_done;
+    a.flags = d_flags;
+    const unsigned n_waves = (nv + 63) / 64;
+    std::pair<hipEvent_t, hipEvent_t>* tp = nullptr;
+    if (timing) {
+      if (timing_used == timing_pool.size()) {
+        if (timing_pool.size() >= 8192) {
+          int r = timing_collect();
+          if (r != KNH_OK) return r;
+        } else {
+          hipEvent_t e0, e1;
+          KNH_HIP(hipEventCreate(&e0));
+          KNH_HIP(hipEventCreate(&e1));
+          timing_pool.emplace_back(e0, e1);
+        }
+      }
+      tp = &timing_pool[timing_used++];
+      KNH_HIP(hipEventRecord(tp->first, s));
+    }
+    KNH_HIP(launch_voice(a, n_waves, s));
+    if (tp) KNH_HIP(hipEventRecord(tp->second, s));
+
+    F* dst = out_device ? static_cast<F*>(out_device) : d_out;
+    if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
+      KNH_HIP(launch_fold(d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), s));
+    else
+      KNH_HIP(launch_fold(d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), s));
+
+    if (!sync) return KNH_OK;
+    const size_t out_bytes = desc.out_channels * block_size * sizeof(F);
+    uint32_t* h_flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h_out) + out_bytes);
+    if (out_host) KNH_HIP(hipMemcpyAsync(h_out, dst, out_bytes, hipMemcpyDeviceToHost, s));
+    KNH_HIP(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (voices_host)
+      KNH_HIP(hipMemcpyAsync(voices_host, d_voices, static_cast<size_t>(nv) * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
+    KNH_HIP(hipStreamSynchronize(s));
+    staging_in_flight = false;
+    if (out_host) {
+      for (uint32_t c = 0; c < desc.out_channels; ++c)
+        std::memcpy(static_cast<F*>(out_host) + c * block_size + offset, h_out + c * block_size + offset, ftp * sizeof(F));
+    }
+    if (out_flags) {
+      uint32_t fl = 0;
+      if (h_flags[0]) fl |= KNH_FLAG_ANY_DONE;
+      if (h_flags[1] == 0) fl |= KNH_FLAG_ALL_DONE;
+      *out_flags = fl;
+    }
+    return KNH_OK;
+  }
+  hipError_t launch_voice(const VoiceKernelArgs<float>& a, unsigned n_waves, hipStream_t s) {
+    return entry->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
+  }
+  hipError_t launch_voice(const VoiceKernelArgs<double>& a, unsigned n_waves, hipStream_t s) {
+    return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
+  }
+  static hipError_t launch_fold(const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, hipStream_t s) {
+    return knh::launch_fold_rows_f32(rows, n, len, fb, fe, out, ch, os, s);
+  }
+  static hipError_t launch_fold(const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, hipStream_t s) {
+    return knh::launch_fold_rows_f64(rows, n, len, fb, fe, out, ch, os, s);
+  }
+
+  int read_done_frames(uint32_t* out) override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    if (!out) return fail(KNH_ERR_INVALID_ARGUMENT, "null output");
+    KNH_HIP(hipSetDevice(device));
+    KNH_HIP(hipStreamSynchronize(own_stream));
+    KNH_HIP(hipMemcpy(out, d_done, static_cast<size_t>(nv) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return KNH_OK;
+  }
+  int synchronize() override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    KNH_HIP(hipSetDevice(device));
+    KNH_HIP(hipDeviceSynchronize());
+    staging_in_flight = false;
+    return KNH_OK;
+  }
+  int timing_collect() {
+    KNH_HIP(hipDeviceSynchronize());
+    for (size_t k = 0; k < timing_used; ++k) {
+      float ms = 0.f;
+      KNH_HIP(hipEventElapsedTime(&ms, timing_pool[k].first, timing_pool[k].second));
+      timing_ms += ms;
+      timing_launches += 1;
+    }
+    timing_used = 0;
+    return KNH_OK;
+  }
+  int timing_reset(int enable) override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    KNH_HIP(hipSetDevice(device));
+    int rc = timing_collect();
+    if (rc != KNH_OK) return rc;
+    timing_ms = 0.0;
+    timing_launches = 0;
+    timing = enable != 0;
+    return KNH_OK;
+  }
+  int timing_read(double* ms, uint64_t* launches) override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    KNH_HIP(hipSetDevice(device));
+    int rc = timing_collect();
+    if (rc != KNH_OK) return rc;
+    if (ms) *ms = timing_ms;
+    if (launches) *launches = timing_launches;
+    return KNH_OK;
+  }
+};
+
+// Chain descriptor -> device signature (kernel_registry.hpp) with structural validation.
+int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std::string* why) {
+  if (n == 0) { *why = "empty chain"; return KNH_ERR_INVALID_ARGUMENT; }
+  sig->clear();
+  bool have_x = false;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (st[i].kind >= KNH_STAGE_KIND_COUNT) { *why = "unknown stage kind"; return KNH_ERR_INVALID_ARGUMENT; }
+    const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC;
+    const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
+    if (st[i].flags & ~KNH_STAGE_FLAG_AR_FREQ) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
+    if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
+    if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }
+    sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
+    have_x = true;
+  }
+  return KNH_OK;
+}
+
+template <typename F>
+knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry) {
+  auto* b = new Bank<F>();
+  b->desc = d;
+  b->entry = entry;
+  b->nv = d.n_voices;
+  int slot = 0, pbase = 0;
+  for (uint32_t i = 0; i < d.n_stages; ++i) {
+    const KindInfo& k = kKinds[d.stages[i].kind];
+    StageInfo s{d.stages[i].kind, d.stages[i].flags, d.stages[i].delayed_changes_per_block, slot, k.n_slots, k.n_params, k.n_ctor, pbase};
+    b->stages.push_back(s);
+    b->ctor.emplace_back(static_cast<size_t>(d.n_voices) * k.n_ctor, 0.0);
+    slot += k.n_slots;
+    pbase += k.n_params;
+  }
+  b->n_slots = slot;
+  b->n_params_total = pbase;
+  b->desc.stages = nullptr;  // the caller's array is not retained
+  return b;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// extern "C" boundary
+// ---------------------------------------------------------------------------
+extern "C" {
+
+uint32_t knh_abi_version(void) { return KNH_ABI_VERSION; }
+
+int32_t knh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int usable = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
+  }
+  return usable;
+}
+
+const char* knh_status_string(int32_t status) {
+  switch (status) {
+    case KNH_OK: return "ok";
+    case KNH_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case KNH_ERR_OUT_OF_RANGE: return "index out of range";
+    case KNH_ERR_UNSUPPORTED_CHAIN: return "no fused kernel for this chain";
+    case KNH_ERR_DEVICE: return "HIP error";
+    case KNH_ERR_NOT_INITIALISED: return "bank not initialised";
+    case KNH_ERR_NO_DEVICE: return "no gfx950 device";
+    case KNH_ERR_WRONG_VALUE_KIND: return "wrong parameter value kind";
+    default: return "unknown status";
+  }
+}
+
+const char* knh_last_error(const knh_bank* bank) { return bank ? bank->err.c_str() : g_create_error.c_str(); }
+
+int32_t knh_chain_ugen_count(const knh_stage_desc* stages, uint32_t n_stages) {
+  if (!stages) return 0;
+  int n = 0;
+  for (uint32_t i = 0; i < n_stages; ++i)
+    if (stages[i].kind < KNH_STAGE_KIND_COUNT) n += kKinds[stages[i].kind].n_nodes;
+  return n;
+}
+
+int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank) {
+  if (out_bank) *out_bank = nullptr;
+  if (!desc || !out_bank) { g_create_error = "null argument"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->abi_version != KNH_ABI_VERSION) { g_create_error = "ABI version mismatch"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->n_voices == 0 || !desc->stages) { g_create_error = "n_voices must be > 0 and stages non-null"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->sample_type > KNH_F64) { g_create_error = "unknown sample type"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->out_channels < 1 || desc->out_channels > 2) { g_create_error = "out_channels must be 1 or 2"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->mix_mode > KNH_MIX_LEFT_FOLD) { g_create_error = "unknown mix mode"; return KNH_ERR_INVALID_ARGUMENT; }
+  std::string sig, why;
+  int rc = build_signature(desc->stages, desc->n_stages, &sig, &why);
+  if (rc != KNH_OK) { g_create_error = why; return rc; }
+  const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
+  if (!entry) {
+    g_create_error = "no pre-built fused kernel for chain signature '" + sig + "'";
+    return KNH_ERR_UNSUPPORTED_CHAIN;
+  }
+  *out_bank = desc->sample_type == KNH_F64 ? make_bank<double>(*desc, entry) : make_bank<float>(*desc, entry);
+  return KNH_OK;
+}
+
+void knh_bank_destroy(knh_bank* bank) { delete bank; }
+
+int32_t knh_bank_set_ctor_args(knh_bank* bank, uint32_t stage, uint32_t first_voice, uint32_t count, const double* args, uint32_t n_args) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->set_ctor(stage, first_voice, count, args, n_args);
+}
+int32_t knh_bank_init(knh_bank* bank, uint32_t sample_rate, size_t block_size) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->init(sample_rate, block_size);
+}
+uint16_t knh_bank_inputs(const knh_bank*) { return 0; }
+uint16_t knh_bank_outputs(const knh_bank* bank) { return bank ? static_cast<uint16_t>(bank->desc.out_channels) : 0; }
+uint16_t knh_bank_stage_parameters(const knh_bank* bank, uint32_t stage) {
+  if (!bank || stage >= bank->stages.size()) return 0;
+  return static_cast<uint16_t>(bank->stages[stage].n_params);
+}
+const char* knh_bank_stage_param_description(const knh_bank* bank, uint32_t stage, uint32_t param) {
+  if (!bank || stage >= bank->stages.size() || param >= static_cast<uint32_t>(bank->stages[stage].n_params)) return nullptr;
+  return kKinds[bank->stages[stage].kind].params[param];
+}
+int32_t knh_bank_param_apply(knh_bank* bank, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double fvalue, int64_t ivalue) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->param_apply(voice, stage, param, kind, fvalue, ivalue);
+}
+int32_t knh_bank_set_delay_within_block_for_param(knh_bank* bank, uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->set_delay(voice, stage, param, delay);
+}
+int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* voices, const uint32_t* stages, const uint32_t* params,
+                                  const uint32_t* kinds, const double* fvalues, const int64_t* ivalues, const uint16_t* delays) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
+  int rc = KNH_OK;
+  for (size_t k = 0; k < count; ++k) {
+    if (delays && delays[k] > 0) {
+      int r = bank->set_delay(voices[k], stages[k], params[k], delays[k]);
+      if (r != KNH_OK) { rc = r; continue; }
+    }
+    int r = bank->param_apply(voices[k], stages[k], params[k], kinds[k], fvalues ? fvalues[k] : 0.0, ivalues ? ivalues[k] : 0);
+    if (r != KNH_OK) rc = r;
+  }
+  return rc;
+}
+int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, uint32_t* out_flags) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output block");
+  return bank->process(frames_to_process, block_start_offset, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+}
+int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out_device, void* hip_stream) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->process(frames_to_process, block_start_offset, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+}
+int32_t knh_bank_process_block_voices(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, void* voices_out, uint32_t* out_flags) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (!voices_out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null voices_out");
+  return bank->process(frames_to_process, block_start_offset, frame_clock, out, nullptr, voices_out, out_flags, nullptr, true);
+}
+int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->read_done_frames(done_frames);
+}
+int32_t knh_bank_synchronize(knh_bank* bank) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->synchronize();
+}
+int32_t knh_bank_timing_reset(knh_bank* bank, int32_t enable) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->timing_reset(enable);
+}
+int32_t knh_bank_timing_read(knh_bank* bank, double* kernel_ms, uint64_t* launches) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->timing_read(kernel_ms, launches);
+}
+int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_t* read_bytes, uint32_t* write_bytes) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  // every slot is read once; mutable slots are written once (masks mirror voice_chain.hpp kMutableMask)
+  uint32_t r = 0, w = 0;
+  const uint32_t word = bank->desc.sample_type == KNH_F64 ? 8 : 4;
+  for (const StageInfo& s : bank->stages) {
+    r += word * s.n_slots;
+    switch (s.kind) {
+      case KNH_STAGE_SIN_WT: w += word * ((s.flags & KNH_STAGE_FLAG_AR_FREQ) ? 2 : 1); break;
+      case KNH_STAGE_SIN_NUMERIC: w += word; break;
+      case KNH_STAGE_SVF: w += word * 2; break;
+      case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: w += word; break;
+      case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: w += word * 3; break;
+      default: break;
+    }
+  }
+  if (read_bytes) *read_bytes = r;
+  if (write_bytes) *write_bytes = w;
+  return KNH_OK;
+}
+
+}  // extern "C"

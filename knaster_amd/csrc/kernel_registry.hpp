@@ -1,0 +1,33 @@
+// kernel_registry.hpp -- maps a chain signature to its pre-instantiated fused kernels.
+//
+// Signature: one character per device stage, in chain order:
+//   W SinWt   R SinWt.ar_params() driven by the running signal   N SinNumeric
+//   S SvfFilter   L OnePoleLpf   H OnePoleHpf   A x*EnvAsr   E x*EnvAr
+//   m x*value   a x+value   s x-value   d x/value
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "voice_chain.hpp"
+
+namespace knh {
+
+template <typename F>
+using VoiceLaunchFn = hipError_t (*)(const knh_dev::VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream);
+
+struct KernelEntry {
+  const char* signature;
+  int n_slots;
+  VoiceLaunchFn<float> f32[2];   // [allow_fma]
+  VoiceLaunchFn<double> f64[2];  // [allow_fma]
+};
+
+const KernelEntry* find_kernel(const char* signature);
+int kernel_count();
+const KernelEntry* kernel_at(int i);
+
+hipError_t launch_fold_rows_f32(const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                                unsigned frame_end, float* out, unsigned channels, unsigned out_stride, hipStream_t s);
+hipError_t launch_fold_rows_f64(const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                                unsigned frame_end, double* out, unsigned channels, unsigned out_stride, hipStream_t s);
+
+}  // namespace knh

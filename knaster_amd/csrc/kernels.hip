@@ -1,0 +1,69 @@
+// kernels.hip -- gfx950 instantiations of the fused voice-bank kernel.
+// Built with -ffp-contract=off: the compiler never fuses a*b+c on its own; the
+// FMA variants fuse explicitly.
+#include <cstring>
+
+#include "kernel_registry.hpp"
+
+namespace knh {
+using namespace knh_dev;
+
+template <typename F, bool FMA, typename... S>
+static hipError_t launch_voice(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
+  if (n_wavefronts == 0) return hipSuccess;
+  hipLaunchKernelGGL((voice_kernel<F, FMA, 1, S...>), dim3(n_wavefronts), dim3(64), 0, stream, args);
+  return hipGetLastError();
+}
+
+#define KNH_CHAIN(sig, ...)                                                                  \
+  {sig, Chain<float, false, 0, __VA_ARGS__>::kSlots,                                         \
+   {launch_voice<float, false, __VA_ARGS__>, launch_voice<float, true, __VA_ARGS__>},        \
+   {launch_voice<double, false, __VA_ARGS__>, launch_voice<double, true, __VA_ARGS__>}}
+
+static const KernelEntry kEntries[] = {
+    // BASELINE.json configs
+    KNH_CHAIN("Wm", SinWt, MulVal),                             // C1: SinWt * 0.2 ; bench "sine * 0.05"
+    KNH_CHAIN("Nm", SinNum, MulVal),                            // C2: SinNumeric + gain
+    KNH_CHAIN("WmSA", SinWt, MulVal, Svf, MulAsr),              // C3/C4: SinWt.wr_mul -> Svf -> * EnvAsr
+    KNH_CHAIN("WmaRm", SinWt, MulVal, AddVal, SinWtAr, MulVal), // C5: audio-rate FM
+    // single stages and common shapes
+    KNH_CHAIN("W", SinWt),
+    KNH_CHAIN("N", SinNum),
+    KNH_CHAIN("WS", SinWt, Svf),
+    KNH_CHAIN("WA", SinWt, MulAsr),
+    KNH_CHAIN("WE", SinWt, MulAr),
+    KNH_CHAIN("WmE", SinWt, MulVal, MulAr),                     // knaster/examples/many_sines.rs:51-63 minus Pan2
+    KNH_CHAIN("WSAm", SinWt, Svf, MulAsr, MulVal),
+    KNH_CHAIN("WLAm", SinWt, OnePoleLp, MulAsr, MulVal),
+    KNH_CHAIN("WHEm", SinWt, OnePoleHp, MulAr, MulVal),
+    KNH_CHAIN("NSAm", SinNum, Svf, MulAsr, MulVal),
+    KNH_CHAIN("Wasd", SinWt, AddVal, SubVal, DivVal),
+};
+
+const KernelEntry* find_kernel(const char* signature) {
+  for (const KernelEntry& e : kEntries)
+    if (std::strcmp(e.signature, signature) == 0) return &e;
+  return nullptr;
+}
+int kernel_count() { return (int)(sizeof(kEntries) / sizeof(kEntries[0])); }
+const KernelEntry* kernel_at(int i) { return (i >= 0 && i < kernel_count()) ? &kEntries[i] : nullptr; }
+
+template <typename F>
+static hipError_t launch_fold(const F* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin, unsigned frame_end,
+                              F* out, unsigned channels, unsigned out_stride, hipStream_t s) {
+  if (frame_end <= frame_begin || n_rows == 0) return hipSuccess;
+  unsigned grid = (frame_end - frame_begin + 63u) / 64u;
+  hipLaunchKernelGGL((fold_rows_kernel<F>), dim3(grid), dim3(64), 0, s, rows, n_rows, row_len, frame_begin, frame_end, out,
+                     channels, out_stride);
+  return hipGetLastError();
+}
+hipError_t launch_fold_rows_f32(const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                                unsigned frame_end, float* out, unsigned channels, unsigned out_stride, hipStream_t s) {
+  return launch_fold<float>(rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, s);
+}
+hipError_t launch_fold_rows_f64(const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                                unsigned frame_end, double* out, unsigned channels, unsigned out_stride, hipStream_t s) {
+  return launch_fold<double>(rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, s);
+}
+
+}  // namespace knh

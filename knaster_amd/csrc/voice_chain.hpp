@@ -1,0 +1,501 @@
+// voice_chain.hpp -- device-side UGen stages and the fused voice-bank kernel (gfx950).
+//
+// One lane = one voice.  A chain is a compile-time list of stages evaluated in
+// order on one running sample x; all per-voice state lives in registers for the
+// whole block and is read from / written back to a struct-of-arrays in HBM once
+// per launch (coalesced: lane i touches word i of each slot row).
+//
+// Arithmetic contract: with FMA == false every a*b+c below is a separate
+// multiply and add in source order (the translation unit is also built with
+// -ffp-contract=off), which makes each voice's signal bit-identical to the
+// reference's scalar Rust.  Citations are file:line in the knaster repo.
+//
+// This header is self-contained (no libc/libstdc++ includes) so the same text
+// can be handed to hiprtc for chains that are not pre-instantiated.
+#pragma once
+
+// Accurate (not v_sin_f32) sine from the ROCm device library, linked by hipcc and hiprtc alike.
+extern "C" __device__ float __ocml_sin_f32(float);
+extern "C" __device__ double __ocml_sin_f64(double);
+
+namespace knh_dev {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+// Slot word: u32 for an f32 bank, u64 for an f64 bank.
+template <typename F> struct WordOf;
+template <> struct WordOf<float> { typedef u32 type; };
+template <> struct WordOf<double> { typedef u64 type; };
+
+template <typename F> __device__ __forceinline__ F word_to_f(typename WordOf<F>::type w);
+template <> __device__ __forceinline__ float word_to_f<float>(u32 w) { return __builtin_bit_cast(float, w); }
+template <> __device__ __forceinline__ double word_to_f<double>(u64 w) { return __builtin_bit_cast(double, w); }
+__device__ __forceinline__ u32 f_to_word(float f) { return __builtin_bit_cast(u32, f); }
+__device__ __forceinline__ u64 f_to_word(double f) { return __builtin_bit_cast(u64, f); }
+
+template <bool FMA> __device__ __forceinline__ float mad(float a, float b, float c) {
+  if constexpr (FMA) return __builtin_fmaf(a, b, c);
+  else return a * b + c;
+}
+template <bool FMA> __device__ __forceinline__ double mad(double a, double b, double c) {
+  if constexpr (FMA) return __builtin_fma(a, b, c);
+  else return a * b + c;
+}
+
+// Rust `as u32` from f64: NaN -> 0, negative -> 0, too large -> u32::MAX (osc.rs:129).
+__device__ __forceinline__ u32 sat_u32(double v) {
+  if (!(v > 0.0)) return 0u;
+  if (v >= 4294967295.0) return 0xFFFFFFFFu;
+  return (u32)v;
+}
+
+// Event opcodes (host -> device state patches, applied at an in-block frame).
+enum { EV_SET = 0, EV_ENV_ASR_RELEASE = 1, EV_NOP = 2, EV_SPLIT = 0x80 /* flag: change came out of a WrPreciseTiming queue */ };
+
+struct Event {   // 16 bytes
+  u32 frame_op;  // frame (low 16) | op (bits 16..23)
+  u32 slot;      // absolute slot index of the patched word (EV_SET) or the stage's first slot
+  u64 bits;      // new word (low 32 bits for an f32 bank)
+};
+
+// Uniform per-launch context.
+struct Ctx {
+  const float* sine;  // LDS copy of the 16384-entry sine table
+  double f2pi;        // SinWt::freq_to_phase_inc (osc.rs:144-145)
+};
+
+// ---------------------------------------------------------------------------
+// Stages.  Each has: kSlots, kMutableMask (slots written back), Regs<F>,
+// load/store, tick (one sample), on_event.
+// ---------------------------------------------------------------------------
+
+// SinWt -- knaster_core_dsp/src/ugens/osc.rs:97-168, wavetable.rs:21-60,322-324
+// slots: 0 phase, 1 phase_offset, 2 phase_increment
+template <bool AR_FREQ>
+struct SinWtT {
+  static constexpr int kSlots = 3;
+  static constexpr u32 kMutableMask = AR_FREQ ? 0b101u : 0b001u;
+  static constexpr bool kUsesSine = true;
+  static constexpr bool kIsEnv = false;
+  template <typename F> struct Regs { u32 phase, off, inc; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
+    r.phase = (u32)s[0]; r.off = (u32)s[stride]; r.inc = (u32)s[2 * stride];
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long stride) {
+    s[0] = (W)r.phase;
+    if (AR_FREQ) s[2 * stride] = (W)r.inc;
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx& c, u32, u32&) {
+    if (AR_FREQ) {
+      // WrArParams::process (audio_rate.rs:42-57): param_apply(freq, x as f64) then process.
+      r.inc = sat_u32((double)x * c.f2pi);
+    }
+    float s = c.sine[((r.phase + r.off) >> 16) & 16383u];
+    r.phase += r.inc;
+    return (F)s;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    if (rel == 0) r.phase = (u32)bits;
+    else if (rel == 1) r.off = (u32)bits;
+    else r.inc = (u32)bits;
+  }
+};
+typedef SinWtT<false> SinWt;
+typedef SinWtT<true> SinWtAr;
+
+// SinNumeric -- osc.rs:222-271.  slots: 0 phase, 1 phase_offset, 2 phase_increment
+struct SinNum {
+  static constexpr int kSlots = 3;
+  static constexpr u32 kMutableMask = 0b001u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  template <typename F> struct Regs { F phase, off, inc; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
+    r.phase = word_to_f<F>(s[0]); r.off = word_to_f<F>(s[stride]); r.inc = word_to_f<F>(s[2 * stride]);
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = f_to_word(r.phase); }
+  static __device__ __forceinline__ float sin_f(float v) { return __ocml_sin_f32(v); }
+  static __device__ __forceinline__ double sin_f(double v) { return __ocml_sin_f64(v); }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
+    const F TAU = (F)6.28318530717958647692;
+    F out = sin_f((r.phase + r.off) * TAU);
+    r.phase += r.inc;
+    if (r.phase > (F)1) r.phase -= (F)1;
+    return out;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel == 0) r.phase = v;
+    else if (rel == 1) r.off = v;
+    else r.inc = v;
+  }
+};
+
+// SvfFilter tick -- svf.rs:272-278.  slots: 0 ic1eq, 1 ic2eq, 2 a1, 3 a2, 4 a3, 5 m0, 6 m1, 7 m2
+// All nine filter types share this tick; the type only changes the coefficients (host side).
+struct Svf {
+  static constexpr int kSlots = 8;
+  static constexpr u32 kMutableMask = 0b11u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m0, m1, m2; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.ic1 = word_to_f<F>(s[0]); r.ic2 = word_to_f<F>(s[st]); r.a1 = word_to_f<F>(s[2 * st]);
+    r.a2 = word_to_f<F>(s[3 * st]); r.a3 = word_to_f<F>(s[4 * st]); r.m0 = word_to_f<F>(s[5 * st]);
+    r.m1 = word_to_f<F>(s[6 * st]); r.m2 = word_to_f<F>(s[7 * st]);
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    s[0] = f_to_word(r.ic1); s[st] = f_to_word(r.ic2);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F v0, const Ctx&, u32, u32&) {
+    const F v3 = v0 - r.ic2;
+    if constexpr (FMA) {
+      const F v1 = mad<true>(r.a2, v3, r.a1 * r.ic1);
+      const F v2 = mad<true>(r.a3, v3, mad<true>(r.a2, r.ic1, r.ic2));
+      r.ic1 = mad<true>((F)2, v1, -r.ic1);
+      r.ic2 = mad<true>((F)2, v2, -r.ic2);
+      return mad<true>(r.m2, v2, mad<true>(r.m1, v1, r.m0 * v0));
+    } else {
+      const F v1 = r.a1 * r.ic1 + r.a2 * v3;
+      const F v2 = r.ic2 + r.a2 * r.ic1 + r.a3 * v3;
+      r.ic1 = (F)2 * v1 - r.ic1;
+      r.ic2 = (F)2 * v2 - r.ic2;
+      return r.m0 * v0 + r.m1 * v1 + r.m2 * v2;
+    }
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    switch (rel) {
+      case 0: r.ic1 = v; break; case 1: r.ic2 = v; break; case 2: r.a1 = v; break; case 3: r.a2 = v; break;
+      case 4: r.a3 = v; break; case 5: r.m0 = v; break; case 6: r.m1 = v; break; default: r.m2 = v; break;
+    }
+  }
+};
+
+// OnePoleLpf / OnePoleHpf tick -- onepole.rs:64-92.  slots: 0 last_output, 1 a0, 2 b1
+template <bool HIGHPASS>
+struct OnePoleT {
+  static constexpr int kSlots = 3;
+  static constexpr u32 kMutableMask = 0b1u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  template <typename F> struct Regs { F y, a0, b1; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.y = word_to_f<F>(s[0]); r.a0 = word_to_f<F>(s[st]); r.b1 = word_to_f<F>(s[2 * st]);
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = f_to_word(r.y); }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32, u32&) {
+    if constexpr (FMA) r.y = mad<true>(x, r.a0, r.y * r.b1);
+    else r.y = x * r.a0 + r.y * r.b1;
+    return HIGHPASS ? x - r.y : r.y;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel == 0) r.y = v; else if (rel == 1) r.a0 = v; else r.b1 = v;
+  }
+};
+typedef OnePoleT<false> OnePoleLp;
+typedef OnePoleT<true> OnePoleHp;
+
+// x * EnvAsr / x * EnvAr -- envelopes.rs:52-81,113-128 / 205-233 and MathUGen Mul (math.rs:39-49).
+// slots: 0 state, 1 t, 2 attack_rate, 3 release_rate, 4 release_scale
+// state: 0 Stopped, 1 Attacking, 2 Sustaining, 3 Releasing
+template <bool AR>
+struct MulEnvT {
+  static constexpr int kSlots = 5;
+  static constexpr u32 kMutableMask = 0b10011u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = true;
+  template <typename F> struct Regs { u32 state; F t, ar, rr, scale; u32 seg; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.state = (u32)s[0]; r.t = word_to_f<F>(s[st]); r.ar = word_to_f<F>(s[2 * st]);
+    r.rr = word_to_f<F>(s[3 * st]); r.scale = word_to_f<F>(s[4 * st]);
+    r.seg = 0;
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    s[0] = (W)r.state; s[st] = f_to_word(r.t); s[4 * st] = f_to_word(r.scale);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32 frame, u32& done_frame) {
+    const u32 st = r.state;
+    const F t = r.t;
+    // powi(3) = t*(t*t) (num-traits pow by squaring); then * release_scale
+    const F rel_out = (t * (t * t)) * r.scale;
+    F env = (F)0;
+    if (st == 1u) env = t;
+    if (st == 2u) env = (F)1;
+    if (st == 3u) env = rel_out;
+    if (st == 1u) {
+      F nt = t + r.ar;
+      r.t = nt;
+      if (nt >= (F)1) {
+        if (AR) { r.scale = (F)1; r.state = 3u; r.t = (F)1; }
+        else r.state = 2u;
+      }
+    } else if (st == 3u) {
+      F nt = t - r.rr;
+      r.t = nt;
+      // mark_done(i): i counts from the start of the (partial) block the envelope was handed
+      // (envelopes.rs:158-162 under precise_timing.rs:104-110)
+      if (nt <= (F)0) { r.state = 0u; r.t = (F)0; done_frame = frame - r.seg; }
+    }
+    return x * env;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 frame) {
+    if (op & EV_SPLIT) r.seg = frame;  // a queued WrPreciseTiming change starts a new partial block here
+    op &= 0x7Fu;
+    if (op == EV_ENV_ASR_RELEASE) {  // EnvAsr::t_release, envelopes.rs:113-128
+      if (r.state == 1u) { r.scale = r.t; r.state = 3u; r.t = (F)1; }
+      else if (r.state == 2u) { r.scale = (F)1; r.state = 3u; r.t = (F)1; }
+      return;
+    }
+    if ((op & 0x7Fu) != EV_SET) return;
+    if (rel == 0) { r.state = (u32)bits; return; }
+    F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel == 1) r.t = v; else if (rel == 2) r.ar = v; else if (rel == 3) r.rr = v; else r.scale = v;
+  }
+};
+typedef MulEnvT<false> MulAsr;
+typedef MulEnvT<true> MulAr;
+
+// x (op) value: Constant + MathUGen (util.rs:61-63, math.rs:22-85) and WrMul/WrAdd/WrSub
+// (wrappers_core/math.rs:62-67).  slot 0: value.  OP: 0 mul, 1 add, 2 sub, 3 div
+template <int OP>
+struct ValT {
+  static constexpr int kSlots = 1;
+  static constexpr u32 kMutableMask = 0u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  template <typename F> struct Regs { F v; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.v = word_to_f<F>(s[0]); }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32, u32&) {
+    if (OP == 0) return x * r.v;
+    if (OP == 1) return x + r.v;
+    if (OP == 2) return x - r.v;
+    return x / r.v;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32, u64 bits, u32 /*frame*/) {
+    if ((op & 0x7Fu) == EV_SET) r.v = word_to_f<F>((typename WordOf<F>::type)bits);
+  }
+};
+typedef ValT<0> MulVal;
+typedef ValT<1> AddVal;
+typedef ValT<2> SubVal;
+typedef ValT<3> DivVal;
+
+// ---------------------------------------------------------------------------
+// Chain = compile-time stage list with all registers inline.
+// ---------------------------------------------------------------------------
+template <typename F, bool FMA, int BASE, typename... S> struct Chain;
+template <typename F, bool FMA, int BASE>
+struct Chain<F, FMA, BASE> {
+  static constexpr int kSlots = BASE;
+  static constexpr bool kUsesSine = false;
+  template <typename W> __device__ __forceinline__ void load(const W*, long) {}
+  template <typename W> __device__ __forceinline__ void store(W*, long) const {}
+  __device__ __forceinline__ F tick(F x, const Ctx&, u32, u32&) { return x; }
+  __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
+  __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
+  __device__ __forceinline__ void begin_block(u32) {}
+};
+template <typename F, bool FMA, int BASE, typename S0, typename... Rest>
+struct Chain<F, FMA, BASE, S0, Rest...> {
+  typedef Chain<F, FMA, BASE + S0::kSlots, Rest...> RestT;
+  static constexpr int kSlots = RestT::kSlots;
+  static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
+  typename S0::template Regs<F> r;
+  RestT rest;
+  template <typename W> __device__ __forceinline__ void load(const W* s, long stride) {
+    S0::template load<F, W>(r, s + (long)BASE * stride, stride);
+    rest.load(s, stride);
+  }
+  template <typename W> __device__ __forceinline__ void store(W* s, long stride) const {
+    S0::template store<F, W>(r, s + (long)BASE * stride, stride);
+    rest.store(s, stride);
+  }
+  __device__ __forceinline__ F tick(F x, const Ctx& c, u32 frame, u32& done_frame) {
+    x = S0::template tick<F, FMA>(r, x, c, frame, done_frame);
+    return rest.tick(x, c, frame, done_frame);
+  }
+  __device__ __forceinline__ void on_event(u32 op, u32 slot, u64 bits, u32 frame) {
+    if (slot >= (u32)BASE && slot < (u32)(BASE + S0::kSlots)) S0::template on_event<F>(r, op, slot - BASE, bits, frame);
+    else rest.on_event(op, slot, bits, frame);
+  }
+  __device__ __forceinline__ bool last_env_stopped(bool dflt) const {
+    if constexpr (S0::kIsEnv) return rest.last_env_stopped(r.state == 0u);
+    else return rest.last_env_stopped(dflt);
+  }
+  __device__ __forceinline__ void begin_block(u32 frame_begin) {
+    if constexpr (S0::kIsEnv) r.seg = frame_begin;
+    rest.begin_block(frame_begin);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Kernel arguments
+// ---------------------------------------------------------------------------
+template <typename F>
+struct VoiceKernelArgs {
+  typename WordOf<F>::type* state;  // [n_slots][stride]
+  long stride;                      // words per slot row (>= n_voices, multiple of 64)
+  u32 n_voices;
+  u32 block_size;                   // row length of partials / voices_out
+  u32 frame_begin, frame_end;       // frames [begin, end) of the block are processed
+  const float* sine_table;          // 16384 floats in HBM (staged to LDS)
+  double f2pi;
+  const u32* ev_start;              // [n_voices + 1] or null when the block has no events
+  const Event* events;
+  F* partials;                      // [n_waves][block_size]: per-wavefront left-fold of its 64 voices
+  F* voices_out;                    // [n_voices][block_size] or null
+  u32* done_frames;                 // [n_voices]
+  u32* flags;                       // [0] |= any-done, [1] += voices whose last envelope is not Stopped
+};
+
+constexpr int kWave = 64;
+constexpr int kTile = 8;  // samples evaluated stage-by-stage in registers
+
+// LDS: sine table (64 KiB, only if a stage uses it) + one [TN][65] transpose tile per wave.
+template <typename F, bool FMA, int WAVES, typename... S>
+__global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a) {
+  typedef Chain<F, FMA, 0, S...> ChainT;
+  typedef typename WordOf<F>::type W;
+  constexpr int TN = sizeof(F) == 4 ? 64 : 32;  // frames per reduce tile
+  constexpr int TS = 65;                        // row stride: conflict-free both ways
+  __shared__ float sine[ChainT::kUsesSine ? 16384 : 1];
+  __shared__ F tile[WAVES][TN][TS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  if (ChainT::kUsesSine) {
+    const float4* src = reinterpret_cast<const float4*>(a.sine_table);
+    float4* dst = reinterpret_cast<float4*>(sine);
+    for (int i = threadIdx.x; i < 4096; i += WAVES * 64) dst[i] = src[i];
+    __syncthreads();
+  }
+  Ctx ctx;
+  ctx.sine = sine;
+  ctx.f2pi = a.f2pi;
+
+  const u32 wave_global = blockIdx.x * WAVES + wave;
+  const u32 v0 = wave_global * 64u;
+  if (v0 >= a.n_voices) return;
+  const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;  // live voices in this wave
+  const bool live = (u32)lane < nv;
+  const u32 voice = live ? v0 + lane : v0 + nv - 1;  // idle lanes shadow the last live voice, never store
+
+  ChainT chain;
+  chain.load(a.state + voice, a.stride);
+  chain.begin_block(a.frame_begin);
+
+  u32 ev_i = 0, ev_end = 0;
+  if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
+  u32 next_frame = 0xFFFFFFFFu;
+  if (ev_i < ev_end) next_frame = a.events[ev_i].frame_op & 0xFFFFu;
+  u32 done_frame = 0xFFFFFFFFu;
+
+  auto apply_events_upto = [&](u32 n) {
+    while (next_frame <= n) {
+      Event e = a.events[ev_i];
+      chain.on_event((e.frame_op >> 16) & 0xFFu, e.slot, e.bits, e.frame_op & 0xFFFFu);
+      ++ev_i;
+      next_frame = ev_i < ev_end ? (a.events[ev_i].frame_op & 0xFFFFu) : 0xFFFFFFFFu;
+    }
+  };
+
+  F(*my)[TS] = tile[wave];
+  for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {
+    const u32 len = a.frame_end - n0 < (u32)TN ? a.frame_end - n0 : (u32)TN;
+    for (u32 j0 = 0; j0 < len; j0 += kTile) {
+      const u32 n = n0 + j0;
+      apply_events_upto(n);
+      const bool full = j0 + kTile <= len;
+      const bool ev_inside = next_frame < n + kTile;
+      if (full && !__builtin_amdgcn_ballot_w64(ev_inside)) {
+        // fast path: kTile samples, fully unrolled
+        F x[kTile];
+#pragma unroll
+        for (int j = 0; j < kTile; ++j) x[j] = chain.tick((F)0, ctx, n + j, done_frame);
+#pragma unroll
+        for (int j = 0; j < kTile; ++j) my[j0 + j][lane] = x[j];
+      } else {
+        const u32 m = len - j0 < (u32)kTile ? len - j0 : (u32)kTile;
+        for (u32 j = 0; j < m; ++j) {
+          apply_events_upto(n + j);
+          my[j0 + j][lane] = chain.tick((F)0, ctx, n + j, done_frame);
+        }
+      }
+    }
+    // Transposed reduce: lane j folds frame j over the wave's voices in voice order.
+    // (same-wave LDS traffic: program order is enough, no barrier needed)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if ((u32)lane < len) {
+      F acc = my[lane][0];
+      for (u32 v = 1; v < nv; ++v) acc = acc + my[lane][v];
+      a.partials[(long)wave_global * a.block_size + n0 + lane] = acc;
+    }
+    if (a.voices_out) {
+      for (u32 v = 0; v < nv; ++v)
+        if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[lane][v];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+  // changes due exactly at the end of the processed range (precise_timing.rs:85-103 runs the
+  // change loop once more before breaking out)
+  apply_events_upto(a.frame_end);
+
+  if (live) {
+    chain.store(a.state + voice, a.stride);
+    a.done_frames[voice] = done_frame;
+  }
+  const bool any_done = live && done_frame != 0xFFFFFFFFu;
+  const bool running = live && !chain.last_env_stopped(false);
+  const u64 bd = __builtin_amdgcn_ballot_w64(any_done);
+  const u64 br = __builtin_amdgcn_ballot_w64(running);
+  if (lane == 0) {
+    if (bd) atomicOr(&a.flags[0], 1u);
+    if (br) atomicAdd(&a.flags[1], (u32)__builtin_popcountll(br));
+  }
+}
+
+// Folds the per-wavefront partials in wavefront order and writes every output channel.
+// out: [channels][block_size]; frames [frame_begin, frame_end) are written.
+template <typename F>
+__global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
+                                                        u32 frame_end, F* out, u32 channels, u32 out_stride) {
+  const u32 n = frame_begin + blockIdx.x * 64u + threadIdx.x;
+  if (n >= frame_end) return;
+  F acc = rows[n];
+  for (u32 r = 1; r < n_rows; ++r) acc = acc + rows[(long)r * row_len + n];
+  for (u32 c = 0; c < channels; ++c) out[(long)c * out_stride + n] = acc;
+}
+
+}  // namespace knh_dev

@@ -1,0 +1,49 @@
+"""Shared test plumbing: drive the HIP bank and the CPU oracle with identical calls."""
+from __future__ import annotations
+
+import numpy as np
+
+from knaster_amd import _lib as L
+from knaster_amd import configs
+
+
+def make_oracle(oracle, w: configs.Workload, want_mix=True, want_voices=True):
+    b = oracle.OracleBank(w.stages, w.n_voices, w.sample_type, w.out_channels, want_mix, want_voices)
+    for s, a in w.ctor.items():
+        b.set_ctor_args(s, a)
+    b.init(configs.SAMPLE_RATE, w.block_size)
+    return b
+
+
+def make_gpu(knh, w: configs.Workload, mix_mode=L.MIX_TREE, allow_fma=False):
+    b = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, mix_mode, -1, allow_fma)
+    for s, a in w.ctor.items():
+        b.set_ctor_args(s, a)
+    b.init(configs.SAMPLE_RATE, w.block_size)
+    return b
+
+
+def fire_all(bank, n_voices, stage, param):
+    """One trigger per voice, in voice order (param_apply_many on both backends)."""
+    bank.param_apply_many(np.arange(n_voices, dtype=np.uint32), stage, param, L.VALUE_TRIGGER)
+
+
+def bits(a: np.ndarray) -> np.ndarray:
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def assert_bit_equal(a: np.ndarray, b: np.ndarray, what=""):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, f"{what}: shape/dtype {a.shape}{a.dtype} vs {b.shape}{b.dtype}"
+    # -0.0 and +0.0 are the same sample; everything else must match to the bit
+    same = (bits(a) == bits(b)) | ((a == 0) & (b == 0))
+    if not same.all():
+        idx = np.argwhere(~same)[0]
+        raise AssertionError(f"{what}: {np.count_nonzero(~same)} of {a.size} samples differ; first at {tuple(idx)}: "
+                             f"{a[tuple(idx)]!r} vs {b[tuple(idx)]!r}")
+
+
+def f64_mix(voices: np.ndarray) -> np.ndarray:
+    """The mix accumulated in f64 (the tolerance reference of SURVEY.md hard part 3)."""
+    return voices.astype(np.float64).sum(axis=0)

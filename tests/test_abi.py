@@ -1,0 +1,114 @@
+"""The C-ABI boundary on a machine without a GPU: the library loads, exports every symbol the
+header declares (and the ctypes prototypes cover all of them), validates chains, and refuses to
+compute -- there is no CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from knaster_amd import _lib as L
+from knaster_amd import configs
+from knaster_amd.bank import Stage
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "knaster_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(knh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(knh):
+    lib = C.CDLL(L.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in knaster_hip.h but not exported"
+    assert set(names) == set(L.PROTOTYPES), "ctypes prototypes and header disagree"
+    assert knh.lib.load().knh_abi_version() == L.KNH_ABI_VERSION
+
+
+def test_no_oracle_in_product():
+    """The product never links, includes or imports the oracle."""
+    for root, _dirs, files in os.walk(os.path.join(ROOT, "knaster_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert "oracle" not in text.lower().replace("oracle/_ref", ""), f"{f} mentions the oracle"
+
+
+def test_chain_validation_and_ugen_count(knh):
+    c3 = configs.config("C3", n_voices=4, block_size=16)
+    assert knh.chain_ugen_count(c3.stages) == 4      # SinWt(+WrMul), SvfFilter, EnvAsr, MathUGen Mul
+    assert knh.chain_ugen_count(configs.config("C1").stages) == 3  # SinWt, Constant, MathUGen Mul
+    with pytest.raises(L.KnasterHipError) as e:      # processor without a source
+        knh.VoiceBank([Stage(L.STAGE_SVF)], 4)
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    with pytest.raises(L.KnasterHipError) as e:      # second plain source mid-chain
+        knh.VoiceBank([Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT)], 4)
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    with pytest.raises(L.KnasterHipError) as e:      # valid chain, but no fused kernel is built for it
+        knh.VoiceBank([Stage(L.STAGE_SIN_NUMERIC), Stage(L.STAGE_ONEPOLE_HPF), Stage(L.STAGE_ONEPOLE_LPF),
+                       Stage(L.STAGE_DIV_CONST)], 4)
+    assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
+    with pytest.raises(L.KnasterHipError):
+        knh.VoiceBank(c3.stages, 0)
+    with pytest.raises(L.KnasterHipError):
+        knh.VoiceBank(c3.stages, 4, out_channels=3)
+
+
+def test_bank_metadata_without_device(knh):
+    w = configs.config("C3", n_voices=4, block_size=16)
+    b = knh.VoiceBank(w.stages, 4)
+    assert b.inputs() == 0 and b.outputs() == 2
+    assert b.stage_param_descriptions(0) == ["freq", "phase_offset", "reset_phase"]          # osc.rs:126-140
+    assert b.stage_param_descriptions(1) == ["wr_mul"]                                       # math.rs:79
+    assert b.stage_param_descriptions(2) == ["cutoff_freq", "q", "gain", "filter", "t_calculate_coefficients"]
+    assert b.stage_param_descriptions(3) == ["attack_time", "release_time", "t_release", "t_restart"]
+    assert b.algorithmic_bytes_per_voice_block() == (68, 24)  # 92 B per voice per block
+    with pytest.raises(L.KnasterHipError) as e:
+        b.set_ctor_args(0, np.zeros((5, 1)))  # more voices than the bank has
+    assert e.value.status == L.ERR_OUT_OF_RANGE
+    with pytest.raises(L.KnasterHipError) as e:
+        b.set_ctor_args(2, np.zeros((4, 1)))  # SvfFilter::new takes 4 arguments
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    with pytest.raises(L.KnasterHipError) as e:
+        b.param_apply(0, 0, 0, 440.0)
+    assert e.value.status == L.ERR_NOT_INITIALISED
+    with pytest.raises(L.KnasterHipError) as e:
+        b.process_block()
+    assert e.value.status == L.ERR_NOT_INITIALISED
+    b.close()
+    w64 = configs.config("C4", n_voices=4, block_size=16)
+    b = knh.VoiceBank(w64.stages, 4, L.F64)
+    assert b.algorithmic_bytes_per_voice_block() == (136, 48)
+    b.close()
+
+
+def test_compute_fails_loudly_without_gpu(knh):
+    if knh.lib.load().knh_device_count() > 0:
+        pytest.skip("a gfx950 device is present")
+    w = configs.config("C1")
+    b = knh.VoiceBank(w.stages, 1)
+    for s, a in w.ctor.items():
+        b.set_ctor_args(s, a)
+    with pytest.raises(L.KnasterHipError) as e:
+        b.init(48000, 64)
+    assert e.value.status == L.ERR_NO_DEVICE
+    assert "no CPU path" in str(e.value)
+    b.close()
+
+
+def test_workload_inputs_are_deterministic():
+    a = configs.voice_parameters(16)
+    b = configs.voice_parameters(16)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert a["freq"].min() >= 55.0 and a["freq"].max() <= 3520.0
+    assert a["cutoff"].max() < 24000.0
+    w = configs.config("C3")
+    assert (w.n_voices, w.block_size, w.sample_type) == (16384, 512, L.F32)
+    assert abs(float(w.ctor[1].sum()) - 1.0) < 1e-9  # sum of gains = 1

@@ -1,0 +1,269 @@
+"""GPU parity: the HIP voice bank, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: every voice's own signal bit-exact (integer phase, + - * only); SinNumeric
+within 1e-5 (device sin); the mixed block within 1e-5 of the f64-accumulated mix, and bit-exact
+in KNH_MIX_LEFT_FOLD mode."""
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, f64_mix, fire_all, make_gpu, make_oracle
+from knaster_amd import _lib as L
+from knaster_amd import configs
+from knaster_amd.bank import Stage
+
+pytestmark = pytest.mark.gpu
+
+MIX_TOL = 1e-5  # north_star: "f32 output within 1e-5 of CPU reference"
+
+
+def run_pair(knh, oracle, w, blocks, events=None, mix_mode=L.MIX_TREE, allow_fma=False, voice_tol=None):
+    """events(block, bank) is called on both banks before each block."""
+    g = make_gpu(knh, w, mix_mode, allow_fma)
+    o = make_oracle(oracle, w)
+    for b in range(blocks):
+        if events:
+            events(b, g)
+            events(b, o)
+        g_out, g_voices, g_flags = g.process_block_voices()
+        o_out, o_voices, o_flags, o_done = o.process_block()
+        if voice_tol is None:
+            assert_bit_equal(g_voices, o_voices, f"{w.name} block {b} per-voice")
+        else:
+            assert np.max(np.abs(g_voices.astype(np.float64) - o_voices)) <= voice_tol, f"{w.name} block {b}"
+        ref = f64_mix(o_voices)
+        for c in range(w.out_channels):
+            assert np.max(np.abs(g_out[c].astype(np.float64) - ref)) <= MIX_TOL, f"{w.name} block {b} mix ch{c}"
+            if mix_mode == L.MIX_LEFT_FOLD and voice_tol is None:
+                assert_bit_equal(g_out[c], o_out[c], f"{w.name} block {b} left-fold mix ch{c}")
+        if w.out_channels == 2:
+            assert_bit_equal(g_out[0], g_out[1], "L == R")
+        np.testing.assert_array_equal(g.read_done_frames(), o_done)
+        assert (g_flags & L.FLAG_ANY_DONE) == (o_flags & L.FLAG_ANY_DONE)
+    g.close()
+    o.close()
+
+
+def test_c1_readme_example(knh, oracle):
+    w = configs.config("C1")
+    run_pair(knh, oracle, w, 4, mix_mode=L.MIX_LEFT_FOLD)
+
+
+def c3_events(w):
+    def ev(block, bank):
+        if block == 0:
+            fire_all(bank, w.n_voices, *w.restart)
+        if block == 2:
+            fire_all(bank, w.n_voices, w.release[0], w.release[1])
+    return ev
+
+
+@pytest.mark.parametrize("mix_mode", [L.MIX_TREE, L.MIX_LEFT_FOLD])
+def test_c3_chain_bit_exact(knh, oracle, mix_mode):
+    w = configs.config("C3", n_voices=320, block_size=512)
+    run_pair(knh, oracle, w, 5, c3_events(w), mix_mode)
+
+
+def test_c4_f64_chain_bit_exact(knh, oracle):
+    w = configs.config("C4", n_voices=192, block_size=512)
+    run_pair(knh, oracle, w, 4, c3_events(w), L.MIX_LEFT_FOLD)
+
+
+def test_c2_sin_numeric_within_tolerance(knh, oracle):
+    w = configs.config("C2", n_voices=256, block_size=256)
+    # device sin vs glibc sinf: not bit-exact by design; phase accumulation is, so errors do not grow
+    run_pair(knh, oracle, w, 6, voice_tol=1e-5 / 256 * 4)
+    w64 = configs.config("C2", n_voices=64, block_size=256, sample_type=L.F64)
+    run_pair(knh, oracle, w64, 3, voice_tol=1e-12)
+
+
+def test_c5_audio_rate_fm_with_sample_accurate_changes(knh, oracle):
+    w = configs.config("C5", n_voices=192, block_size=128)
+
+    def ev(block, bank):
+        e = configs.c5_events(w, block)
+        if e is not None:
+            voices, stages, params, kinds, fvalues, delays = e
+            bank.param_apply_many(voices, stages, params, kinds, fvalues, None, delays)
+    run_pair(knh, oracle, w, 8, ev, L.MIX_LEFT_FOLD)
+
+
+def test_fm_saturating_frequency_cast(knh, oracle):
+    """Negative / huge instantaneous frequencies: Rust `as u32` saturates (osc.rs:129)."""
+    w = configs.config("C5", n_voices=64, block_size=128)
+    w.ctor[1] = np.full((64, 1), 3.0e9)   # index: +-3e9 Hz swings -> negative and > u32::MAX increments
+    w.ctor[2] = np.linspace(-1000.0, 1000.0, 64).reshape(64, 1)
+    run_pair(knh, oracle, w, 3, None, L.MIX_TREE)
+
+
+@pytest.mark.parametrize("ty", range(9))
+def test_every_svf_type_and_its_setters(knh, oracle, ty):
+    n = 64
+    w = configs.Workload("svf", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SVF)], n, 256, L.F32, 1)
+    p = configs.voice_parameters(n)
+    w.ctor = {0: p["freq"].reshape(n, 1),
+              1: np.stack([np.full(n, float(ty)), p["cutoff"], p["q"], np.linspace(-12, 12, n)], axis=1)}
+    v = np.arange(n, dtype=np.uint32)
+
+    def ev(block, bank):
+        if block == 1:
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, p["cutoff"] * 0.5)
+        if block == 2:
+            bank.param_apply_many(v, 1, 1, L.VALUE_FLOAT, p["q"] + 1.0)
+            bank.param_apply_many(v, 1, 2, L.VALUE_FLOAT, np.full(n, 3.0))
+        if block == 3:
+            bank.param_apply_many(v, 1, 3, L.VALUE_INTEGER, None, (v.astype(np.int64) + ty) % 11)  # 9,10 -> Low
+            bank.param_apply_many(v, 1, 4, L.VALUE_TRIGGER)
+    run_pair(knh, oracle, w, 5, ev)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_onepole_and_envelope_chains(knh, oracle, sample_type):
+    n = 96
+    p = configs.voice_parameters(n)
+    gain = np.full((n, 1), 1.0 / n)
+    lp = configs.Workload("lp", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_ONEPOLE_LPF), Stage(L.STAGE_MUL_ENV_ASR),
+                                 Stage(L.STAGE_MUL_CONST)], n, 128, sample_type, 2)
+    lp.ctor = {0: p["freq"].reshape(n, 1), 1: p["cutoff"].reshape(n, 1),
+               2: np.stack([p["attack"] * 0.1, p["release"] * 0.02], axis=1), 3: gain}
+    hp = configs.Workload("hp", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_ONEPOLE_HPF), Stage(L.STAGE_MUL_ENV_AR),
+                                 Stage(L.STAGE_MUL_CONST)], n, 128, sample_type, 2)
+    hp.ctor = {0: p["freq"].reshape(n, 1), 2: np.stack([p["attack"] * 0.1, p["release"] * 0.02], axis=1), 3: gain}
+    v = np.arange(n, dtype=np.uint32)
+
+    def ev_lp(block, bank):
+        if block == 0:
+            fire_all(bank, n, 2, 3)
+        if block == 1:  # early release for half the voices while still attacking (release_scale = t)
+            bank.param_apply_many(v[::2], 2, 2, L.VALUE_TRIGGER)
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, p["cutoff"] * 2.0)
+        if block == 4:
+            fire_all(bank, n, 2, 2)
+        if block == 6:  # restart from wherever t is (envelopes.rs:47-49)
+            fire_all(bank, n, 2, 3)
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, np.zeros(n))  # attack 0 -> rate 1
+
+    def ev_hp(block, bank):
+        if block in (0, 5):
+            fire_all(bank, n, 2, 2)
+        if block == 2:
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, p["cutoff"])
+            bank.param_apply_many(v, 2, 1, L.VALUE_FLOAT, p["release"] * 0.01)
+    run_pair(knh, oracle, lp, 9, ev_lp, L.MIX_LEFT_FOLD)
+    run_pair(knh, oracle, hp, 8, ev_hp, L.MIX_LEFT_FOLD)
+
+
+def test_many_sines_shape_and_math_stages(knh, oracle):
+    n = 130
+    p = configs.voice_parameters(n)
+    ms = configs.Workload("many_sines", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_MUL_ENV_AR)], n, 64,
+                          L.F32, 2)
+    ms.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.0125), 2: np.tile([0.01, 0.1], (n, 1))}
+    v = np.arange(n, dtype=np.uint32)
+
+    def ev(block, bank):
+        if block % 3 == 0:
+            bank.param_apply_many(v, 2, 2, L.VALUE_TRIGGER)
+            bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, p["freq"] * (1 + block))
+        if block == 4:
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, np.full(n, 0.02))  # "wr_mul"
+            bank.param_apply_many(v, 0, 1, L.VALUE_FLOAT, np.linspace(0, 16383, n))  # phase_offset
+            bank.param_apply_many(v[::3], 0, 2, L.VALUE_TRIGGER)  # reset_phase
+    run_pair(knh, oracle, ms, 8, ev, L.MIX_LEFT_FOLD)
+    mt = configs.Workload("math", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_ADD_CONST), Stage(L.STAGE_SUB_CONST),
+                                   Stage(L.STAGE_DIV_CONST)], n, 64, L.F32, 1)
+    mt.ctor = {0: p["freq"].reshape(n, 1), 1: p["q"].reshape(n, 1), 2: p["attack"].reshape(n, 1), 3: p["cutoff"].reshape(n, 1)}
+    run_pair(knh, oracle, mt, 3, None, L.MIX_LEFT_FOLD)
+
+
+@pytest.mark.parametrize("n_voices,block_size", [(1, 1), (63, 7), (65, 100), (130, 64), (64, 513)])
+def test_ragged_sizes(knh, oracle, n_voices, block_size):
+    w = configs.config("C3", n_voices=n_voices, block_size=block_size)
+    run_pair(knh, oracle, w, 4, c3_events(w), L.MIX_LEFT_FOLD)
+
+
+def test_precise_timing_semantics(knh, oracle):
+    """WrPreciseTiming quirks (precise_timing.rs): FIFO head-of-line blocking, armed delays persisting,
+    capacity overflow dropping changes, changes due past the block being lost."""
+    n = 64
+    w = configs.Workload("pt", [Stage(L.STAGE_SIN_WT, delayed_changes_per_block=3), Stage(L.STAGE_SVF, delayed_changes_per_block=2),
+                                Stage(L.STAGE_MUL_ENV_ASR, delayed_changes_per_block=4)], n, 64, L.F32, 1)
+    p = configs.voice_parameters(n)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.stack([np.zeros(n), p["cutoff"], p["q"], np.zeros(n)], axis=1),
+              2: np.tile([0.0005, 0.001], (n, 1))}
+    rng = np.random.default_rng(7)
+    script = []
+    for block in range(10):
+        ops = []
+        for _ in range(rng.integers(0, 40)):
+            voice = int(rng.integers(0, n))
+            stage = int(rng.integers(0, 3))
+            if stage == 0:
+                param = int(rng.integers(0, 3))
+                value = [float(rng.uniform(50, 5000)), float(rng.uniform(0, 16000)), None][param]
+            elif stage == 1:
+                param = int(rng.integers(0, 3))
+                value = [float(rng.uniform(100, 9000)), float(rng.uniform(0.5, 4)), float(rng.uniform(-6, 6))][param]
+            else:
+                param = int(rng.integers(0, 4))
+                value = [float(rng.uniform(0.0001, 0.002)), float(rng.uniform(0.0001, 0.002)), None, None][param]
+            delay = int(rng.choice([0, 0, 1, 5, 17, 63, 64, 70]))
+            arm = bool(rng.integers(0, 2))
+            ops.append((voice, stage, param, value, delay, arm))
+        script.append(ops)
+
+    def ev(block, bank):
+        from knaster_amd.bank import TRIGGER
+        for voice, stage, param, value, delay, arm in script[block]:
+            if arm:
+                bank.set_delay_within_block_for_param(voice, stage, param, delay)
+            bank.param_apply(voice, stage, param, TRIGGER if value is None else value)
+    run_pair(knh, oracle, w, 10, ev)
+
+
+def test_fma_variant_within_tolerance(knh, oracle):
+    w = configs.config("C3", n_voices=256, block_size=512)
+    run_pair(knh, oracle, w, 4, c3_events(w), allow_fma=True, voice_tol=1e-5 / 256 * 8)
+
+
+def test_done_flags_and_all_done(knh, oracle):
+    n = 70
+    w = configs.Workload("done", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MUL_ENV_ASR)], n, 16, L.F32, 2)
+    w.ctor = {0: np.full((n, 1), 440.0), 1: np.tile([0.0, 0.0], (n, 1))}  # graph.rs:2483-2513
+
+    def ev(block, bank):
+        if block == 1:
+            fire_all(bank, n, 1, 3)
+        if block == 2:
+            fire_all(bank, n, 1, 2)
+    run_pair(knh, oracle, w, 5, ev, L.MIX_LEFT_FOLD)
+    g = make_gpu(knh, w)
+    _, flags = g.process_block()
+    assert flags & L.FLAG_ALL_DONE  # never started: every envelope Stopped
+    fire_all(g, n, 1, 3)
+    _, flags = g.process_block()
+    assert not (flags & L.FLAG_ALL_DONE)
+    fire_all(g, n, 1, 2)
+    _, flags = g.process_block()
+    assert flags & L.FLAG_ANY_DONE
+    _, flags = g.process_block()
+    assert flags & L.FLAG_ALL_DONE and not (flags & L.FLAG_ANY_DONE)
+    g.close()
+
+
+def test_error_behaviour_on_device(knh):
+    w = configs.config("C3", n_voices=8, block_size=32)
+    g = make_gpu(knh, w)
+    with pytest.raises(L.KnasterHipError) as e:
+        g.param_apply(8, 0, 0, 1.0)
+    assert e.value.status == L.ERR_OUT_OF_RANGE
+    with pytest.raises(L.KnasterHipError) as e:
+        g.param_apply(0, 0, 3, 1.0)  # SinWt has 3 params
+    assert e.value.status == L.ERR_OUT_OF_RANGE
+    with pytest.raises(L.KnasterHipError) as e:
+        g.param_apply(0, 2, 0, knh.TRIGGER)  # cutoff_freq wants a float
+    assert e.value.status == L.ERR_WRONG_VALUE_KIND
+    with pytest.raises(L.KnasterHipError) as e:
+        g.process_block(frames_to_process=33)
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    out, _ = g.process_block()  # still usable after errors ("log and continue")
+    assert out.shape == (2, 32)
+    g.close()
