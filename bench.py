@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- UGen-samples/s of the fused voice-bank path on N MI355X (BASELINE.json metric).
+
+Workload: BASELINE.json configs[2] ("C3"): 16384 voices per GPU, chain
+SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, block_size 512, f32, 48 kHz, synthetic
+per-voice parameters (xorshift32).  One *step* = one 512-frame block of every
+voice on every rank.  Voices shard across ranks (one process per GPU); each rank folds its own
+voices into a stereo block and the stereo blocks are sum-reduced to rank 0 over RCCL in batches
+of REDUCE_EVERY blocks (the reduce is latency-bound at 4 KiB per block).
+
+Launch: `python bench.py` (N=1) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_OPS = 78.6e12        # 157.3 TFLOP/s FP32 vector counts an FMA as 2: 78.6e12 non-fused ops/s
+OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per voice-sample / 4 UGens
+REDUCE_EVERY = 64              # blocks per RCCL reduce
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--voices-per-gpu", type=int, default=16384)
+    ap.add_argument("--block-size", type=int, default=512)
+    ap.add_argument("--allow-fma", action="store_true", help="non-bit-exact FMA kernels (reported as such)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-blocks", type=int, default=0, help="0 = auto (about 10-20 s)")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, cores: int, blocks: int):
+    """The oracle (unfused reference-shaped graph, `cores` independent sequential schedulers) on a
+    bounded sample of the same workload.  Checker code timed as a baseline -- never the product."""
+    from oracle import oracle_py
+
+    t0 = time.perf_counter()
+    secs, _ = oracle_py.baseline_run(w.stages, w.n_voices, w.sample_type, w.out_channels, w.ctor, 48000, w.block_size,
+                                     1, blocks, cores, w.restart, (w.release[0], w.release[1], blocks // 2))
+    wall = time.perf_counter() - t0
+    return secs, wall
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+
+    import knaster_amd
+    from knaster_amd import _lib as L
+    from knaster_amd import configs
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the voice-bank path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    nv, bs = args.voices_per_gpu, args.block_size
+    # every rank owns a contiguous range of the global voice list: parameters are drawn for the whole
+    # list (one xorshift stream, voices in index order) and sliced
+    w_all = configs.config("C3", n_voices=nv * world, block_size=bs)
+    lo, hi = rank * nv, (rank + 1) * nv
+    bank = knaster_amd.VoiceBank(w_all.stages, nv, w_all.sample_type, w_all.out_channels, L.MIX_TREE, local_rank, args.allow_fma)
+    for s, a in w_all.ctor.items():
+        bank.set_ctor_args(s, a[lo:hi])
+    bank.init(configs.SAMPLE_RATE, bs)
+    ugens = knaster_amd.chain_ugen_count(w_all.stages)
+    voices = np.arange(nv, dtype=np.uint32)
+
+    stream = torch.cuda.current_stream()
+    ring = torch.zeros((REDUCE_EVERY, w_all.out_channels, bs), dtype=torch.float32, device=dev)
+    slot_bytes = w_all.out_channels * bs * 4
+    ring_ptr = ring.data_ptr()
+
+    def run_steps(first_step: int, n: int, release_at: int):
+        for i in range(n):
+            step = first_step + i
+            if step == 0:
+                bank.param_apply_many(voices, w_all.restart[0], w_all.restart[1], L.VALUE_TRIGGER)
+            if step == release_at:
+                bank.param_apply_many(voices, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER)
+            slot = step % REDUCE_EVERY
+            bank.process_block_device(ring_ptr + slot * slot_bytes, stream.cuda_stream)
+            if world > 1 and slot == REDUCE_EVERY - 1:
+                dist.reduce(ring, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    release_at = args.warmup + args.steps // 2
+    run_steps(0, args.warmup, release_at)
+    fence()
+    bank.timing_reset(True)
+    t0 = time.perf_counter()
+    run_steps(args.warmup, args.steps, release_at)
+    if world > 1 and (args.warmup + args.steps) % REDUCE_EVERY != 0:
+        dist.reduce(ring, dst=0, op=dist.ReduceOp.SUM)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = bank.timing_read()
+    bank.timing_reset(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kernel_avg_ms = float(k.item())
+    else:
+        kernel_avg_ms = kernel_ms / max(launches, 1)
+
+    sane = bool(torch.isfinite(ring).all().item())
+    if rank == 0:
+        total_voices = nv * world
+        ugen_samples = float(total_voices) * bs * ugens * args.steps
+        value = ugen_samples / elapsed
+        rd, wr = bank.algorithmic_bytes_per_voice_block()
+        alg_bytes_per_launch = float(rd + wr) * nv  # one launch = one block of this rank's voices
+        achieved_gbs = alg_bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+        kernel_rate = float(nv) * bs * ugens / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
+        line = {
+            "metric": "UGen-samples/sec (voices x block_size x UGens / s)",
+            "value": value,
+            "unit": "UGen-samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3: SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, stereo mix",
+                "voices_per_gpu": nv, "voices_total": total_voices, "block_size": bs, "sample_rate": 48000,
+                "ugens_per_voice": ugens, "mix": "two-level left fold (deterministic)",
+                "arithmetic": "fma" if args.allow_fma else "exact (bit-identical per voice to the CPU oracle)",
+                "parallelism": f"voices sharded over {world} rank(s); RCCL sum-reduce of stereo blocks every {REDUCE_EVERY} blocks",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "voice_kernel<float,...,SinWt,MulVal,Svf,MulAsr>",
+                "kernel_avg_ms": kernel_avg_ms, "launches": launches,
+                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "note": "fused kernel moves 92 B per voice per block; it is bound by dependent FP32 VALU issue, not HBM (see valu)",
+            },
+            "valu": {
+                "achieved_ops_per_s": kernel_rate * OPS_PER_UGEN_SAMPLE, "peak_ops_per_s": VALU_PEAK_OPS,
+                "frac": kernel_rate * OPS_PER_UGEN_SAMPLE / VALU_PEAK_OPS,
+                "ops_per_ugen_sample": OPS_PER_UGEN_SAMPLE, "kernel_only_ugen_samples_per_s": kernel_rate,
+            },
+            "output_finite": sane,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cores = os.cpu_count() or 1
+            blocks = args.cpu_baseline_blocks or 64
+            secs, wall = cpu_baseline(w_all, cores, blocks)
+            line["cpu_baseline"] = {
+                "value": float(total_voices) * bs * ugens * blocks / secs, "unit": "UGen-samples/s", "cores": cores,
+                "kind": "port",
+                "sample": f"{blocks} blocks of the same {total_voices}-voice C3 graph, unfused reference-shaped node graph, "
+                          f"{cores} independent sequential schedulers (oracle, g++ -O3 -ffp-contract=off)",
+                "seconds": secs,
+            }
+            secs1, _ = cpu_baseline(w_all, 1, max(4, blocks // 8))
+            line["cpu_baseline_single_thread"] = {
+                "value": float(total_voices) * bs * ugens * max(4, blocks // 8) / secs1, "unit": "UGen-samples/s", "cores": 1,
+                "kind": "port", "sample": f"{max(4, blocks // 8)} blocks, one sequential scheduler (the reference is single-threaded)",
+            }
+        print(json.dumps(line), flush=True)
+    bank.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

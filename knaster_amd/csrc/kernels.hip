@@ -33,6 +33,7 @@ static const KernelEntry kEntries[] = {
     KNH_CHAIN("WA", SinWt, MulAsr),
     KNH_CHAIN("WE", SinWt, MulAr),
     KNH_CHAIN("WmE", SinWt, MulVal, MulAr),                     // knaster/examples/many_sines.rs:51-63 minus Pan2
+    KNH_CHAIN("WSA", SinWt, Svf, MulAsr),
     KNH_CHAIN("WSAm", SinWt, Svf, MulAsr, MulVal),
     KNH_CHAIN("WLAm", SinWt, OnePoleLp, MulAsr, MulVal),
     KNH_CHAIN("WHEm", SinWt, OnePoleHp, MulAr, MulVal),

@@ -426,6 +426,9 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
     while (next_frame <= n) {
       Event e = a.events[ev_i];
       chain.on_event((e.frame_op >> 16) & 0xFFu, e.slot, e.bits, e.frame_op & 0xFFFFu);
+      // a patched coefficient slot is not part of the end-of-block write-back: persist it now
+      // (mutable slots are overwritten by their evolved value at the end of the block)
+      if (live && ((e.frame_op >> 16) & 0x7Fu) == EV_SET) a.state[(long)e.slot * a.stride + voice] = (W)e.bits;
       ++ev_i;
       next_frame = ev_i < ev_end ? (a.events[ev_i].frame_op & 0xFFFFu) : 0xFFFFFFFFu;
     }

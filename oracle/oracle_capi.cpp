@@ -199,41 +199,49 @@ double kno_baseline_run(const knh_stage_desc* stages, uint32_t n_stages, uint32_
   }
   const size_t esz = sample_type == KNH_F64 ? 8 : 4;
   const size_t out_len = out_channels * block_size;
-  std::vector<std::vector<unsigned char>> outs(threads, std::vector<unsigned char>(out_len * esz));
-  std::vector<unsigned char> total(out_len * esz);
-  auto fire = [&](int stage, uint32_t param) {
-    for (uint32_t t = 0; t < threads; ++t)
-      for (uint32_t v = 0; v < first[t + 1] - first[t]; ++v)
-        shards[t]->param_apply(v, static_cast<uint32_t>(stage), param, ParameterValue::Trig());
+  // Every shard runs all its blocks on its own thread (an independent sequential scheduler, as a
+  // user could do with independent AudioProcessors); per-block partial mixes are summed afterwards.
+  const uint32_t total_blocks = warmup_blocks + blocks;
+  std::vector<std::vector<unsigned char>> outs(threads, std::vector<unsigned char>(out_len * esz * blocks));
+  auto shard_run = [&](uint32_t t, uint32_t from, uint32_t to) {
+    const uint32_t nv = first[t + 1] - first[t];
+    std::vector<unsigned char> scratch(out_len * esz);
+    for (uint32_t i = from; i < to; ++i) {
+      if (restart_stage >= 0 && i == 0)
+        for (uint32_t v = 0; v < nv; ++v) shards[t]->param_apply(v, static_cast<uint32_t>(restart_stage), restart_param, ParameterValue::Trig());
+      if (release_stage >= 0 && i == warmup_blocks + release_block)
+        for (uint32_t v = 0; v < nv; ++v) shards[t]->param_apply(v, static_cast<uint32_t>(release_stage), release_param, ParameterValue::Trig());
+      void* dst = i < warmup_blocks ? scratch.data() : outs[t].data() + static_cast<size_t>(i - warmup_blocks) * out_len * esz;
+      shards[t]->process(dst, nullptr, nullptr, nullptr);
+    }
   };
-  auto run_block = [&]() {
+  auto run_range = [&](uint32_t from, uint32_t to) {
     if (threads == 1) {
-      shards[0]->process(outs[0].data(), nullptr, nullptr, nullptr);
+      shard_run(0, from, to);
     } else {
       std::vector<std::thread> th;
-      for (uint32_t t = 0; t < threads; ++t)
-        th.emplace_back([&, t] { shards[t]->process(outs[t].data(), nullptr, nullptr, nullptr); });
+      for (uint32_t t = 0; t < threads; ++t) th.emplace_back(shard_run, t, from, to);
       for (auto& x : th) x.join();
     }
-    std::memcpy(total.data(), outs[0].data(), total.size());
+  };
+  run_range(0, warmup_blocks);
+  auto t0 = std::chrono::steady_clock::now();
+  run_range(warmup_blocks, total_blocks);
+  std::vector<unsigned char> total(out_len * esz);
+  for (uint32_t i = 0; i < blocks; ++i) {
+    std::memcpy(total.data(), outs[0].data() + static_cast<size_t>(i) * out_len * esz, total.size());
     for (uint32_t t = 1; t < threads; ++t) {
+      const unsigned char* src = outs[t].data() + static_cast<size_t>(i) * out_len * esz;
       if (esz == 4) {
         float* a = reinterpret_cast<float*>(total.data());
-        const float* b = reinterpret_cast<const float*>(outs[t].data());
-        for (size_t i = 0; i < out_len; ++i) a[i] += b[i];
+        const float* b = reinterpret_cast<const float*>(src);
+        for (size_t k = 0; k < out_len; ++k) a[k] += b[k];
       } else {
         double* a = reinterpret_cast<double*>(total.data());
-        const double* b = reinterpret_cast<const double*>(outs[t].data());
-        for (size_t i = 0; i < out_len; ++i) a[i] += b[i];
+        const double* b = reinterpret_cast<const double*>(src);
+        for (size_t k = 0; k < out_len; ++k) a[k] += b[k];
       }
     }
-  };
-  if (restart_stage >= 0) fire(restart_stage, restart_param);
-  for (uint32_t i = 0; i < warmup_blocks; ++i) run_block();
-  auto t0 = std::chrono::steady_clock::now();
-  for (uint32_t i = 0; i < blocks; ++i) {
-    if (release_stage >= 0 && i == release_block) fire(release_stage, release_param);
-    run_block();
   }
   auto t1 = std::chrono::steady_clock::now();
   if (last_out) std::memcpy(last_out, total.data(), total.size());
