@@ -133,10 +133,11 @@ typedef struct knh_stage_desc {
 
 /* How the N per-voice signals are folded into the output block. */
 typedef enum knh_mix_mode {
-  /* Deterministic two-level fold: left fold over each wavefront's 64 voices in
-   * voice order, then a left fold over the wavefront partials in order.  Same
-   * result on every run; differs from the reference's single left fold only
-   * by f32 reassociation (bounded; see DESIGN.md "mixdown"). */
+  /* Deterministic three-level fold: left fold over each wavefront's 64 voices in
+   * voice order, left fold over each group of 16 consecutive wavefront partials,
+   * left fold over the group results.  Same result on every run; differs from the
+   * reference's single left fold only by f32 reassociation (bounded; see
+   * DESIGN.md "mixdown"). */
   KNH_MIX_TREE = 0,
   /* Bit-exact reference order ((v0+v1)+v2)+... in sample precision
    * (knaster_graph/src/graph.rs:827-872).  Serial in the voice axis: slower. */
@@ -248,6 +249,26 @@ int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process,
 int32_t knh_bank_process_block_voices(knh_bank* bank, size_t frames_to_process,
                                       size_t block_start_offset, uint64_t frame_clock, void* out,
                                       void* voices_out, uint32_t* out_flags);
+/* Several consecutive whole blocks in ONE launch (non-realtime rendering): the voices' state stays in
+ * registers across the blocks, so launch overhead and the sine-table staging are paid once.  Results
+ * are identical, bit for bit, to n_blocks calls of knh_bank_process_block.  This is
+ * AudioProcessor::run_without_inputs() called n_blocks times (knaster_graph/src/processor.rs:142-179)
+ * with every SchedulingEvent of those blocks known up front; changes for block k > 0 of the launch are
+ * queued with knh_bank_param_apply_many_at.
+ *   out / out_device: [n_blocks][out_channels][block_size] of F. */
+int32_t knh_bank_process_blocks(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out,
+                                uint32_t* out_flags);
+int32_t knh_bank_process_blocks_device(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock,
+                                       void* out_device, void* hip_stream);
+/* knh_bank_param_apply_many addressed to block `block_offset` (0 = the next block) of the next
+ * launch: what GraphGen does with a SchedulingEvent whose Time is not yet due -- it keeps it and
+ * applies it in the block where to_samples_until_due() < block_size
+ * (knaster_graph/src/graph_gen.rs:110-166, scheduling.rs:95-121). */
+int32_t knh_bank_param_apply_many_at(knh_bank* bank, uint32_t block_offset, size_t count,
+                                     const uint32_t* voices, const uint32_t* stages,
+                                     const uint32_t* params, const uint32_t* kinds,
+                                     const double* fvalues, const int64_t* ivalues,
+                                     const uint16_t* delays);
 /* Per-voice done frame of the last processed block (UGenFlags::done,
  * ugen.rs:169-175): done_frames[v] = frame in block, or UINT32_MAX. */
 int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames);

@@ -135,7 +135,7 @@ class VoiceBank:
     def set_delay_within_block_for_param(self, voice: int, stage: int, param: int, delay: int):
         self._check(self._lib.knh_bank_set_delay_within_block_for_param(self._h, voice, stage, param, delay))
 
-    def param_apply_many(self, voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None):
+    def param_apply_many(self, voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None, block_offset=0):
         v = np.ascontiguousarray(voices, dtype=np.uint32)
         n = v.shape[0]
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(stages, dtype=np.uint32), (n,)))
@@ -145,7 +145,11 @@ class VoiceBank:
         i = None if ivalues is None else np.ascontiguousarray(np.broadcast_to(np.asarray(ivalues, dtype=np.int64), (n,)))
         d = None if delays is None else np.ascontiguousarray(np.broadcast_to(np.asarray(delays, dtype=np.uint16), (n,)))
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-        self._check(self._lib.knh_bank_param_apply_many(self._h, n, ptr(v), ptr(s), ptr(p), ptr(k), ptr(f), ptr(i), ptr(d)))
+        if block_offset:
+            self._check(self._lib.knh_bank_param_apply_many_at(self._h, block_offset, n, ptr(v), ptr(s), ptr(p), ptr(k), ptr(f),
+                                                               ptr(i), ptr(d)))
+        else:
+            self._check(self._lib.knh_bank_param_apply_many(self._h, n, ptr(v), ptr(s), ptr(p), ptr(k), ptr(f), ptr(i), ptr(d)))
 
     def process_block(self, frames_to_process: Optional[int] = None, block_start_offset: int = 0, frame_clock: int = 0,
                       out: Optional[np.ndarray] = None):
@@ -172,6 +176,17 @@ class VoiceBank:
         ftp = self.block_size if frames_to_process is None else frames_to_process
         self._check(self._lib.knh_bank_process_block_device(self._h, ftp, block_start_offset, frame_clock,
                                                             C.c_void_p(out_device_ptr or None), C.c_void_p(hip_stream or None)))
+
+    def process_blocks(self, n_blocks: int, frame_clock: int = 0):
+        """n_blocks whole blocks in one launch -> (out [n_blocks, ch, B], flags)."""
+        out = np.zeros((n_blocks, self.out_channels, self.block_size), dtype=self.dtype)
+        flags = C.c_uint32(0)
+        self._check(self._lib.knh_bank_process_blocks(self._h, n_blocks, frame_clock, out.ctypes.data_as(C.c_void_p), C.byref(flags)))
+        return out, int(flags.value)
+
+    def process_blocks_device(self, n_blocks: int, out_device_ptr: int = 0, hip_stream: int = 0, frame_clock: int = 0):
+        self._check(self._lib.knh_bank_process_blocks_device(self._h, n_blocks, frame_clock, C.c_void_p(out_device_ptr or None),
+                                                             C.c_void_p(hip_stream or None)))
 
     def read_done_frames(self) -> np.ndarray:
         d = np.zeros(self.n_voices, dtype=np.uint32)

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libknaster_hip.so")
 SOURCES = ["kernels.hip", "bank.hip"]
-HEADERS = ["voice_chain.hpp", "kernel_registry.hpp", os.path.join("..", "..", "include", "knaster_hip.h")]
+HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "kernel_registry.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
+           os.path.join("..", "build.py")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -158,8 +159,10 @@ struct knh_bank {
   virtual int init(uint32_t sr, size_t bs) = 0;
   virtual int param_apply(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i) = 0;
   virtual int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) = 0;
-  virtual int process(size_t ftp, size_t offset, uint64_t clock, void* out_host, void* out_device, void* voices_host,
-                      uint32_t* out_flags, void* stream, bool sync) = 0;
+  virtual int call_at(uint32_t block_offset, bool is_delay, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f,
+                      int64_t i, uint16_t delay) = 0;
+  virtual int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t clock, void* out_host, void* out_device,
+                      void* voices_host, uint32_t* out_flags, void* stream, bool sync) = 0;
   virtual int read_done_frames(uint32_t* out) = 0;
   virtual int synchronize() = 0;
   virtual int timing_reset(int enable) = 0;
@@ -187,6 +190,7 @@ template <typename F>
 struct Bank final : knh_bank {
   typedef typename knh_dev::WordOf<F>::type W;
   const knh::KernelEntry* entry = nullptr;
+  const knh::PipeEntry* pipe = nullptr;  // wave-specialised variant, used when built for this chain
   uint32_t nv = 0;
   long stride = 0;
 
@@ -202,8 +206,14 @@ struct Bank final : knh_bank {
   // WrPreciseTiming state: next_delay per (param, voice) for wrapped stages; queues keyed by voice*n_stages+stage
   std::vector<uint16_t> next_delay;  // [n_params_total][nv], allocated only if some stage is wrapped
   std::unordered_map<uint64_t, std::vector<QueuedChange>> queues;
-  std::vector<HostEvent> immediate;  // patches for the start of the next processed block, arrival order
-  std::vector<HostEvent> resolved;   // scratch
+  // Device state patches of the next launch, in application order: block 0's immediate changes as they
+  // arrive, then (at process time) block 0's queued changes, block 1's immediate ones, ...
+  std::vector<HostEvent> pending;
+  bool pending_needs_sort = false;   // some voice may have events out of frame order
+  uint32_t frame_base = 0;           // absolute frame of frame 0 of the block being assembled
+  // param_apply / set_delay calls addressed to later blocks of the next multi-block launch
+  struct Call { uint8_t is_delay; uint16_t delay; uint32_t voice, stage, param, kind; double f; int64_t i; };
+  std::vector<std::vector<Call>> future;  // [block_offset]
 
   // device
   hipStream_t own_stream = nullptr;
@@ -408,7 +418,21 @@ struct Bank final : knh_bank {
         return KNH_OK;
       }
     }
-    apply_now(voice, stage, param, f, i, 0, immediate);
+    apply_now(voice, stage, param, f, i, frame_base, pending);
+    return KNH_OK;
+  }
+  // The same two calls addressed to block `block_offset` of the next multi-block launch: validated now,
+  // replayed in order when that block is assembled.
+  int call_at(uint32_t block_offset, bool is_delay, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f,
+              int64_t i, uint16_t delay) override {
+    if (block_offset == 0) return is_delay ? set_delay(voice, stage, param, delay) : param_apply(voice, stage, param, kind, f, i);
+    int rc = check_target(voice, stage, param);
+    if (rc != KNH_OK) return rc;
+    if (block_offset >= 65536) return fail(KNH_ERR_OUT_OF_RANGE, "block_offset too large");
+    if (!is_delay && static_cast<int>(kind) != expected_value_kind(stages[stage].kind, param))
+      return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
+    if (future.size() <= block_offset) future.resize(block_offset + 1);
+    future[block_offset].push_back(Call{static_cast<uint8_t>(is_delay), delay, voice, stage, param, kind, f, i});
     return KNH_OK;
   }
 
@@ -476,7 +500,7 @@ struct Bank final : knh_bank {
 
   // WrPreciseTiming::process_block's change loop (precise_timing.rs:65-114) for every wrapped node
   // with queued changes: FIFO with head-of-line blocking, changes past the processed range are lost.
-  void resolve_queues(uint32_t frame_begin, uint32_t frame_end) {
+  void resolve_queues(uint32_t frame_begin, uint32_t frame_end) {  // block-relative range; events get frame_base added
     for (auto& kv : queues) {
       std::vector<QueuedChange>& q = kv.second;
       if (q.empty()) continue;
@@ -487,13 +511,14 @@ struct Bank final : knh_bank {
         uint32_t due = std::max<uint32_t>(c.delay, at);
         if (due > frame_end) break;
         at = due;
-        const size_t first = resolved.size();
-        apply_now(voice, stage, c.param, c.f, c.i, due, resolved);
+        const size_t first = pending.size();
+        apply_now(voice, stage, c.param, c.f, c.i, frame_base + due, pending);
         // a queued change splits the node's block at `due` (precise_timing.rs:104-110)
         if (due > frame_begin) {
-          if (resolved.size() == first)  // the setter emitted no patch (value unchanged): still a split
-            resolved.push_back(HostEvent{voice, due, knh_dev::EV_NOP, static_cast<uint32_t>(stages[stage].slot_base), 0});
-          for (size_t k = first; k < resolved.size(); ++k) resolved[k].op |= knh_dev::EV_SPLIT;
+          if (pending.size() == first)  // the setter emitted no patch (value unchanged): still a split
+            pending.push_back(HostEvent{voice, frame_base + due, knh_dev::EV_NOP, static_cast<uint32_t>(stages[stage].slot_base), 0});
+          for (size_t k = first; k < pending.size(); ++k) pending[k].op |= knh_dev::EV_SPLIT;
+          pending_needs_sort = true;
         }
       }
       q.clear();
@@ -504,7 +529,7 @@ struct Bank final : knh_bank {
   // ---- processing ---------------------------------------------------------------------------
   int upload_events(hipStream_t s, bool* have_events) {
     *have_events = false;
-    const size_t total = immediate.size() + resolved.size();
+    const size_t total = pending.size();
     if (total == 0) return KNH_OK;
     if (staging_in_flight) {  // the previous upload must have left the pinned staging buffers
       KNH_HIP(hipEventSynchronize(staging_free));
@@ -524,51 +549,97 @@ struct Bank final : knh_bank {
       KNH_HIP(hipMalloc(&d_events, h_events_cap * sizeof(Event)));
       d_events_cap = h_events_cap;
     }
-    // counting sort by voice (stable), then order each voice's few events by frame (stable)
+    // counting sort by voice (stable: keeps application order), then each voice's few events by frame (stable)
     std::fill(h_ev_start, h_ev_start + nv + 1, 0u);
-    for (const HostEvent& e : immediate) h_ev_start[e.voice + 1]++;
-    for (const HostEvent& e : resolved) h_ev_start[e.voice + 1]++;
+    for (const HostEvent& e : pending) h_ev_start[e.voice + 1]++;
     for (uint32_t v = 0; v < nv; ++v) h_ev_start[v + 1] += h_ev_start[v];
-    std::vector<uint32_t> cursor(h_ev_start, h_ev_start + nv);
-    auto put = [&](const HostEvent& e) {
+    cursor.assign(h_ev_start, h_ev_start + nv);
+    for (const HostEvent& e : pending) {
       Event& d = h_events[cursor[e.voice]++];
-      d.frame_op = (e.frame & 0xFFFFu) | (e.op << 16);
-      d.slot = e.slot;
+      d.frame = e.frame;
+      d.slot_op = (e.slot & 0xFFFFFFu) | (e.op << 24);
       d.bits = e.bits;
-    };
-    for (const HostEvent& e : immediate) put(e);
-    for (const HostEvent& e : resolved) put(e);
-    if (!resolved.empty()) {
+    }
+    if (pending_needs_sort) {
       for (uint32_t v = 0; v < nv; ++v) {
         Event* b = h_events + h_ev_start[v];
         Event* e = h_events + h_ev_start[v + 1];
-        if (e - b > 1)
-          std::stable_sort(b, e, [](const Event& x, const Event& y) { return (x.frame_op & 0xFFFFu) < (y.frame_op & 0xFFFFu); });
+        if (e - b > 1) std::stable_sort(b, e, [](const Event& x, const Event& y) { return x.frame < y.frame; });
       }
     }
     KNH_HIP(hipMemcpyAsync(d_ev_start, h_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     KNH_HIP(hipMemcpyAsync(d_events, h_events, total * sizeof(Event), hipMemcpyHostToDevice, s));
     KNH_HIP(hipEventRecord(staging_free, s));
     staging_in_flight = true;
-    immediate.clear();
-    resolved.clear();
+    pending.clear();
+    pending_needs_sort = false;
     *have_events = true;
     return KNH_OK;
   }
+  std::vector<uint32_t> cursor;
 
-  int process(size_t ftp, size_t offset, uint64_t /*clock*/, void* out_host, void* out_device, void* voices_host,
+  int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t /*clock*/, void* out_host, void* out_device, void* voices_host,
               uint32_t* out_flags, void* stream, bool sync) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
     if (offset + ftp > block_size) return fail(KNH_ERR_INVALID_ARGUMENT, "block_start_offset + frames_to_process exceeds block_size");
+    if (n_blocks == 0 || n_blocks > 4096) return fail(KNH_ERR_INVALID_ARGUMENT, "n_blocks must be in 1..4096");
+    if (n_blocks > 1 && (offset != 0 || ftp != block_size)) return fail(KNH_ERR_INVALID_ARGUMENT, "multi-block launches process whole blocks");
+    if (n_blocks > 1 && voices_host) return fail(KNH_ERR_INVALID_ARGUMENT, "per-voice output is only available for single blocks");
     KNH_HIP(hipSetDevice(device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : own_stream;
     const uint32_t fb = static_cast<uint32_t>(offset), fe = static_cast<uint32_t>(offset + ftp);
-    resolve_queues(fb, fe);
+    // Assemble the launch's state patches block by block, in the order the reference would apply them.
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      frame_base = b * static_cast<uint32_t>(block_size);
+      if (b > 0 && b < future.size()) {
+        for (const Call& c : future[b]) {
+          if (c.is_delay) set_delay(c.voice, c.stage, c.param, c.delay);
+          else param_apply(c.voice, c.stage, c.param, c.kind, c.f, c.i);
+        }
+        if (!future[b].empty()) pending_needs_sort = pending_needs_sort || n_blocks > 1;
+      }
+      resolve_queues(fb, fe);
+    }
+    frame_base = 0;
     bool have_events = false;
     int rc = upload_events(s, &have_events);
     if (rc != KNH_OK) return rc;
-    const bool want_voices = voices_host != nullptr || desc.mix_mode == KNH_MIX_LEFT_FOLD;
+    if (!future.empty()) {  // calls addressed beyond this launch move up; those now due for the next
+                            // block are applied right away, ahead of anything that arrives later
+      if (future.size() <= n_blocks) future.clear();
+      else future.erase(future.begin(), future.begin() + n_blocks);
+      if (!future.empty()) {
+        std::vector<Call> due;
+        due.swap(future[0]);
+        for (const Call& c : due) {
+          if (c.is_delay) set_delay(c.voice, c.stage, c.param, c.delay);
+          else param_apply(c.voice, c.stage, c.param, c.kind, c.f, c.i);
+        }
+      }
+    }
+    const bool want_voices = voices_host != nullptr || (desc.mix_mode == KNH_MIX_LEFT_FOLD);
+    if (desc.mix_mode == KNH_MIX_LEFT_FOLD && n_blocks > 1)
+      return fail(KNH_ERR_INVALID_ARGUMENT, "KNH_MIX_LEFT_FOLD processes one block per call");
     if (want_voices) KNH_HIP(ensure_voices());
+    const unsigned n_waves = (nv + 63) / 64;
+    if (n_blocks > partials_blocks) {
+      KNH_HIP(hipStreamSynchronize(s));
+      KNH_HIP(hipFree(d_partials));
+      d_partials = nullptr;
+      KNH_HIP(hipMalloc(&d_partials, static_cast<size_t>(n_blocks) * n_waves * block_size * sizeof(F)));
+      partials_blocks = n_blocks;
+    }
+    if (!out_device && n_blocks > out_blocks) {
+      KNH_HIP(hipStreamSynchronize(s));
+      KNH_HIP(hipFree(d_out));
+      d_out = nullptr;
+      KNH_HIP(hipMalloc(&d_out, static_cast<size_t>(n_blocks) * desc.out_channels * block_size * sizeof(F)));
+      KNH_HIP(hipMemsetAsync(d_out, 0, static_cast<size_t>(n_blocks) * desc.out_channels * block_size * sizeof(F), s));
+      if (h_out) KNH_HIP(hipHostFree(h_out));
+      h_out = nullptr;
+      KNH_HIP(hipHostMalloc(&h_out, static_cast<size_t>(n_blocks) * desc.out_channels * block_size * sizeof(F) + 2 * sizeof(uint32_t)));
+      out_blocks = n_blocks;
+    }
 
     KNH_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), s));
     VoiceKernelArgs<F> a;
@@ -576,6 +647,7 @@ struct Bank final : knh_bank {
     a.stride = stride;
     a.n_voices = nv;
     a.block_size = static_cast<uint32_t>(block_size);
+    a.n_blocks = n_blocks;
     a.frame_begin = fb;
     a.frame_end = fe;
     a.sine_table = d_sine;
@@ -586,7 +658,6 @@ struct Bank final : knh_bank {
     a.voices_out = want_voices ? d_voices : nullptr;
     a.done_frames = d_done;
     a.flags = d_flags;
-    const unsigned n_waves = (nv + 63) / 64;
     std::pair<hipEvent_t, hipEvent_t>* tp = nullptr;
     if (timing) {
       if (timing_used == timing_pool.size()) {
@@ -608,13 +679,14 @@ struct Bank final : knh_bank {
 
     F* dst = out_device ? static_cast<F*>(out_device) : d_out;
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
-      KNH_HIP(launch_fold(d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), s));
+      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), 1, s));
     else
-      KNH_HIP(launch_fold(d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), s));
+      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), n_blocks, s));
 
     if (!sync) return KNH_OK;
-    const size_t out_bytes = desc.out_channels * block_size * sizeof(F);
-    uint32_t* h_flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h_out) + out_bytes);
+    const size_t blk_elems = desc.out_channels * block_size;
+    const size_t out_bytes = static_cast<size_t>(n_blocks) * blk_elems * sizeof(F);
+    uint32_t* h_flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h_out) + static_cast<size_t>(out_blocks) * blk_elems * sizeof(F));
     if (out_host) KNH_HIP(hipMemcpyAsync(h_out, dst, out_bytes, hipMemcpyDeviceToHost, s));
     KNH_HIP(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (voices_host)
@@ -622,28 +694,37 @@ struct Bank final : knh_bank {
     KNH_HIP(hipStreamSynchronize(s));
     staging_in_flight = false;
     if (out_host) {
-      for (uint32_t c = 0; c < desc.out_channels; ++c)
-        std::memcpy(static_cast<F*>(out_host) + c * block_size + offset, h_out + c * block_size + offset, ftp * sizeof(F));
+      if (n_blocks > 1) {
+        std::memcpy(out_host, h_out, out_bytes);
+      } else {
+        for (uint32_t c = 0; c < desc.out_channels; ++c)
+          std::memcpy(static_cast<F*>(out_host) + c * block_size + offset, h_out + c * block_size + offset, ftp * sizeof(F));
+      }
     }
     if (out_flags) {
       uint32_t fl = 0;
       if (h_flags[0]) fl |= KNH_FLAG_ANY_DONE;
-      if (h_flags[1] == 0) fl |= KNH_FLAG_ALL_DONE;
+      bool has_env = false;
+      for (const StageInfo& st : stages) has_env = has_env || st.kind == KNH_STAGE_MUL_ENV_ASR || st.kind == KNH_STAGE_MUL_ENV_AR;
+      if (has_env && h_flags[1] == 0) fl |= KNH_FLAG_ALL_DONE;  // a chain without an envelope never finishes
       *out_flags = fl;
     }
     return KNH_OK;
   }
+  uint32_t partials_blocks = 1, out_blocks = 1;
   hipError_t launch_voice(const VoiceKernelArgs<float>& a, unsigned n_waves, hipStream_t s) {
+    if (pipe) return pipe->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
   hipError_t launch_voice(const VoiceKernelArgs<double>& a, unsigned n_waves, hipStream_t s) {
+    if (pipe) return pipe->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
-  static hipError_t launch_fold(const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, hipStream_t s) {
-    return knh::launch_fold_rows_f32(rows, n, len, fb, fe, out, ch, os, s);
+  static hipError_t launch_fold(bool tree, const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, unsigned nb, hipStream_t s) {
+    return knh::launch_fold_f32(tree, rows, n, len, fb, fe, out, ch, os, nb, s);
   }
-  static hipError_t launch_fold(const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, hipStream_t s) {
-    return knh::launch_fold_rows_f64(rows, n, len, fb, fe, out, ch, os, s);
+  static hipError_t launch_fold(bool tree, const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, unsigned nb, hipStream_t s) {
+    return knh::launch_fold_f64(tree, rows, n, len, fb, fe, out, ch, os, nb, s);
   }
 
   int read_done_frames(uint32_t* out) override {
@@ -717,6 +798,10 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry) {
   auto* b = new Bank<F>();
   b->desc = d;
   b->entry = entry;
+  {  // KNH_PIPELINE=0 forces the single-wave kernel (A/B measurements)
+    const char* env = std::getenv("KNH_PIPELINE");
+    if (!(env && env[0] == '0')) b->pipe = knh::find_pipe(entry->signature);
+  }
   b->nv = d.n_voices;
   int slot = 0, pbase = 0;
   for (uint32_t i = 0; i < d.n_stages; ++i) {
@@ -843,16 +928,42 @@ int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* 
 int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, uint32_t* out_flags) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output block");
-  return bank->process(frames_to_process, block_start_offset, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+  return bank->process(1, frames_to_process, block_start_offset, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
 }
 int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out_device, void* hip_stream) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->process(frames_to_process, block_start_offset, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+  return bank->process(1, frames_to_process, block_start_offset, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
 }
 int32_t knh_bank_process_block_voices(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, void* voices_out, uint32_t* out_flags) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   if (!voices_out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null voices_out");
-  return bank->process(frames_to_process, block_start_offset, frame_clock, out, nullptr, voices_out, out_flags, nullptr, true);
+  return bank->process(1, frames_to_process, block_start_offset, frame_clock, out, nullptr, voices_out, out_flags, nullptr, true);
+}
+int32_t knh_bank_process_blocks(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out, uint32_t* out_flags) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output");
+  return bank->process(n_blocks, bank->block_size, 0, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+}
+int32_t knh_bank_process_blocks_device(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out_device, void* hip_stream) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+}
+int32_t knh_bank_param_apply_many_at(knh_bank* bank, uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stages,
+                                     const uint32_t* params, const uint32_t* kinds, const double* fvalues, const int64_t* ivalues,
+                                     const uint16_t* delays) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
+  int rc = KNH_OK;
+  for (size_t k = 0; k < count; ++k) {
+    if (delays && delays[k] > 0) {
+      int r = bank->call_at(block_offset, true, voices[k], stages[k], params[k], 0, 0.0, 0, delays[k]);
+      if (r != KNH_OK) { rc = r; continue; }
+    }
+    int r = bank->call_at(block_offset, false, voices[k], stages[k], params[k], kinds[k], fvalues ? fvalues[k] : 0.0,
+                          ivalues ? ivalues[k] : 0, 0);
+    if (r != KNH_OK) rc = r;
+  }
+  return rc;
 }
 int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;

@@ -20,14 +20,24 @@ struct KernelEntry {
   VoiceLaunchFn<float> f32[2];   // [allow_fma]
   VoiceLaunchFn<double> f64[2];  // [allow_fma]
 };
+// Wave-specialised (pipelined) variant of a chain, when one is built (voice_pipe.hpp).
+struct PipeEntry {
+  const char* signature;
+  int n_groups;
+  VoiceLaunchFn<float> f32[2];
+  VoiceLaunchFn<double> f64[2];
+};
+const PipeEntry* find_pipe(const char* signature);
 
 const KernelEntry* find_kernel(const char* signature);
 int kernel_count();
 const KernelEntry* kernel_at(int i);
 
-hipError_t launch_fold_rows_f32(const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
-                                unsigned frame_end, float* out, unsigned channels, unsigned out_stride, hipStream_t s);
-hipError_t launch_fold_rows_f64(const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
-                                unsigned frame_end, double* out, unsigned channels, unsigned out_stride, hipStream_t s);
+// n_blocks consecutive [n_rows][row_len] row sets -> n_blocks consecutive [channels][out_stride] blocks.
+// tree = false: exact left fold of the rows in order; tree = true: 16-ary two-level fold (deterministic)
+hipError_t launch_fold_f32(bool tree, const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                           unsigned frame_end, float* out, unsigned channels, unsigned out_stride, unsigned n_blocks, hipStream_t s);
+hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                           unsigned frame_end, double* out, unsigned channels, unsigned out_stride, unsigned n_blocks, hipStream_t s);
 
 }  // namespace knh

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "kernel_registry.hpp"
+#include "voice_pipe.hpp"
 
 namespace knh {
 using namespace knh_dev;
@@ -41,6 +42,42 @@ static const KernelEntry kEntries[] = {
     KNH_CHAIN("Wasd", SinWt, AddVal, SubVal, DivVal),
 };
 
+template <typename F, bool FMA, typename... Gs>
+static hipError_t launch_pipe(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
+  if (n_wavefronts == 0) return hipSuccess;
+  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, Gs...>), dim3(n_wavefronts), dim3((sizeof...(Gs) + 1) * 64), 0, stream, args);
+  return hipGetLastError();
+}
+#define KNH_PIPE(sig, n, ...)                                                             \
+  {sig, n, {launch_pipe<float, false, __VA_ARGS__>, launch_pipe<float, true, __VA_ARGS__>}, \
+   {launch_pipe<double, false, __VA_ARGS__>, launch_pipe<double, true, __VA_ARGS__>}}
+
+typedef Group<SinWt, MulVal> G_Wm;
+typedef Group<SinWt> G_W;
+typedef Group<SinNum> G_N;
+typedef Group<Svf> G_S;
+typedef Group<MulAsr> G_A;
+typedef Group<MulAr> G_E;
+typedef Group<MulAsr, MulVal> G_Am;
+typedef Group<MulVal> G_m;
+typedef Group<SinWt, MulVal, AddVal> G_Wma;
+typedef Group<SinWtAr, MulVal> G_Rm;
+
+static const PipeEntry kPipes[] = {
+    KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope (+ mixer wave)
+    KNH_PIPE("WSAm", 3, G_W, G_S, G_Am),
+    KNH_PIPE("WSA", 3, G_W, G_S, G_A),
+    KNH_PIPE("WS", 2, G_W, G_S),
+    KNH_PIPE("WmaRm", 2, G_Wma, G_Rm),     // C5: modulator | carrier
+    KNH_PIPE("Nm", 2, G_N, G_m),           // C2
+    KNH_PIPE("NSAm", 3, G_N, G_S, G_Am),
+};
+const PipeEntry* find_pipe(const char* signature) {
+  for (const PipeEntry& e : kPipes)
+    if (std::strcmp(e.signature, signature) == 0) return &e;
+  return nullptr;
+}
+
 const KernelEntry* find_kernel(const char* signature) {
   for (const KernelEntry& e : kEntries)
     if (std::strcmp(e.signature, signature) == 0) return &e;
@@ -50,21 +87,27 @@ int kernel_count() { return (int)(sizeof(kEntries) / sizeof(kEntries[0])); }
 const KernelEntry* kernel_at(int i) { return (i >= 0 && i < kernel_count()) ? &kEntries[i] : nullptr; }
 
 template <typename F>
-static hipError_t launch_fold(const F* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin, unsigned frame_end,
-                              F* out, unsigned channels, unsigned out_stride, hipStream_t s) {
-  if (frame_end <= frame_begin || n_rows == 0) return hipSuccess;
-  unsigned grid = (frame_end - frame_begin + 63u) / 64u;
-  hipLaunchKernelGGL((fold_rows_kernel<F>), dim3(grid), dim3(64), 0, s, rows, n_rows, row_len, frame_begin, frame_end, out,
-                     channels, out_stride);
+static hipError_t launch_fold(bool tree, const F* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin, unsigned frame_end,
+                              F* out, unsigned channels, unsigned out_stride, unsigned n_blocks, hipStream_t s) {
+  if (frame_end <= frame_begin || n_rows == 0 || n_blocks == 0) return hipSuccess;
+  if (tree) {
+    unsigned grid = (frame_end - frame_begin + 15u) / 16u;
+    hipLaunchKernelGGL((fold_tree_kernel<F>), dim3(grid, n_blocks), dim3(256), 0, s, rows, n_rows, row_len, frame_begin, frame_end,
+                       out, channels, out_stride);
+  } else {
+    unsigned grid = (frame_end - frame_begin + 63u) / 64u;
+    hipLaunchKernelGGL((fold_rows_kernel<F>), dim3(grid, n_blocks), dim3(64), 0, s, rows, n_rows, row_len, frame_begin, frame_end,
+                       out, channels, out_stride);
+  }
   return hipGetLastError();
 }
-hipError_t launch_fold_rows_f32(const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
-                                unsigned frame_end, float* out, unsigned channels, unsigned out_stride, hipStream_t s) {
-  return launch_fold<float>(rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, s);
+hipError_t launch_fold_f32(bool tree, const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                           unsigned frame_end, float* out, unsigned channels, unsigned out_stride, unsigned n_blocks, hipStream_t s) {
+  return launch_fold<float>(tree, rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, n_blocks, s);
 }
-hipError_t launch_fold_rows_f64(const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
-                                unsigned frame_end, double* out, unsigned channels, unsigned out_stride, hipStream_t s) {
-  return launch_fold<double>(rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, s);
+hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
+                           unsigned frame_end, double* out, unsigned channels, unsigned out_stride, unsigned n_blocks, hipStream_t s) {
+  return launch_fold<double>(tree, rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, n_blocks, s);
 }
 
 }  // namespace knh

@@ -54,8 +54,9 @@ __device__ __forceinline__ u32 sat_u32(double v) {
 enum { EV_SET = 0, EV_ENV_ASR_RELEASE = 1, EV_NOP = 2, EV_SPLIT = 0x80 /* flag: change came out of a WrPreciseTiming queue */ };
 
 struct Event {   // 16 bytes
-  u32 frame_op;  // frame (low 16) | op (bits 16..23)
-  u32 slot;      // absolute slot index of the patched word (EV_SET) or the stage's first slot
+  u32 frame;     // absolute frame within the launch: block_index * block_size + frame_in_block
+  u32 slot_op;   // slot (low 24 bits: absolute slot index of the patched word, or the stage's first
+                 // slot for ops) | op << 24 (EV_* incl. the EV_SPLIT flag)
   u64 bits;      // new word (low 32 bits for an f32 bank)
 };
 
@@ -98,6 +99,11 @@ struct SinWtT {
     r.phase += r.inc;
     return (F)s;
   }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
     if ((op & 0x7Fu) != EV_SET) return;
@@ -131,6 +137,11 @@ struct SinNum {
     r.phase += r.inc;
     if (r.phase > (F)1) r.phase -= (F)1;
     return out;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
@@ -177,6 +188,11 @@ struct Svf {
       return r.m0 * v0 + r.m1 * v1 + r.m2 * v2;
     }
   }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
     if ((op & 0x7Fu) != EV_SET) return;
@@ -207,6 +223,11 @@ struct OnePoleT {
     if constexpr (FMA) r.y = mad<true>(x, r.a0, r.y * r.b1);
     else r.y = x * r.a0 + r.y * r.b1;
     return HIGHPASS ? x - r.y : r.y;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
@@ -264,6 +285,54 @@ struct MulEnvT {
     }
     return x * env;
   }
+  // T samples at once.  State transitions are rare (at most three per note), so the tile is first
+  // evaluated branch-free under the assumption that no lane changes state inside it; every sample's
+  // transition test is still evaluated, and if any lane would have changed state the tile is redone
+  // with the exact per-sample state machine from the saved registers.  Same values either way.
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    const u32 st = r.state;
+    const bool isA = st == 1u, isR = st == 3u;
+    const bool anyA = __builtin_amdgcn_ballot_w64(isA) != 0, anyR = __builtin_amdgcn_ballot_w64(isR) != 0;
+    const F konst = st == 2u ? (F)1 : (F)0;
+    if (!anyA && !anyR) {  // every lane Sustaining or Stopped
+#pragma unroll
+      for (int j = 0; j < T; ++j) x[j] = x[j] * konst;
+      return;
+    }
+    const F step = isA ? r.ar : (isR ? -r.rr : (F)0);  // t - rr == t + (-rr) exactly
+    F y[T];
+    F t = r.t;
+    bool hit_hi = false, hit_lo = false;
+    if (!anyR) {
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const F env = isA ? t : konst;
+        t = t + step;
+        hit_hi |= t >= (F)1;
+        y[j] = x[j] * env;
+      }
+    } else {
+      const F scale = r.scale;
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const F cube = (t * (t * t)) * scale;
+        const F env = isA ? t : (isR ? cube : konst);
+        t = t + step;
+        hit_hi |= t >= (F)1;
+        hit_lo |= t <= (F)0;
+        y[j] = x[j] * env;
+      }
+    }
+    const bool hit = (isA && hit_hi) || (isR && hit_lo);
+    if (__builtin_amdgcn_ballot_w64(hit) == 0) {
+      r.t = t;
+#pragma unroll
+      for (int j = 0; j < T; ++j) x[j] = y[j];
+      return;
+    }
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 frame) {
     if (op & EV_SPLIT) r.seg = frame;  // a queued WrPreciseTiming change starts a new partial block here
@@ -302,6 +371,11 @@ struct ValT {
     if (OP == 2) return x - r.v;
     return x / r.v;
   }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32, u64 bits, u32 /*frame*/) {
     if ((op & 0x7Fu) == EV_SET) r.v = word_to_f<F>((typename WordOf<F>::type)bits);
@@ -323,6 +397,7 @@ struct Chain<F, FMA, BASE> {
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
   template <typename W> __device__ __forceinline__ void store(W*, long) const {}
   __device__ __forceinline__ F tick(F x, const Ctx&, u32, u32&) { return x; }
+  template <int T> __device__ __forceinline__ void tick_tile(F (&)[T], const Ctx&, u32, u32&) {}
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
   __device__ __forceinline__ void begin_block(u32) {}
@@ -345,6 +420,10 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   __device__ __forceinline__ F tick(F x, const Ctx& c, u32 frame, u32& done_frame) {
     x = S0::template tick<F, FMA>(r, x, c, frame, done_frame);
     return rest.tick(x, c, frame, done_frame);
+  }
+  template <int T> __device__ __forceinline__ void tick_tile(F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    S0::template tick_tile<F, FMA, T>(r, x, c, frame0, done_frame);
+    rest.template tick_tile<T>(x, c, frame0, done_frame);
   }
   __device__ __forceinline__ void on_event(u32 op, u32 slot, u64 bits, u32 frame) {
     if (slot >= (u32)BASE && slot < (u32)(BASE + S0::kSlots)) S0::template on_event<F>(r, op, slot - BASE, bits, frame);
@@ -369,13 +448,14 @@ struct VoiceKernelArgs {
   long stride;                      // words per slot row (>= n_voices, multiple of 64)
   u32 n_voices;
   u32 block_size;                   // row length of partials / voices_out
-  u32 frame_begin, frame_end;       // frames [begin, end) of the block are processed
+  u32 n_blocks;                     // consecutive blocks processed by this launch (state stays in registers)
+  u32 frame_begin, frame_end;       // frames [begin, end) of each block are processed ([0, block_size) unless n_blocks == 1)
   const float* sine_table;          // 16384 floats in HBM (staged to LDS)
   double f2pi;
   const u32* ev_start;              // [n_voices + 1] or null when the block has no events
   const Event* events;
-  F* partials;                      // [n_waves][block_size]: per-wavefront left-fold of its 64 voices
-  F* voices_out;                    // [n_voices][block_size] or null
+  F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its 64 voices
+  F* voices_out;                    // [n_voices][block_size] or null (n_blocks == 1 only)
   u32* done_frames;                 // [n_voices]
   u32* flags;                       // [0] |= any-done, [1] += voices whose last envelope is not Stopped
 };
@@ -389,16 +469,24 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   typedef Chain<F, FMA, 0, S...> ChainT;
   typedef typename WordOf<F>::type W;
   constexpr int TN = sizeof(F) == 4 ? 64 : 32;  // frames per reduce tile
-  constexpr int TS = 65;                        // row stride: conflict-free both ways
+  constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
+                                                // writes (ds_write_b32) and row reads (ds_read_b128)
   __shared__ float sine[ChainT::kUsesSine ? 16384 : 1];
-  __shared__ F tile[WAVES][TN][TS];
+  __shared__ __attribute__((aligned(16))) F tile[WAVES][TN][TS];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   if (ChainT::kUsesSine) {
-    const float4* src = reinterpret_cast<const float4*>(a.sine_table);
-    float4* dst = reinterpret_cast<float4*>(sine);
-    for (int i = threadIdx.x; i < 4096; i += WAVES * 64) dst[i] = src[i];
+    // Stage the 64 KiB table with LDS-DMA: 1 KiB per wave-instruction (16 B per lane, linear in LDS),
+    // all issued back to back, one wait at the end.  The LDS base of each piece is wave-uniform.
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll 8
+    for (int k = wave; k < 64; k += WAVES) {
+      const float* g = a.sine_table + (k * 64 + lane) * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sine + k * 256), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   Ctx ctx;
@@ -414,66 +502,86 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
 
   ChainT chain;
   chain.load(a.state + voice, a.stride);
-  chain.begin_block(a.frame_begin);
 
   u32 ev_i = 0, ev_end = 0;
   if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
   u32 next_frame = 0xFFFFFFFFu;
-  if (ev_i < ev_end) next_frame = a.events[ev_i].frame_op & 0xFFFFu;
+  if (ev_i < ev_end) next_frame = a.events[ev_i].frame;
   u32 done_frame = 0xFFFFFFFFu;
+  u32 base = 0;  // absolute frame of the current block's frame 0
 
-  auto apply_events_upto = [&](u32 n) {
-    while (next_frame <= n) {
+  auto apply_events_upto = [&](u32 n_abs) {
+    while (next_frame <= n_abs) {
       Event e = a.events[ev_i];
-      chain.on_event((e.frame_op >> 16) & 0xFFu, e.slot, e.bits, e.frame_op & 0xFFFFu);
-      // a patched coefficient slot is not part of the end-of-block write-back: persist it now
-      // (mutable slots are overwritten by their evolved value at the end of the block)
-      if (live && ((e.frame_op >> 16) & 0x7Fu) == EV_SET) a.state[(long)e.slot * a.stride + voice] = (W)e.bits;
+      const u32 op = e.slot_op >> 24, slot = e.slot_op & 0xFFFFFFu;
+      chain.on_event(op, slot, e.bits, e.frame - base);
+      // a patched coefficient slot is not part of the end-of-launch write-back: persist it now
+      // (mutable slots are overwritten by their evolved value at the end)
+      if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)e.bits;
       ++ev_i;
-      next_frame = ev_i < ev_end ? (a.events[ev_i].frame_op & 0xFFFFu) : 0xFFFFFFFFu;
+      next_frame = ev_i < ev_end ? a.events[ev_i].frame : 0xFFFFFFFFu;
     }
   };
 
+  const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   F(*my)[TS] = tile[wave];
-  for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {
-    const u32 len = a.frame_end - n0 < (u32)TN ? a.frame_end - n0 : (u32)TN;
-    for (u32 j0 = 0; j0 < len; j0 += kTile) {
-      const u32 n = n0 + j0;
-      apply_events_upto(n);
-      const bool full = j0 + kTile <= len;
-      const bool ev_inside = next_frame < n + kTile;
-      if (full && !__builtin_amdgcn_ballot_w64(ev_inside)) {
-        // fast path: kTile samples, fully unrolled
-        F x[kTile];
+  for (u32 b = 0; b < a.n_blocks; ++b, base += a.block_size) {
+    chain.begin_block(a.frame_begin);
+    F* partial_row = a.partials + ((long)b * n_waves_total + wave_global) * a.block_size;
+    for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {
+      const u32 len = a.frame_end - n0 < (u32)TN ? a.frame_end - n0 : (u32)TN;
+      for (u32 j0 = 0; j0 < len; j0 += kTile) {
+        const u32 n = n0 + j0;
+        apply_events_upto(base + n);
+        const bool full = j0 + kTile <= len;
+        const bool ev_inside = next_frame < base + n + kTile;
+        if (full && !__builtin_amdgcn_ballot_w64(ev_inside)) {
+          // fast path: kTile samples, stage by stage, fully unrolled
+          F x[kTile];
 #pragma unroll
-        for (int j = 0; j < kTile; ++j) x[j] = chain.tick((F)0, ctx, n + j, done_frame);
+          for (int j = 0; j < kTile; ++j) x[j] = (F)0;
+          chain.template tick_tile<kTile>(x, ctx, n, done_frame);
 #pragma unroll
-        for (int j = 0; j < kTile; ++j) my[j0 + j][lane] = x[j];
-      } else {
-        const u32 m = len - j0 < (u32)kTile ? len - j0 : (u32)kTile;
-        for (u32 j = 0; j < m; ++j) {
-          apply_events_upto(n + j);
-          my[j0 + j][lane] = chain.tick((F)0, ctx, n + j, done_frame);
+          for (int j = 0; j < kTile; ++j) my[j0 + j][lane] = x[j];
+        } else {
+          const u32 m = len - j0 < (u32)kTile ? len - j0 : (u32)kTile;
+          for (u32 j = 0; j < m; ++j) {
+            apply_events_upto(base + n + j);
+            my[j0 + j][lane] = chain.tick((F)0, ctx, n + j, done_frame);
+          }
         }
       }
+      // Transposed reduce: lane j folds frame j over the wave's voices in voice order.
+      // (same-wave LDS traffic: program order is enough, no barrier needed)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if ((u32)lane < len) {
+        F acc;
+        if (nv == 64u) {  // full wavefront: 16 LDS reads in flight ahead of the serial adds
+#pragma unroll
+          for (int vb = 0; vb < 64; vb += 16) {
+            F t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = my[lane][vb + k];
+            if (vb == 0) acc = t[0];
+#pragma unroll
+            for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
+          }
+        } else {
+          acc = my[lane][0];
+          for (u32 v = 1; v < nv; ++v) acc = acc + my[lane][v];
+        }
+        partial_row[n0 + lane] = acc;
+      }
+      if (a.voices_out) {
+        for (u32 v = 0; v < nv; ++v)
+          if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[lane][v];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    // Transposed reduce: lane j folds frame j over the wave's voices in voice order.
-    // (same-wave LDS traffic: program order is enough, no barrier needed)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if ((u32)lane < len) {
-      F acc = my[lane][0];
-      for (u32 v = 1; v < nv; ++v) acc = acc + my[lane][v];
-      a.partials[(long)wave_global * a.block_size + n0 + lane] = acc;
-    }
-    if (a.voices_out) {
-      for (u32 v = 0; v < nv; ++v)
-        if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[lane][v];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // changes due exactly at the end of the processed range (precise_timing.rs:85-103 runs the
+    // change loop once more before breaking out)
+    apply_events_upto(base + a.frame_end);
   }
-  // changes due exactly at the end of the processed range (precise_timing.rs:85-103 runs the
-  // change loop once more before breaking out)
-  apply_events_upto(a.frame_end);
 
   if (live) {
     chain.store(a.state + voice, a.stride);
@@ -489,16 +597,75 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   }
 }
 
-// Folds the per-wavefront partials in wavefront order and writes every output channel.
-// out: [channels][block_size]; frames [frame_begin, frame_end) are written.
+// Exact left fold of `n_rows` rows, row order = voice order: out[n] = ((r0+r1)+r2)+... in sample
+// precision (knaster_graph/src/graph.rs:827-872).  Serial in the row axis by definition; loads run
+// 16 rows ahead of the adds.  out: [channels][out_stride]; frames [frame_begin, frame_end) are written.
 template <typename F>
 __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
                                                         u32 frame_end, F* out, u32 channels, u32 out_stride) {
   const u32 n = frame_begin + blockIdx.x * 64u + threadIdx.x;
   if (n >= frame_end) return;
-  F acc = rows[n];
-  for (u32 r = 1; r < n_rows; ++r) acc = acc + rows[(long)r * row_len + n];
+  rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
+  out += (long)blockIdx.y * channels * out_stride;
+  const F* p = rows + n;
+  F acc = p[0];
+  u32 r = 1;
+  for (; r + 16 <= n_rows; r += 16) {
+    F v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = p[(long)(r + k) * row_len];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = acc + v[k];
+  }
+  for (; r < n_rows; ++r) acc = acc + p[(long)r * row_len];
   for (u32 c = 0; c < channels; ++c) out[(long)c * out_stride + n] = acc;
+}
+
+// Deterministic tree fold of the per-wavefront partial rows (KNH_MIX_TREE):
+//   level 2: left fold of each group of 16 consecutive rows; level 3: left fold of the group results.
+// One 256-thread workgroup handles 16 frames: thread (g, f) folds group g (+16, +32, ...) for frame f.
+template <typename F>
+__global__ void __launch_bounds__(256) fold_tree_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
+                                                         u32 frame_end, F* out, u32 channels, u32 out_stride) {
+  __shared__ F part[16][17];
+  rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
+  out += (long)blockIdx.y * channels * out_stride;
+  const u32 f = threadIdx.x & 15u, g = threadIdx.x >> 4;
+  const u32 n = frame_begin + blockIdx.x * 16u + f;
+  const bool in_range = n < frame_end;
+  const u32 n_groups = (n_rows + 15u) / 16u;
+  F total = (F)0;
+  for (u32 g0 = 0; g0 < n_groups; g0 += 16) {  // 256 groups of rows at a time
+    const u32 grp = g0 + g;
+    F acc = (F)0;
+    if (in_range && grp < n_groups) {
+      const u32 r0 = grp * 16u;
+      const u32 cnt = n_rows - r0 < 16u ? n_rows - r0 : 16u;
+      const F* p = rows + (long)r0 * row_len + n;
+      if (cnt == 16u) {
+        F v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = p[(long)k * row_len];
+        acc = v[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) acc = acc + v[k];
+      } else {
+        acc = p[0];
+        for (u32 k = 1; k < cnt; ++k) acc = acc + p[(long)k * row_len];
+      }
+    }
+    part[g][f] = acc;
+    __syncthreads();
+    if (g == 0 && in_range) {
+      const u32 m = n_groups - g0 < 16u ? n_groups - g0 : 16u;
+      u32 k = 0;
+      if (g0 == 0) { total = part[0][f]; k = 1; }
+      for (; k < m; ++k) total = total + part[k][f];
+    }
+    __syncthreads();
+  }
+  if (g == 0 && in_range)
+    for (u32 c = 0; c < channels; ++c) out[(long)c * out_stride + n] = total;
 }
 
 }  // namespace knh_dev

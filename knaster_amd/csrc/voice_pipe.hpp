@@ -1,0 +1,250 @@
+// voice_pipe.hpp -- wave-specialised (software-pipelined) form of the fused voice-bank kernel.
+//
+// Why: at the headline size (16 384 voices = 256 wavefronts) every wavefront is alone on its
+// SIMD, where one wave issues at most one VALU instruction per 4 cycles.  A block's run time is
+// then (instructions per sample in that one wave) x 4 cycles x block_size -- the serial SVF /
+// envelope recurrences forbid splitting a voice over time.  So the chain is cut into stage groups
+// and each group runs in its own wavefront of the same workgroup (one per SIMD of the CU), handing
+// 16-sample tiles to the next group through double-buffered LDS; a final "mixer" wavefront does the
+// transposed per-frame fold.  The critical path per sample drops from the whole chain to the
+// heaviest group.  Every voice still executes exactly the same arithmetic in the same order, so
+// results are bit-identical to the single-wave kernel.
+#pragma once
+#include "voice_chain.hpp"
+
+namespace knh_dev {
+
+template <typename... S> struct Group {};
+
+template <typename G> struct GroupInfo;
+template <typename... S> struct GroupInfo<Group<S...>> {
+  static constexpr int slots = (0 + ... + S::kSlots);
+  static constexpr bool uses_sine = (false || ... || S::kUsesSine);
+  static constexpr bool has_env = (false || ... || S::kIsEnv);
+};
+template <typename F, bool FMA, int BASE, typename G> struct GroupChain;
+template <typename F, bool FMA, int BASE, typename... S> struct GroupChain<F, FMA, BASE, Group<S...>> {
+  typedef Chain<F, FMA, BASE, S...> type;
+};
+
+template <typename F> struct PipeTile { static constexpr int value = sizeof(F) == 4 ? 32 : 16; };  // samples per pipeline step
+
+template <typename F> struct PipeShared {
+  float* sine;
+  F* edge;  // [n_edges][2][T][64]
+  F* mix;   // [2][TN][TS]
+};
+
+// One stage group = one wavefront.  I: group index, NG: number of chain groups (mixer excluded),
+// LAST_ENV: index of the group holding the chain's last envelope stage (-1: none).
+template <typename F, bool FMA, int NG, int I, int BASE, int LAST_ENV, typename G>
+__device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
+  typedef typename GroupChain<F, FMA, BASE, G>::type ChainT;
+  typedef typename WordOf<F>::type W;
+  constexpr int T = PipeTile<F>::value;
+  constexpr int TN = sizeof(F) == 4 ? 64 : 32;
+  constexpr int TS = 68;
+  constexpr u32 SLOT_LO = (u32)BASE, SLOT_HI = (u32)(BASE + GroupInfo<G>::slots);
+
+  Ctx ctx;
+  ctx.sine = sh.sine;
+  ctx.f2pi = a.f2pi;
+  const bool live = (u32)lane < nv;
+  const u32 voice = live ? v0 + lane : v0 + nv - 1;
+  ChainT chain;
+  chain.load(a.state + voice, a.stride);
+
+  u32 ev_i = 0, ev_end = 0;
+  if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
+  u32 next_frame = 0xFFFFFFFFu;
+  if (ev_i < ev_end) next_frame = a.events[ev_i].frame;
+  u32 done_frame = 0xFFFFFFFFu;
+  u32 base = 0;  // absolute frame of the current block's frame 0
+  auto apply_events_upto = [&](u32 n_abs) {
+    while (next_frame <= n_abs) {
+      Event e = a.events[ev_i];
+      const u32 op = e.slot_op >> 24, slot = e.slot_op & 0xFFFFFFu;
+      if (slot >= SLOT_LO && slot < SLOT_HI) {  // every group scans the list, the owner applies
+        chain.on_event(op, slot, e.bits, e.frame - base);
+        if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)e.bits;
+      }
+      ++ev_i;
+      next_frame = ev_i < ev_end ? a.events[ev_i].frame : 0xFFFFFFFFu;
+    }
+  };
+
+  // The pipeline runs continuously over all blocks of the launch: global tile g = (block, tile in block).
+  const u32 n_frames = a.frame_end - a.frame_begin;
+  const int tpb = (int)((n_frames + T - 1) / T);           // tiles per block
+  const int qpb = (int)((n_frames + TN - 1) / TN);         // mix tiles per block
+  const int n_tiles = tpb * (int)a.n_blocks;
+  const int n_steps = n_tiles + NG;
+  int blk = 0, ti = 0;                                      // position of this group's next tile
+  for (int s = 0; s < n_steps; ++s) {
+    const int g = s - I;
+    if (g >= 0 && g < n_tiles) {
+      if (ti == 0) chain.begin_block(a.frame_begin);
+      const u32 n = a.frame_begin + (u32)ti * T;
+      const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
+      apply_events_upto(base + n);
+      F x[T];
+      if (I > 0) {
+        const F* in = sh.edge + ((long)((I - 1) * 2 + (g & 1)) * T) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < T; ++j) x[j] = in[j * 64];
+      } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j) x[j] = (F)0;
+      }
+      const bool ev_inside = next_frame < base + n + T;
+      if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev_inside)) {
+        chain.template tick_tile<T>(x, ctx, n, done_frame);
+      } else {
+        for (u32 j = 0; j < m; ++j) {
+          apply_events_upto(base + n + j);
+          x[j] = chain.tick(x[j], ctx, n + j, done_frame);
+        }
+      }
+      if (I < NG - 1) {
+        F* out = sh.edge + ((long)(I * 2 + (g & 1)) * T) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < T; ++j) out[j * 64] = x[j];
+      } else {  // last chain group: column write into the transposed mix tile
+        const u32 rel = (u32)ti * T;
+        const u32 qg = (u32)blk * (u32)qpb + rel / TN;  // global mix-tile counter: double-buffer parity
+        F* out = sh.mix + ((long)(qg & 1u) * TN + (rel % TN)) * TS + lane;
+#pragma unroll
+        for (int j = 0; j < T; ++j) out[j * TS] = x[j];
+      }
+      if (++ti == tpb) {  // block finished for this group
+        apply_events_upto(base + a.frame_end);  // changes due exactly at the end (precise_timing.rs:85-103)
+        ti = 0;
+        ++blk;
+        base += a.block_size;
+      }
+    }
+    __syncthreads();
+  }
+  if (live) chain.store(a.state + voice, a.stride);
+  if (GroupInfo<G>::has_env) {
+    const bool any_done = live && done_frame != 0xFFFFFFFFu;
+    if (I == LAST_ENV && live) a.done_frames[voice] = done_frame;
+    const u64 bd = __builtin_amdgcn_ballot_w64(any_done);
+    if (lane == 0 && bd) atomicOr(&a.flags[0], 1u);
+    if (I == LAST_ENV) {
+      const bool running = live && !chain.last_env_stopped(false);
+      const u64 br = __builtin_amdgcn_ballot_w64(running);
+      if (lane == 0 && br) atomicAdd(&a.flags[1], (u32)__builtin_popcountll(br));
+    }
+  }
+}
+
+// The mixer wavefront: lane j folds frame j of a finished mix tile over the wave's voices in voice order.
+template <typename F, int NG>
+__device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global,
+                                               u32 v0, u32 nv) {
+  constexpr int T = PipeTile<F>::value;
+  constexpr int TN = sizeof(F) == 4 ? 64 : 32;
+  constexpr int TS = 68;
+  const u32 n_frames = a.frame_end - a.frame_begin;
+  const int tpb = (int)((n_frames + T - 1) / T);
+  const int qpb = (int)((n_frames + TN - 1) / TN);
+  const int n_tiles = tpb * (int)a.n_blocks;
+  const int n_steps = n_tiles + NG;
+  const u32 n_waves_total = (a.n_voices + 63u) / 64u;
+  int blk = 0, ti = 0;
+  for (int s = 0; s < n_steps; ++s) {
+    const int g = s - NG;  // the tile the last chain group finished in the previous step
+    if (g >= 0 && g < n_tiles) {
+      const u32 rel_end = (u32)(ti + 1) * T < n_frames ? (u32)(ti + 1) * T : n_frames;  // frames of this block written so far
+      if (rel_end % TN == 0 || ti == tpb - 1) {
+        const u32 q = ((u32)ti * T) / TN;
+        const u32 qg = (u32)blk * (u32)qpb + q;
+        const u32 len = rel_end - q * TN;
+        const F* my = sh.mix + (long)(qg & 1u) * TN * TS;
+        const u32 n0 = a.frame_begin + q * TN;
+        if ((u32)lane < len) {
+          const F* row = my + (long)lane * TS;
+          F acc;
+          if (nv == 64u) {
+#pragma unroll
+            for (int vb = 0; vb < 64; vb += 16) {
+              F t[16];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) t[k] = row[vb + k];
+              if (vb == 0) acc = t[0];
+#pragma unroll
+              for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
+            }
+          } else {
+            acc = row[0];
+            for (u32 v = 1; v < nv; ++v) acc = acc + row[v];
+          }
+          a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
+        }
+        if (a.voices_out) {
+          for (u32 v = 0; v < nv; ++v)
+            if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[(long)lane * TS + v];
+        }
+      }
+      if (++ti == tpb) { ti = 0; ++blk; }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename F, bool FMA, int NG, int I, int BASE, int LAST_ENV, typename G, typename... Rest>
+__device__ __forceinline__ void pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
+  if (wave == I) {
+    pipe_run_group<F, FMA, NG, I, BASE, LAST_ENV, G>(sh, a, lane, v0, nv);
+    return;
+  }
+  if constexpr (sizeof...(Rest) > 0)
+    pipe_dispatch<F, FMA, NG, I + 1, BASE + GroupInfo<G>::slots, LAST_ENV, Rest...>(wave, sh, a, lane, v0, nv);
+}
+
+template <int I, typename... Gs> struct LastEnv;
+template <int I> struct LastEnv<I> { static constexpr int value = -1; };
+template <int I, typename G, typename... Rest> struct LastEnv<I, G, Rest...> {
+  static constexpr int later = LastEnv<I + 1, Rest...>::value;
+  static constexpr int value = later >= 0 ? later : (GroupInfo<G>::has_env ? I : -1);
+};
+
+// One workgroup = 64 voices = (number of groups + 1) wavefronts.
+template <typename F, bool FMA, typename... Gs>
+__global__ void __launch_bounds__((sizeof...(Gs) + 1) * 64) voice_pipe_kernel(VoiceKernelArgs<F> a) {
+  constexpr int NG = (int)sizeof...(Gs);
+  constexpr int WAVES = NG + 1;
+  constexpr int T = PipeTile<F>::value;
+  constexpr int TN = sizeof(F) == 4 ? 64 : 32;
+  constexpr int TS = 68;
+  constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
+  __shared__ float sine[kSine ? 16384 : 1];
+  __shared__ __attribute__((aligned(16))) F edge[(NG > 1 ? NG - 1 : 1) * 2 * T * 64];
+  __shared__ __attribute__((aligned(16))) F mix[2 * TN * TS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  if (kSine) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll 4
+    for (int k = wave; k < 64; k += WAVES) {
+      const float* g = a.sine_table + (k * 64 + lane) * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sine + k * 256), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  PipeShared<F> sh;
+  sh.sine = sine;
+  sh.edge = edge;
+  sh.mix = mix;
+  const u32 wave_global = blockIdx.x;  // one 64-voice wavefront-group per workgroup
+  const u32 v0 = wave_global * 64u;
+  const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
+  if (wave == NG) pipe_run_mixer<F, NG>(sh, a, lane, wave_global, v0, nv);
+  else pipe_dispatch<F, FMA, NG, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, v0, nv);
+}
+
+}  // namespace knh_dev

@@ -1,0 +1,175 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties, plus the equivalences
+between the library's own execution forms (single-wave vs wave-pipelined kernel, one launch per
+block vs many blocks per launch, whole vs split blocks).  All comparisons are bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, fire_all, make_gpu, make_oracle
+from knaster_amd import _lib as L
+from knaster_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def left_fold(rows: np.ndarray) -> np.ndarray:
+    acc = rows[0].copy()
+    for r in rows[1:]:
+        acc = acc + r
+    return acc
+
+
+def tree_mix(voices: np.ndarray) -> np.ndarray:
+    """The documented KNH_MIX_TREE order: fold 64 voices per wavefront, fold 16 wavefronts per group, fold groups."""
+    n = voices.shape[0]
+    waves = [left_fold(voices[i:i + 64]) for i in range(0, n, 64)]
+    groups = [left_fold(np.stack(waves[i:i + 16])) for i in range(0, len(waves), 16)]
+    return left_fold(np.stack(groups))
+
+
+def c3_script(w, block, bank, offset=0):
+    v = np.arange(w.n_voices, dtype=np.uint32)
+    if block == 0:
+        bank.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER, block_offset=offset)
+    if block == 3:
+        bank.param_apply_many(v[::3], w.release[0], w.release[1], L.VALUE_TRIGGER, block_offset=offset)
+    if block == 4:  # sample-accurate cutoff changes on half the voices (stage 2 is not wrapped -> immediate)
+        p = configs.voice_parameters(w.n_voices)
+        bank.param_apply_many(v[1::2], 2, 0, L.VALUE_FLOAT, p["cutoff"][1::2] * 0.5, None, None, block_offset=offset)
+
+
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pipeline):
+    """16384 voices x 512 frames: (a) the tree mix equals the documented fold of the per-voice signals,
+    (b) the left-fold mix equals the serial fold, (c) 96 sampled voices equal the oracle run on just
+    those voices (voices are independent), all bit for bit."""
+    monkeypatch.setenv("KNH_PIPELINE", pipeline)
+    w = configs.config("C3")
+    g_tree = make_gpu(knh, w, L.MIX_TREE)
+    g_fold = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    pick = np.unique(np.concatenate([np.arange(0, 32), np.arange(8191, 8223), np.arange(w.n_voices - 32, w.n_voices)]))
+    sub = configs.Workload("sub", w.stages, len(pick), w.block_size, w.sample_type, w.out_channels,
+                           {s: a[pick] for s, a in w.ctor.items()})
+    o = make_oracle(oracle, sub, want_mix=False)
+    for block in range(3):
+        for bank, n in ((g_tree, w.n_voices), (g_fold, w.n_voices), (o, len(pick))):
+            if block == 0:
+                fire_all(bank, n, *w.restart)
+            if block == 2:
+                fire_all(bank, n, w.release[0], w.release[1])
+        out_t, voices, _ = g_tree.process_block_voices()
+        out_f, voices_f, _ = g_fold.process_block_voices()
+        _, o_voices, _, _ = o.process_block()
+        assert_bit_equal(voices, voices_f, "tree vs fold banks per-voice")
+        assert_bit_equal(voices[pick], o_voices, f"block {block}: sampled voices vs oracle")
+        assert_bit_equal(out_t[0], tree_mix(voices), f"block {block}: tree mix")
+        assert_bit_equal(out_f[0], left_fold(voices), f"block {block}: left-fold mix")
+        assert_bit_equal(out_t[0], out_t[1], "L == R")
+        ref = voices.astype(np.float64).sum(axis=0)
+        assert np.max(np.abs(out_t[0] - ref)) <= 1e-5 and np.max(np.abs(out_f[0] - ref)) <= 1e-5
+        assert np.max(np.abs(ref)) > 1e-4  # not silence
+
+
+@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C4", 300, 100), ("C5", 260, 128), ("C2", 200, 48)])
+def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
+    w = configs.config(name, n_voices=n_voices, block_size=block_size)
+    outs = {}
+    for pipeline in ("0", "1"):
+        monkeypatch.setenv("KNH_PIPELINE", pipeline)
+        g = make_gpu(knh, w)
+        res = []
+        for block in range(6):
+            if name in ("C3", "C4"):
+                c3_script(w, block, g)
+            if name == "C5":
+                e = configs.c5_events(w, block)
+                if e is not None:
+                    g.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5])
+            out, voices, flags = g.process_block_voices()
+            res.append((out, voices, flags, g.read_done_frames()))
+        outs[pipeline] = res
+        g.close()
+    for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["0"], outs["1"]):
+        assert_bit_equal(v0, v1, "per-voice")
+        assert_bit_equal(o0, o1, "mix")
+        assert f0 == f1 and np.array_equal(d0, d1)
+
+
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 700, 512), ("C3", 130, 100), ("C5", 200, 128)])
+def test_many_blocks_per_launch_equals_block_by_block(knh, monkeypatch, pipeline, name, n_voices, block_size):
+    monkeypatch.setenv("KNH_PIPELINE", pipeline)
+    w = configs.config(name, n_voices=n_voices, block_size=block_size)
+    n_blocks = 7
+
+    def script(block, bank, offset):
+        if name == "C3":
+            c3_script(w, block, bank, offset)
+        else:
+            e = configs.c5_events(w, block)
+            if e is not None:
+                bank.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5], block_offset=offset)
+    a = make_gpu(knh, w)
+    single = []
+    for block in range(n_blocks):
+        script(block, a, 0)
+        single.append(a.process_block()[0])
+    b = make_gpu(knh, w)
+    for block in range(n_blocks):
+        script(block, b, block)
+    multi, _ = b.process_blocks(n_blocks)
+    for block in range(n_blocks):
+        assert_bit_equal(multi[block], single[block], f"block {block}")
+    # and the state left behind is the same: one more block from each
+    assert_bit_equal(a.process_block_voices()[1], b.process_block_voices()[1], "state after the launch")
+    # two launches of 3 + 4 blocks == one launch of 7
+    c = make_gpu(knh, w)
+    for block in range(n_blocks):
+        script(block, c, block)   # offsets beyond the first launch carry over to the second
+    first, _ = c.process_blocks(3)
+    second, _ = c.process_blocks(4)
+    assert_bit_equal(np.concatenate([first, second]), multi, "3 + 4 blocks")
+
+
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_split_block_equals_whole_block(knh, monkeypatch, pipeline):
+    """ctx.block partial processing (BlockMetadata::make_partial, ugen.rs:87-93): frames [0,k) then [k,B)."""
+    monkeypatch.setenv("KNH_PIPELINE", pipeline)
+    w = configs.config("C3", n_voices=200, block_size=256)
+    whole, parts = make_gpu(knh, w), make_gpu(knh, w)
+    for bank in (whole, parts):
+        fire_all(bank, w.n_voices, *w.restart)
+    for k in (1, 37, 64, 255):
+        ref, _ = whole.process_block()
+        out = np.zeros_like(ref)
+        parts.process_block(frames_to_process=k, block_start_offset=0, out=out)
+        parts.process_block(frames_to_process=w.block_size - k, block_start_offset=k, out=out)
+        assert_bit_equal(out, ref, f"split at {k}")
+
+
+def test_runs_are_deterministic(knh):
+    w = configs.config("C3", n_voices=4096, block_size=512)
+    outs = []
+    for _ in range(2):
+        g = make_gpu(knh, w)
+        fire_all(g, w.n_voices, *w.restart)
+        outs.append(g.process_blocks(4)[0])
+        g.close()
+    assert_bit_equal(outs[0], outs[1], "two runs")
+
+
+def test_mix_is_linear_in_the_voice_set(knh):
+    """Voices are independent: a bank of voices A+B mixes to (mix A) + (mix B) up to f32 reassociation,
+    and exactly when A and B are whole 1024-voice fold groups."""
+    w = configs.config("C3", n_voices=2048, block_size=128)
+    full = make_gpu(knh, w)
+    halves = []
+    for lo in (0, 1024):
+        h = configs.Workload("h", w.stages, 1024, w.block_size, w.sample_type, 2, {s: a[lo:lo + 1024] for s, a in w.ctor.items()})
+        halves.append(make_gpu(knh, h))
+    for bank, n in [(full, 2048), (halves[0], 1024), (halves[1], 1024)]:
+        fire_all(bank, n, *w.restart)
+    for _ in range(3):
+        f = full.process_block()[0]
+        a = halves[0].process_block()[0]
+        b = halves[1].process_block()[0]
+        assert_bit_equal(f, a + b, "mix(A u B) == mix(A) + mix(B)")
