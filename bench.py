@@ -4,9 +4,11 @@
 Workload: BASELINE.json configs[2] ("C3"): 16384 voices per GPU, chain
 SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, block_size 512, f32, 48 kHz, synthetic
 per-voice parameters (xorshift32).  One *step* = one 512-frame block of every
-voice on every rank.  Voices shard across ranks (one process per GPU); each rank folds its own
-voices into a stereo block and the stereo blocks are sum-reduced to rank 0 over RCCL in batches
-of REDUCE_EVERY blocks (the reduce is latency-bound at 4 KiB per block).
+voice on every rank.  Blocks are rendered REDUCE_EVERY per launch (knh_bank_process_blocks_device:
+voice state stays in registers across the blocks of a launch; results are bit-identical to one launch
+per block, tests/test_gpu_properties.py).  Voices shard across ranks (one process per GPU); each rank
+folds its own voices into stereo blocks and each launch's stereo blocks are sum-reduced to rank 0
+over RCCL in one call (the reduce is latency-bound at 4 KiB per block).
 
 Launch: `python bench.py` (N=1) or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
@@ -95,39 +97,46 @@ def main():
     voices = np.arange(nv, dtype=np.uint32)
 
     stream = torch.cuda.current_stream()
+    # the mixed stereo blocks of one batch: [REDUCE_EVERY][channels][block_size], resident in HBM
     ring = torch.zeros((REDUCE_EVERY, w_all.out_channels, bs), dtype=torch.float32, device=dev)
-    slot_bytes = w_all.out_channels * bs * 4
     ring_ptr = ring.data_ptr()
+    CYCLE = 64  # the note cycle of SURVEY.md 8(d): t_restart at block 0, t_release at block 32 of every 64 blocks
 
-    def run_steps(first_step: int, n: int, release_at: int):
+    def schedule(first_step: int, n: int):
+        """Queue the parameter events of steps [first_step, first_step + n) for the next launch."""
         for i in range(n):
-            step = first_step + i
-            if step == 0:
-                bank.param_apply_many(voices, w_all.restart[0], w_all.restart[1], L.VALUE_TRIGGER)
-            if step == release_at:
-                bank.param_apply_many(voices, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER)
-            slot = step % REDUCE_EVERY
-            bank.process_block_device(ring_ptr + slot * slot_bytes, stream.cuda_stream)
-            if world > 1 and slot == REDUCE_EVERY - 1:
-                dist.reduce(ring, dst=0, op=dist.ReduceOp.SUM)
+            phase = (first_step + i) % CYCLE
+            if phase == 0:
+                bank.param_apply_many(voices, w_all.restart[0], w_all.restart[1], L.VALUE_TRIGGER, block_offset=i)
+            elif phase == CYCLE // 2:
+                bank.param_apply_many(voices, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER, block_offset=i)
+
+    def run_steps(first_step: int, n: int):
+        """n steps (blocks), REDUCE_EVERY blocks per launch; one RCCL reduce of the batch's stereo blocks."""
+        done = 0
+        while done < n:
+            k = min(REDUCE_EVERY, n - done)
+            schedule(first_step + done, k)
+            bank.process_blocks_device(k, ring_ptr, stream.cuda_stream)
+            if world > 1:
+                dist.reduce(ring[:k], dst=0, op=dist.ReduceOp.SUM)
+            done += k
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    release_at = args.warmup + args.steps // 2
-    run_steps(0, args.warmup, release_at)
+    run_steps(0, args.warmup)
     fence()
     bank.timing_reset(True)
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps, release_at)
-    if world > 1 and (args.warmup + args.steps) % REDUCE_EVERY != 0:
-        dist.reduce(ring, dst=0, op=dist.ReduceOp.SUM)
+    run_steps(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = bank.timing_read()
     bank.timing_reset(False)
+    blocks_per_launch = args.steps / max(launches, 1)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -140,14 +149,25 @@ def main():
         kernel_avg_ms = kernel_ms / max(launches, 1)
 
     sane = bool(torch.isfinite(ring).all().item())
+    traffic = None  # HBM bytes per launch from the committed PMC passes, if they were taken on this launch shape
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            prof = json.load(f)
+        wl = prof.get("workload", {})
+        if (wl.get("voices"), wl.get("block_size"), wl.get("blocks_per_launch")) == (nv, bs, int(round(args.steps / max(launches, 1)))):
+            traffic = prof["voice_pipe_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0:
         total_voices = nv * world
         ugen_samples = float(total_voices) * bs * ugens * args.steps
         value = ugen_samples / elapsed
         rd, wr = bank.algorithmic_bytes_per_voice_block()
-        alg_bytes_per_launch = float(rd + wr) * nv  # one launch = one block of this rank's voices
+        # 92 B per voice per block (state read once + mutable state written once per block)
+        # x the voice-blocks one launch processes
+        alg_bytes_per_launch = float(rd + wr) * nv * blocks_per_launch
         achieved_gbs = alg_bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
-        kernel_rate = float(nv) * bs * ugens / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
+        kernel_rate = float(nv) * bs * ugens * blocks_per_launch / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
         line = {
             "metric": "UGen-samples/sec (voices x block_size x UGens / s)",
             "value": value,
@@ -166,13 +186,16 @@ def main():
                 "voices_per_gpu": nv, "voices_total": total_voices, "block_size": bs, "sample_rate": 48000,
                 "ugens_per_voice": ugens, "mix": "two-level left fold (deterministic)",
                 "arithmetic": "fma" if args.allow_fma else "exact (bit-identical per voice to the CPU oracle)",
-                "parallelism": f"voices sharded over {world} rank(s); RCCL sum-reduce of stereo blocks every {REDUCE_EVERY} blocks",
+                "parallelism": f"voices sharded over {world} rank(s); {REDUCE_EVERY} blocks per launch; RCCL sum-reduce of the "
+                               f"stereo blocks once per launch",
+                "events": "t_restart on every voice at block 0 and t_release at block 32 of every 64-block cycle",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "voice_kernel<float,...,SinWt,MulVal,Svf,MulAsr>",
-                "kernel_avg_ms": kernel_avg_ms, "launches": launches,
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes)" if traffic else None,
+                "kernel": "voice_pipe_kernel<float,false,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>",
+                "kernel_avg_ms": kernel_avg_ms, "launches": launches, "blocks_per_launch": blocks_per_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "note": "fused kernel moves 92 B per voice per block; it is bound by dependent FP32 VALU issue, not HBM (see valu)",
             },
@@ -184,8 +207,15 @@ def main():
             "output_finite": sane,
         }
         if not args.no_cpu_baseline and world == 1:
-            cores = os.cpu_count() or 1
-            blocks = args.cpu_baseline_blocks or 64
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU is 16 cores
+            blocks = args.cpu_baseline_blocks
+            if not blocks:  # calibrate to roughly 10-15 s of CPU work
+                secs8, _ = cpu_baseline(w_all, cores, 8)
+                blocks = int(max(16, min(4096, 8 * 12.0 / max(secs8, 1e-3))))
             secs, wall = cpu_baseline(w_all, cores, blocks)
             line["cpu_baseline"] = {
                 "value": float(total_voices) * bs * ugens * blocks / secs, "unit": "UGen-samples/s", "cores": cores,
@@ -194,10 +224,11 @@ def main():
                           f"{cores} independent sequential schedulers (oracle, g++ -O3 -ffp-contract=off)",
                 "seconds": secs,
             }
-            secs1, _ = cpu_baseline(w_all, 1, max(4, blocks // 8))
+            b1 = max(4, blocks // 16)
+            secs1, _ = cpu_baseline(w_all, 1, b1)
             line["cpu_baseline_single_thread"] = {
-                "value": float(total_voices) * bs * ugens * max(4, blocks // 8) / secs1, "unit": "UGen-samples/s", "cores": 1,
-                "kind": "port", "sample": f"{max(4, blocks // 8)} blocks, one sequential scheduler (the reference is single-threaded)",
+                "value": float(total_voices) * bs * ugens * b1 / secs1, "unit": "UGen-samples/s", "cores": 1,
+                "kind": "port", "sample": f"{b1} blocks, one sequential scheduler (the reference is single-threaded)",
             }
         print(json.dumps(line), flush=True)
     bank.close()
