@@ -148,6 +148,19 @@ def main():
     else:
         kernel_avg_ms = kernel_ms / max(launches, 1)
 
+    # The same path when the boundary hands the blocks to the HOST (knh_bank_process_blocks: D2H copy of
+    # every launch's stereo blocks over PCIe + stream sync).  Reported beside `value`, never as `value`.
+    host_rate = None
+    if world == 1:
+        n_host = 4
+        schedule(args.warmup + args.steps, REDUCE_EVERY)
+        bank.process_blocks(REDUCE_EVERY)
+        t1 = time.perf_counter()
+        for i in range(n_host):
+            schedule(args.warmup + args.steps + (i + 1) * REDUCE_EVERY, REDUCE_EVERY)
+            bank.process_blocks(REDUCE_EVERY)
+        host_rate = float(nv) * bs * ugens * REDUCE_EVERY * n_host / (time.perf_counter() - t1)
+
     sane = bool(torch.isfinite(ring).all().item())
     traffic = None  # HBM bytes per launch from the committed PMC passes, if they were taken on this launch shape
     try:
@@ -205,6 +218,10 @@ def main():
                 "ops_per_ugen_sample": OPS_PER_UGEN_SAMPLE, "kernel_only_ugen_samples_per_s": kernel_rate,
             },
             "output_finite": sane,
+            "host_output": None if host_rate is None else {
+                "value": host_rate, "unit": "UGen-samples/s",
+                "note": "PCIe-inclusive: each 64-block launch's stereo blocks copied to host memory and synchronised",
+            },
         }
         if not args.no_cpu_baseline and world == 1:
             try:
