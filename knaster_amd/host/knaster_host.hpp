@@ -1,0 +1,589 @@
+// knaster_host.hpp -- C++ host-side mirror of Knaster's graph API for the accelerated path.
+//
+// The reference host is Rust; this image has no Rust toolchain, so the layer above the C ABI
+// (include/knaster_hip.h) is written in C++ with the reference's names and argument meaning:
+//
+//   auto [graph, processor] = AudioProcessor<float>::create(/*outputs*/ 2, {.block_size = 64});
+//   graph.edit([&](GraphEdit<float>& g) {                 // knaster_graph/src/graph.rs:1410
+//     auto s = g.push(SinWt(440.f));                      // graph_edit.rs:88
+//     (s * 0.2f).out({0, 0}).to_graph_out();              // graph_edit.rs:1170-1207, 280-292, 363-369
+//   });                                                   // commit on scope exit (graph_edit.rs:258-262)
+//   processor.run_without_inputs();                       // processor.rs:142-179
+//   float l = processor.output_block().read(0, 0);
+//
+// At commit, every signal connected to the graph output is traced back to its source; voices whose
+// chains have the same shape are gathered into one knh_bank (one fused gfx950 kernel per shape)
+// instead of ~6 nodes per voice.  Parameter handles (`node.param("freq").set(v)`, `.set_at(v, t)`,
+// `.trig()`) and `carrier.link("freq", signal)` keep their meaning; GraphGen's event handling
+// (graph_gen.rs:110-166, scheduling.rs:95-121) is restated in `AudioProcessor::run_*`.
+// Anything that is not a supported voice chain is rejected at commit (the reference would run it on
+// the CPU; that is outside this engine).  Header-only; needs libknaster_hip.so.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <initializer_list>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../include/knaster_hip.h"
+
+namespace knaster {
+
+// ---- Seconds / Time: knaster_primitives/src/time.rs:25-134, knaster_graph/src/scheduling.rs:73-139 ----
+struct Seconds {
+  static constexpr uint32_t kTesimalsPerSecond = 282240000u;
+  uint32_t seconds = 0, subsecond_tesimals = 0;
+  static Seconds zero() { return {}; }
+  static Seconds from_secs_f64(double s) {
+    Seconds r;
+    r.seconds = static_cast<uint32_t>(std::floor(s));
+    r.subsecond_tesimals = static_cast<uint32_t>((s - std::trunc(s)) * static_cast<double>(kTesimalsPerSecond));
+    return r;
+  }
+  static Seconds from_samples(uint64_t samples, uint64_t sample_rate) {
+    return {static_cast<uint32_t>(samples / sample_rate),
+            static_cast<uint32_t>((samples % sample_rate) * kTesimalsPerSecond / sample_rate)};
+  }
+  uint64_t to_samples(uint64_t sample_rate) const {
+    return static_cast<uint64_t>(seconds) * sample_rate + (static_cast<uint64_t>(subsecond_tesimals) * sample_rate) / kTesimalsPerSecond;
+  }
+  bool operator==(const Seconds& o) const { return seconds == o.seconds && subsecond_tesimals == o.subsecond_tesimals; }
+  bool le(const Seconds& o) const { return seconds == o.seconds ? subsecond_tesimals <= o.subsecond_tesimals : seconds < o.seconds; }
+  Seconds saturating_sub(const Seconds& r) const {
+    if (le(r)) return zero();
+    if (subsecond_tesimals >= r.subsecond_tesimals) return {seconds - r.seconds, subsecond_tesimals - r.subsecond_tesimals};
+    return {seconds - r.seconds - 1, kTesimalsPerSecond - (r.subsecond_tesimals - subsecond_tesimals)};
+  }
+};
+struct Time {
+  Seconds seconds;
+  bool absolute = false;
+  static Time at(Seconds s) { return {s, true}; }
+  static Time after(Seconds s) { return {s, false}; }
+  static Time asap() { return {Seconds::zero(), false}; }
+  uint64_t to_samples_until_due(uint64_t block_size, uint64_t sample_rate, uint64_t frame_clock) {
+    if (absolute) {
+      uint64_t t = seconds.to_samples(sample_rate);
+      return t >= frame_clock ? t - frame_clock : 0;
+    }
+    if (seconds == Seconds::zero()) return 0;
+    uint64_t samples = seconds.to_samples(sample_rate);
+    seconds = seconds.saturating_sub(Seconds::from_samples(block_size, sample_rate));
+    return samples;
+  }
+};
+struct PTrigger {};
+
+// ---- UGen descriptions (constructor arguments only; the DSP lives in the fused kernels) ----------
+enum class SvfFilterType : uint8_t { Low = 0, High, Band, Notch, Peak, All, Bell, LowShelf, HighShelf };
+
+struct UGenSpec {
+  UGenSpec() = default;
+  UGenSpec(uint16_t kind_, std::vector<double> args_) : kind(kind_), args(std::move(args_)) {}
+  uint16_t kind = 0;                 // knh_stage_kind of the core UGen
+  std::vector<double> args;          // constructor arguments
+  std::vector<std::pair<uint16_t, double>> wrappers;  // (KNH_STAGE_WR_*, value) in application order
+  bool ar_params_ = false;
+  uint16_t precise_timing_ = 0;
+  bool is_constant = false, is_env = false;
+  // wrappers_core.rs:26-111
+  UGenSpec wr_mul(double v) && { wrappers.emplace_back(KNH_STAGE_WR_MUL, v); return std::move(*this); }
+  UGenSpec wr_add(double v) && { wrappers.emplace_back(KNH_STAGE_WR_ADD, v); return std::move(*this); }
+  UGenSpec wr_sub(double v) && { wrappers.emplace_back(KNH_STAGE_WR_SUB, v); return std::move(*this); }
+  UGenSpec ar_params() && { ar_params_ = true; return std::move(*this); }
+  UGenSpec precise_timing(uint16_t max_changes_per_block) && { precise_timing_ = max_changes_per_block; return std::move(*this); }
+};
+inline UGenSpec SinWt(double freq) { return UGenSpec(KNH_STAGE_SIN_WT, {freq}); }
+inline UGenSpec SinNumeric(double freq) { return UGenSpec(KNH_STAGE_SIN_NUMERIC, {freq}); }
+inline UGenSpec SvfFilter(SvfFilterType ty, double cutoff, double q, double gain_db) {
+  return UGenSpec(KNH_STAGE_SVF, {static_cast<double>(ty), cutoff, q, gain_db});
+}
+inline UGenSpec OnePoleLpf(double cutoff) { return UGenSpec(KNH_STAGE_ONEPOLE_LPF, {cutoff}); }
+inline UGenSpec OnePoleHpf() { return UGenSpec(KNH_STAGE_ONEPOLE_HPF, {}); }
+inline UGenSpec EnvAsr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_ASR, {attack, release}); s.is_env = true; return s; }
+inline UGenSpec EnvAr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_AR, {attack, release}); s.is_env = true; return s; }
+inline UGenSpec Constant(double value) { UGenSpec s(KNH_STAGE_MUL_CONST, {value}); s.is_constant = true; return s; }
+
+struct GraphError : std::runtime_error { using std::runtime_error::runtime_error; };
+enum class ParameterError { Ok = 0, ParameterIndexOutOfBounds, DescriptionNotFound };
+
+template <typename F> class Graph;
+template <typename F> class GraphEdit;
+template <typename F> class AudioProcessor;
+
+// A node of the (host-side) graph table.
+struct NodeRec {
+  enum Type { UGEN, MATH } type = UGEN;
+  UGenSpec spec;            // UGEN
+  uint16_t math_kind = 0;   // MATH: KNH_STAGE_{MUL,ADD,SUB,DIV}_CONST for op with a Constant; 0xFFFF = signal * signal
+  int in0 = -1, in1 = -1;   // input edges (node ids)
+  int link_source = -1, link_param = -1;  // audio-rate parameter edge (graph_edit.rs:735-754)
+  // where the node ended up after commit
+  int bank = -1, voice = -1, stage = -1;
+};
+
+struct SchedulingEvent {  // scheduling.rs:29-36
+  int node = -1;
+  uint32_t parameter = 0;
+  uint32_t kind = KNH_VALUE_FLOAT;
+  double f = 0;
+  int64_t i = 0;
+  bool has_time = false;
+  Time time;
+};
+
+// What a voice chain looks like to the planner: the stage list plus the node behind every stage.
+struct ChainPlan {
+  std::vector<knh_stage_desc> stages;
+  std::vector<int> stage_node;                  // node id whose parameters stage s exposes (-1: none)
+  std::vector<std::vector<double>> stage_args;  // constructor arguments per stage
+  std::string signature() const {
+    std::string s;
+    for (auto& st : stages) {
+      s += std::to_string(st.kind) + "." + std::to_string(st.flags) + "." + std::to_string(st.delayed_changes_per_block) + ";";
+    }
+    return s;
+  }
+};
+
+// ---- signal handles --------------------------------------------------------------------------------
+template <typename F>
+class Sig {  // SH / DH of graph_edit.rs:266-277: one or more output channels of nodes
+ public:
+  Sig(GraphEdit<F>* g, std::vector<int> nodes) : g_(g), nodes_(std::move(nodes)) {}
+  Sig operator*(double c) const { return g_->math_const(*this, KNH_STAGE_MUL_CONST, c); }
+  Sig operator+(double c) const { return g_->math_const(*this, KNH_STAGE_ADD_CONST, c); }
+  Sig operator-(double c) const { return g_->math_const(*this, KNH_STAGE_SUB_CONST, c); }
+  Sig operator/(double c) const { return g_->math_const(*this, KNH_STAGE_DIV_CONST, c); }
+  Sig operator*(const Sig& o) const { return g_->math_sig(*this, o); }
+  Sig operator>>(const Sig& sink) const { return g_->connect(*this, sink); }  // graph_edit.rs:1347-1417
+  // .out([0,0]): the same channel twice (graph_edit.rs:280-292)
+  Sig out(std::initializer_list<int> channels) const {
+    std::vector<int> n;
+    for (int c : channels) {
+      if (c < 0 || c >= static_cast<int>(nodes_.size())) throw GraphError("out(): channel out of range");
+      n.push_back(nodes_[static_cast<size_t>(c)]);
+    }
+    return Sig(g_, n);
+  }
+  void to_graph_out() const { g_->to_graph_out(*this); }  // additive (graph_edit.rs:363-369)
+  int node() const { return nodes_.at(0); }
+  const std::vector<int>& nodes() const { return nodes_; }
+
+  // node.param("freq") -> Parameter (graph_edit.rs:761, 1700-1886)
+  class Parameter {
+   public:
+    Parameter(Graph<F>* graph, int node, uint32_t index) : graph_(graph), node_(node), index_(index) {}
+    void set(double v) { graph_->schedule({node_, index_, KNH_VALUE_FLOAT, v, 0, false, {}}); }
+    void set(int64_t v) { graph_->schedule({node_, index_, KNH_VALUE_INTEGER, 0, v, false, {}}); }
+    void set_at(double v, Time t) { graph_->schedule({node_, index_, KNH_VALUE_FLOAT, v, 0, true, t}); }
+    void trig() { graph_->schedule({node_, index_, KNH_VALUE_TRIGGER, 0, 0, false, {}}); }
+    void trig_at(Time t) { graph_->schedule({node_, index_, KNH_VALUE_TRIGGER, 0, 0, true, t}); }
+    void set(PTrigger) { trig(); }
+   private:
+    Graph<F>* graph_;
+    int node_;
+    uint32_t index_;
+  };
+  Parameter param(const std::string& name) const { return g_->param(node(), name); }
+  Parameter param(uint32_t index) const { return g_->param(node(), index); }
+  // carrier.link("freq", modulator): audio-rate parameter edge; needs .ar_params() on the carrier
+  Sig link(const std::string& name, const Sig& source) const { g_->link(node(), name, source); return *this; }
+
+ private:
+  GraphEdit<F>* g_;
+  std::vector<int> nodes_;
+};
+
+inline const char* const* stage_param_names(uint16_t kind, int* n) {
+  static const char* sin[] = {"freq", "phase_offset", "reset_phase"};
+  static const char* svf[] = {"cutoff_freq", "q", "gain", "filter", "t_calculate_coefficients"};
+  static const char* op[] = {"cutoff_freq"};
+  static const char* asr[] = {"attack_time", "release_time", "t_release", "t_restart"};
+  static const char* ar[] = {"attack_time", "release_time", "t_restart"};
+  static const char* val[] = {"value"};
+  switch (kind) {
+    case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: *n = 3; return sin;
+    case KNH_STAGE_SVF: *n = 5; return svf;
+    case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: *n = 1; return op;
+    case KNH_STAGE_MUL_ENV_ASR: *n = 4; return asr;
+    case KNH_STAGE_MUL_ENV_AR: *n = 3; return ar;
+    default: *n = 1; return val;
+  }
+}
+
+// ---- Graph -----------------------------------------------------------------------------------------
+template <typename F>
+class Graph {
+ public:
+  struct Bank {
+    knh_bank* h = nullptr;
+    ChainPlan plan;
+    uint32_t n_voices = 0;
+    std::vector<F> out;  // [channels][block_size] of the last block(s)
+  };
+  Graph(uint32_t outputs, uint32_t sample_rate, size_t block_size) : outputs_(outputs), sample_rate_(sample_rate), block_size_(block_size) {
+    if (outputs < 1 || outputs > 2) throw GraphError("this engine renders mono or stereo graphs");
+  }
+  ~Graph() {
+    for (auto& b : banks_) knh_bank_destroy(b.h);
+  }
+  Graph(const Graph&) = delete;
+  Graph& operator=(const Graph&) = delete;
+
+  // graph.edit(|g| ...): changes are committed when the closure returns (graph.rs:1410, graph_edit.rs:258-262)
+  template <typename Fn>
+  void edit(Fn&& fn) {
+    GraphEdit<F> g(this);
+    fn(g);
+    commit_changes();
+  }
+  size_t num_banks() const { return banks_.size(); }
+  const Bank& bank(size_t i) const { return banks_.at(i); }
+  size_t num_nodes() const { return nodes_.size(); }
+  uint32_t sample_rate() const { return sample_rate_; }
+  size_t block_size() const { return block_size_; }
+  uint32_t outputs() const { return outputs_; }
+  // Set `plan_only` before the first edit to build the plan without touching a device (tests on CPU).
+  bool plan_only = false;
+
+ private:
+  friend class GraphEdit<F>;
+  friend class AudioProcessor<F>;
+  template <typename> friend class Sig;
+
+  void schedule(const SchedulingEvent& ev) { events_.push_back(ev); }
+
+  // ---- chain recognition -------------------------------------------------------------------------
+  void trace(int node, ChainPlan& p, std::vector<int>& visited) {
+    if (node < 0) throw GraphError("unconnected input in a voice chain");
+    NodeRec& n = nodes_[static_cast<size_t>(node)];
+    if (n.bank >= 0) throw GraphError("a node feeds more than one voice chain (fan-out is not a per-voice chain)");
+    visited.push_back(node);
+    if (n.type == NodeRec::MATH) {
+      if (n.math_kind != 0xFFFF) {  // signal (op) Constant: graph_edit.rs:1036-1066
+        trace(n.in0, p, visited);
+        const NodeRec& c = nodes_[static_cast<size_t>(n.in1)];
+        push_stage(p, n.math_kind, 0, c.spec.precise_timing_, n.in1, c.spec.args);
+        visited.push_back(n.in1);
+        return;
+      }
+      // signal * envelope (either operand order; multiplication commutes exactly)
+      const NodeRec& a = nodes_[static_cast<size_t>(n.in0)];
+      const NodeRec& b = nodes_[static_cast<size_t>(n.in1)];
+      int env = (b.type == NodeRec::UGEN && b.spec.is_env) ? n.in1 : (a.type == NodeRec::UGEN && a.spec.is_env) ? n.in0 : -1;
+      if (env < 0) throw GraphError("signal * signal is only fused when one side is an EnvAsr/EnvAr");
+      trace(env == n.in1 ? n.in0 : n.in1, p, visited);
+      const NodeRec& e = nodes_[static_cast<size_t>(env)];
+      if (!e.spec.wrappers.empty()) throw GraphError("wrappers on an envelope inside a product are not fused");
+      push_stage(p, e.spec.kind, 0, e.spec.precise_timing_, env, e.spec.args);
+      visited.push_back(env);
+      return;
+    }
+    const UGenSpec& s = n.spec;
+    if (s.is_env || s.is_constant) throw GraphError("an envelope/constant must be an operand of * + - /");
+    const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC;
+    uint16_t flags = 0;
+    if (source) {
+      if (n.link_source >= 0) {
+        if (!(s.kind == KNH_STAGE_SIN_WT && s.ar_params_ && n.link_param == 0))
+          throw GraphError("only SinWt(..).ar_params() with link(\"freq\", ..) is fused");
+        trace(n.link_source, p, visited);
+        flags = KNH_STAGE_FLAG_AR_FREQ;
+      }
+    } else {
+      trace(n.in0, p, visited);
+    }
+    push_stage(p, s.kind, flags, s.precise_timing_, node, s.args);
+    for (auto& w : s.wrappers) push_stage(p, w.first, 0, 0, node, {w.second});
+  }
+  static void push_stage(ChainPlan& p, uint16_t kind, uint16_t flags, uint16_t dcpb, int node, std::vector<double> args) {
+    p.stages.push_back(knh_stage_desc{kind, flags, dcpb, 0});
+    p.stage_node.push_back(node);
+    p.stage_args.push_back(std::move(args));
+  }
+
+  // graph.rs:1707-1726: plan the newly connected voices, create their banks, upload their state.
+  void commit_changes() {
+    struct Voice { ChainPlan plan; std::vector<int> nodes; };
+    std::vector<Voice> voices;
+    for (auto& conn : new_outputs_) {
+      // conn = the per-channel nodes of one to_graph_out(); every channel must carry the same signal
+      for (int n : conn)
+        if (n != conn[0]) throw GraphError("different signals per output channel are not a mono voice chain");
+      if (conn.size() != outputs_) throw GraphError("to_graph_out(): channel count does not match the graph outputs");
+      Voice v;
+      trace(conn[0], v.plan, v.nodes);
+      voices.push_back(std::move(v));
+    }
+    new_outputs_.clear();
+    // group by chain shape, first appearance first
+    std::vector<std::string> order;
+    std::map<std::string, std::vector<size_t>> groups;
+    for (size_t i = 0; i < voices.size(); ++i) {
+      std::string sig = voices[i].plan.signature();
+      if (!groups.count(sig)) order.push_back(sig);
+      groups[sig].push_back(i);
+    }
+    for (const std::string& sig : order) {
+      const std::vector<size_t>& members = groups[sig];
+      Bank b;
+      b.plan = voices[members[0]].plan;
+      b.n_voices = static_cast<uint32_t>(members.size());
+      const int bank_index = static_cast<int>(banks_.size());
+      for (size_t vi = 0; vi < members.size(); ++vi) {
+        const Voice& v = voices[members[vi]];
+        for (size_t s = 0; s < v.plan.stages.size(); ++s) {
+          int node = v.plan.stage_node[s];
+          NodeRec& nr = nodes_[static_cast<size_t>(node)];
+          if (nr.bank < 0) { nr.bank = bank_index; nr.voice = static_cast<int>(vi); nr.stage = static_cast<int>(s); }
+        }
+        for (int node : v.nodes) {
+          NodeRec& nr = nodes_[static_cast<size_t>(node)];
+          if (nr.bank < 0) { nr.bank = bank_index; nr.voice = static_cast<int>(vi); nr.stage = -1; }
+        }
+      }
+      if (!plan_only) {
+        knh_bank_desc d{};
+        d.abi_version = KNH_ABI_VERSION;
+        d.n_voices = b.n_voices;
+        d.sample_type = sizeof(F) == 8 ? KNH_F64 : KNH_F32;
+        d.n_stages = static_cast<uint32_t>(b.plan.stages.size());
+        d.stages = b.plan.stages.data();
+        d.out_channels = outputs_;
+        d.mix_mode = KNH_MIX_TREE;
+        d.device = -1;
+        d.allow_fma = 0;
+        if (knh_bank_create(&d, &b.h) != KNH_OK) throw GraphError(std::string("knh_bank_create: ") + knh_last_error(nullptr));
+        for (size_t s = 0; s < b.plan.stages.size(); ++s) {
+          const size_t n_args = b.plan.stage_args[s].size();
+          if (!n_args) continue;
+          std::vector<double> args(members.size() * n_args);
+          for (size_t vi = 0; vi < members.size(); ++vi)
+            std::copy(voices[members[vi]].plan.stage_args[s].begin(), voices[members[vi]].plan.stage_args[s].end(), args.begin() + static_cast<long>(vi * n_args));
+          check(b, knh_bank_set_ctor_args(b.h, static_cast<uint32_t>(s), 0, b.n_voices, args.data(), static_cast<uint32_t>(n_args)));
+        }
+        // UGen::init runs at push time in the reference (graph.rs:462-475); the bank's voices all init here
+        check(b, knh_bank_init(b.h, sample_rate_, block_size_));
+      }
+      b.out.assign(static_cast<size_t>(outputs_) * block_size_, F(0));
+      banks_.push_back(std::move(b));
+    }
+  }
+  static void check(const Bank& b, int rc) {
+    if (rc != KNH_OK) throw GraphError(std::string("knaster_hip: ") + knh_last_error(b.h));
+  }
+
+  uint32_t outputs_, sample_rate_;
+  size_t block_size_;
+  std::vector<NodeRec> nodes_;
+  std::vector<std::vector<int>> new_outputs_;
+  std::vector<Bank> banks_;
+  std::vector<SchedulingEvent> events_;  // the rtrb channel of graph.rs:225-230, drained by the processor
+};
+
+// ---- GraphEdit: the builder handed to graph.edit() -------------------------------------------------
+template <typename F>
+class GraphEdit {
+ public:
+  explicit GraphEdit(Graph<F>* g) : graph_(g) {}
+  Sig<F> push(UGenSpec spec) {  // graph_edit.rs:88-98
+    NodeRec n;
+    n.type = NodeRec::UGEN;
+    n.spec = std::move(spec);
+    graph_->nodes_.push_back(std::move(n));
+    return Sig<F>(this, {static_cast<int>(graph_->nodes_.size()) - 1});
+  }
+
+ private:
+  template <typename> friend class Sig;
+  Sig<F> math_const(const Sig<F>& s, uint16_t kind, double c) {  // graph_edit.rs:1036-1066
+    std::vector<int> outs;
+    int cn = push(Constant(c)).node();
+    for (int src : s.nodes()) {
+      NodeRec m;
+      m.type = NodeRec::MATH;
+      m.math_kind = kind;
+      m.in0 = src;
+      m.in1 = cn;
+      graph_->nodes_.push_back(m);
+      outs.push_back(static_cast<int>(graph_->nodes_.size()) - 1);
+    }
+    return Sig<F>(this, outs);
+  }
+  Sig<F> math_sig(const Sig<F>& a, const Sig<F>& b) {  // graph_edit.rs:936-971
+    NodeRec m;
+    m.type = NodeRec::MATH;
+    m.math_kind = 0xFFFF;
+    m.in0 = a.node();
+    m.in1 = b.node();
+    graph_->nodes_.push_back(m);
+    return Sig<F>(this, {static_cast<int>(graph_->nodes_.size()) - 1});
+  }
+  Sig<F> connect(const Sig<F>& src, const Sig<F>& sink) {
+    NodeRec& n = graph_->nodes_[static_cast<size_t>(sink.node())];
+    if (n.type != NodeRec::UGEN) throw GraphError(">>: the sink must be a pushed UGen");
+    n.in0 = src.node();
+    return sink;
+  }
+  void to_graph_out(const Sig<F>& s) { graph_->new_outputs_.push_back(s.nodes()); }
+  typename Sig<F>::Parameter param(int node, const std::string& name) {
+    const NodeRec& n = graph_->nodes_[static_cast<size_t>(node)];
+    if (n.type != NodeRec::UGEN) throw GraphError("param(): not a UGen node");
+    int cnt = 0;
+    const char* const* names = stage_param_names(n.spec.kind, &cnt);
+    for (int i = 0; i < cnt; ++i)
+      if (name == names[i]) return typename Sig<F>::Parameter(graph_, node, static_cast<uint32_t>(i));
+    // "wr_mul" = index T::Parameters of the wrapped node (wrappers_core/math.rs:69-98)
+    uint32_t idx = static_cast<uint32_t>(cnt);
+    for (auto& w : n.spec.wrappers) {
+      if (w.first == KNH_STAGE_WR_MUL) {
+        if (name == "wr_mul") return typename Sig<F>::Parameter(graph_, node, idx);
+        ++idx;
+      }
+    }
+    throw GraphError("DescriptionNotFound(" + name + ")");  // ParameterError::DescriptionNotFound, ugen.rs:365
+  }
+  typename Sig<F>::Parameter param(int node, uint32_t index) { return typename Sig<F>::Parameter(graph_, node, index); }
+  void link(int node, const std::string& name, const Sig<F>& source) {
+    NodeRec& n = graph_->nodes_[static_cast<size_t>(node)];
+    int cnt = 0;
+    const char* const* names = stage_param_names(n.spec.kind, &cnt);
+    for (int i = 0; i < cnt; ++i)
+      if (name == names[i]) { n.link_source = source.node(); n.link_param = i; return; }
+    throw GraphError("DescriptionNotFound(" + name + ")");
+  }
+  Graph<F>* graph_;
+};
+
+// ---- AudioProcessor: the non-realtime driver (processor.rs:47-197) ---------------------------------
+struct AudioProcessorOptions {  // processor.rs:23-45
+  size_t block_size = 64;
+  uint32_t sample_rate = 48000;
+};
+template <typename F>
+class OutputBlock {  // RawContiguousBlock view, knaster_graph/src/block.rs:19-78
+ public:
+  OutputBlock(const F* data, size_t channels, size_t block_size) : d_(data), ch_(channels), bs_(block_size) {}
+  F read(size_t channel, size_t frame) const {
+    if (channel >= ch_ || frame >= bs_) throw std::out_of_range("OutputBlock::read");
+    return d_[channel * bs_ + frame];
+  }
+  const F* channel_as_slice(size_t channel) const { return d_ + channel * bs_; }
+  size_t channels() const { return ch_; }
+  size_t block_size() const { return bs_; }
+ private:
+  const F* d_;
+  size_t ch_, bs_;
+};
+
+template <typename F>
+class AudioProcessor {
+ public:
+  // AudioProcessor::<F>::new::<U0, Outputs>(options) -> (Graph, AudioProcessor)
+  static std::pair<std::unique_ptr<Graph<F>>, std::unique_ptr<AudioProcessor<F>>> create(uint32_t outputs, AudioProcessorOptions o = {}) {
+    if (o.block_size == 0) throw GraphError("The block size must not be 0");
+    auto g = std::make_unique<Graph<F>>(outputs, o.sample_rate, o.block_size);
+    auto p = std::unique_ptr<AudioProcessor<F>>(new AudioProcessor<F>(g.get()));
+    return {std::move(g), std::move(p)};
+  }
+  size_t block_size() const { return graph_->block_size(); }
+  uint16_t inputs() const { return 0; }
+  uint16_t outputs() const { return static_cast<uint16_t>(graph_->outputs()); }
+  uint64_t frame_clock() const { return frame_clock_; }
+
+  // One block: GraphGen::process_block steps (ii), (iv), (v) of SURVEY call stack B.
+  void run_without_inputs() { run_blocks(1); }
+  // k blocks rendered in one launch per bank; events are resolved per block exactly as k calls would.
+  void run_blocks(uint32_t k) {
+    Graph<F>& g = *graph_;
+    const uint64_t bs = g.block_size(), sr = g.sample_rate();
+    const uint32_t keep = static_cast<uint32_t>(sr / bs);  // graph_gen.rs:73-75
+    // (ii) parameter changes: waiting ones first, then the new ones (graph_gen.rs:110-166)
+    std::vector<SchedulingEvent> fresh;
+    fresh.swap(g.events_);
+    for (uint32_t b = 0; b < k; ++b) {
+      const uint64_t clock = frame_clock_ + b * bs;
+      size_t n_waiting = waiting_.size();
+      for (size_t i = 0; i < n_waiting; ++i) {
+        auto [ev, blocks_waiting] = waiting_.front();
+        waiting_.pop_front();
+        if (blocks_waiting > keep) continue;
+        if (!apply_parameter_change(ev, b, clock)) waiting_.emplace_back(ev, blocks_waiting + 1);
+      }
+      if (b == 0)
+        for (SchedulingEvent& ev : fresh)
+          if (!apply_parameter_change(ev, b, clock)) waiting_.emplace_back(ev, 0);
+    }
+    // (iv) run the banks, (v) sum their blocks in bank order into the output block
+    out_.assign(static_cast<size_t>(k) * g.outputs() * bs, F(0));
+    for (auto& bank : g.banks_) {
+      if (!bank.h) continue;
+      bank.out.resize(static_cast<size_t>(k) * g.outputs() * bs);
+      uint32_t flags = 0;
+      int rc = k == 1 ? knh_bank_process_block(bank.h, bs, 0, frame_clock_, bank.out.data(), &flags)
+                      : knh_bank_process_blocks(bank.h, k, frame_clock_, bank.out.data(), &flags);
+      if (rc != KNH_OK) throw GraphError(std::string("knaster_hip: ") + knh_last_error(bank.h));
+      for (size_t i = 0; i < out_.size(); ++i) out_[i] = out_[i] + bank.out[i];
+    }
+    frame_clock_ += static_cast<uint64_t>(k) * bs;
+    last_blocks_ = k;
+  }
+  // The last processed block (block `b` of the last run_blocks call)
+  OutputBlock<F> output_block(uint32_t b = 0) const {
+    if (b >= last_blocks_) throw std::out_of_range("output_block");
+    const size_t n = static_cast<size_t>(graph_->outputs()) * graph_->block_size();
+    return OutputBlock<F>(out_.data() + b * n, graph_->outputs(), graph_->block_size());
+  }
+
+ private:
+  explicit AudioProcessor(Graph<F>* g) : graph_(g) {}
+  // graph_gen.rs:269-305: returns true when applied (or unroutable), false to keep waiting
+  bool apply_parameter_change(SchedulingEvent& ev, uint32_t block_offset, uint64_t clock) {
+    Graph<F>& g = *graph_;
+    uint64_t delay = 0;
+    if (ev.has_time) {
+      delay = ev.time.to_samples_until_due(g.block_size(), g.sample_rate(), clock);
+      if (delay >= g.block_size()) return false;
+    }
+    const NodeRec& n = g.nodes_.at(static_cast<size_t>(ev.node));
+    if (n.bank < 0 || n.stage < 0) return true;  // not part of a committed voice chain: dropped
+    typename Graph<F>::Bank& bank = g.banks_[static_cast<size_t>(n.bank)];
+    if (!bank.h) return true;
+    // a parameter of the wrapped node, or one of its WrMul wrappers' "wr_mul"
+    int cnt = 0;
+    stage_param_names(n.spec.kind, &cnt);
+    uint32_t stage = static_cast<uint32_t>(n.stage), param = ev.parameter;
+    if (n.type == NodeRec::UGEN && static_cast<int>(ev.parameter) >= cnt) {
+      uint32_t k = ev.parameter - static_cast<uint32_t>(cnt), s = stage;
+      for (auto& w : n.spec.wrappers) {
+        ++s;
+        if (w.first == KNH_STAGE_WR_MUL) {
+          if (k == 0) { stage = s; param = 0; break; }
+          --k;
+        }
+      }
+    }
+    const uint32_t voice = static_cast<uint32_t>(n.voice);
+    const uint16_t d16 = static_cast<uint16_t>(delay);
+    const uint32_t kind = ev.kind;
+    knh_bank_param_apply_many_at(bank.h, block_offset, 1, &voice, &stage, &param, &kind, &ev.f, &ev.i, delay > 0 ? &d16 : nullptr);
+    return true;
+  }
+  Graph<F>* graph_;
+  uint64_t frame_clock_ = 0;
+  uint32_t last_blocks_ = 0;
+  std::vector<F> out_;
+  std::deque<std::pair<SchedulingEvent, uint32_t>> waiting_;
+};
+
+}  // namespace knaster

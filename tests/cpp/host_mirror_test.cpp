@@ -1,0 +1,281 @@
+// Tests of the C++ host mirror, written the way the reference's own graph tests read
+// (knaster_graph/src/tests/graph_tests.rs, README.md:34-51, knaster/examples/many_sines.rs).
+//   host_mirror_test --plan   : no device needed (chain recognition, grouping, parameter names, Time)
+//   host_mirror_test --gpu    : end to end on a MI355X, checked against the CPU oracle
+#include <cstdio>
+#include <cstring>
+
+#include "../../knaster_amd/host/knaster_host.hpp"
+#include "../../oracle/knaster_oracle.hpp"  // test-side checker only
+
+using namespace knaster;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                   \
+  do {                                                                \
+    if (!(cond)) {                                                    \
+      std::printf("  FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+      ++g_fail;                                                       \
+    }                                                                 \
+  } while (0)
+#define RUN(name)                                                         \
+  do {                                                                    \
+    int before = g_fail;                                                  \
+    try { name(); } catch (const std::exception& e) { std::printf("  EXCEPTION %s\n", e.what()); ++g_fail; } \
+    std::printf("%s %s\n", g_fail == before ? "ok  " : "FAIL", #name);    \
+  } while (0)
+
+static std::vector<double> voice_freqs(int n) {
+  kno::XOrShift32Rng rng(0x9E3779B9u);
+  std::vector<double> f;
+  for (int i = 0; i < n; ++i) f.push_back(55.0 * std::exp2(6.0 * static_cast<double>(rng.gen_f32())));
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static void plan_readme_example() {
+  auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
+  graph->plan_only = true;
+  graph->edit([&](GraphEdit<float>& g) {
+    auto s = g.push(SinWt(440.));
+    (s * 0.2).out({0, 0}).to_graph_out();
+  });
+  CHECK(graph->num_banks() == 1);
+  CHECK(graph->num_nodes() == 3);  // SinWt, Constant, MathUGen Mul (graph_edit.rs:1047-1049)
+  const auto& b = graph->bank(0);
+  CHECK(b.n_voices == 1 && b.plan.stages.size() == 2);
+  CHECK(b.plan.stages[0].kind == KNH_STAGE_SIN_WT && b.plan.stages[1].kind == KNH_STAGE_MUL_CONST);
+  CHECK(knh_chain_ugen_count(b.plan.stages.data(), 2) == 3);
+  CHECK(processor->outputs() == 2 && processor->inputs() == 0 && processor->block_size() == 64);
+}
+static void plan_groups_voices_by_chain_shape() {
+  auto [graph, processor] = AudioProcessor<float>::create(2, {128, 48000});
+  (void)processor;
+  graph->plan_only = true;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int i = 0; i < 5; ++i) {  // many_sines.rs:51-63 without the Pan2
+      auto env = g.push(EnvAr(0.01, 0.1));
+      auto sine = g.push(SinWt(300. + i).wr_mul(0.0125));
+      (env * sine).out({0, 0}).to_graph_out();
+    }
+    for (int i = 0; i < 3; ++i) {
+      auto s = g.push(SinWt(100. + i).wr_mul(0.1));
+      auto f = g.push(SvfFilter(SvfFilterType::Low, 1000., 1., 0.));
+      auto e = g.push(EnvAsr(0.01, 0.2));
+      ((s >> f) * e).out({0, 0}).to_graph_out();
+    }
+    auto m = g.push(SinWt(3.));
+    auto c = g.push(SinWt(440.).ar_params().precise_timing(4));
+    c.link("freq", m * 50. + 440.);
+    (c * 0.1).out({0, 0}).to_graph_out();
+  });
+  CHECK(graph->num_banks() == 3);
+  CHECK(graph->bank(0).n_voices == 5 && graph->bank(1).n_voices == 3 && graph->bank(2).n_voices == 1);
+  const auto& b0 = graph->bank(0).plan.stages;
+  CHECK(b0.size() == 3 && b0[0].kind == KNH_STAGE_SIN_WT && b0[1].kind == KNH_STAGE_WR_MUL && b0[2].kind == KNH_STAGE_MUL_ENV_AR);
+  const auto& b1 = graph->bank(1).plan.stages;
+  CHECK(b1.size() == 4 && b1[2].kind == KNH_STAGE_SVF && b1[3].kind == KNH_STAGE_MUL_ENV_ASR);
+  const auto& b2 = graph->bank(2).plan.stages;
+  CHECK(b2.size() == 5 && b2[3].kind == KNH_STAGE_SIN_WT && (b2[3].flags & KNH_STAGE_FLAG_AR_FREQ) && b2[3].delayed_changes_per_block == 4);
+  CHECK(b2[1].kind == KNH_STAGE_MUL_CONST && b2[2].kind == KNH_STAGE_ADD_CONST && b2[4].kind == KNH_STAGE_MUL_CONST);
+}
+static void plan_rejects_what_is_not_a_voice_chain() {
+  auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
+  (void)processor;
+  graph->plan_only = true;
+  bool threw = false;
+  try {
+    graph->edit([&](GraphEdit<float>& g) {
+      auto a = g.push(SinWt(100.)), b = g.push(SinWt(200.));
+      (a * b).out({0, 0}).to_graph_out();  // ring modulation of two oscillators: not a per-voice chain shape we fuse
+    });
+  } catch (const GraphError&) { threw = true; }
+  CHECK(threw);
+  auto [g2, p2] = AudioProcessor<float>::create(2, {64, 48000});
+  (void)p2;
+  g2->plan_only = true;
+  threw = false;
+  try {
+    g2->edit([&](GraphEdit<float>& g) { g.push(SinWt(1.)).param("no_such_param"); });
+  } catch (const GraphError& e) { threw = std::strstr(e.what(), "DescriptionNotFound") != nullptr; }
+  CHECK(threw);
+}
+static void time_and_seconds() {
+  // knaster_primitives/src/time.rs:474-503
+  CHECK(Seconds::from_samples(1, 44100).to_samples(88200) == 2);
+  CHECK(Seconds::from_samples(44100 * 3 + 1, 44100).to_samples(88200) == 3 * 88200 + 2);
+  CHECK(Seconds::from_samples(96000 * 3 + 8, 96000).to_samples(88200) == 3 * 88200 + 7);
+  CHECK((Seconds::from_samples(22050, 44100) == Seconds::from_secs_f64(0.5)));
+  // scheduling.rs:95-121 against the oracle's restatement, absolute and relative
+  for (uint64_t due : {0ull, 5ull, 63ull, 64ull, 200ull, 100000ull}) {
+    Time t = Time::at(Seconds::from_samples(due, 48000));
+    kno::Time ot = kno::Time::at(kno::Seconds::from_samples(due, 48000));
+    for (uint64_t clock = 0; clock < 400; clock += 64) CHECK(t.to_samples_until_due(64, 48000, clock) == ot.to_samples_until_due(64, 48000, clock));
+    Time r = Time::after(Seconds::from_samples(due, 48000));
+    kno::Time orr = kno::Time::after(kno::Seconds::from_samples(due, 48000));
+    for (int k = 0; k < 6; ++k) CHECK(r.to_samples_until_due(64, 48000, 0) == orr.to_samples_until_due(64, 48000, 0));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static void gpu_readme_example() {  // BASELINE.json configs[0] through the graph API
+  auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
+  graph->edit([&](GraphEdit<float>& g) {
+    auto s = g.push(SinWt(440.));
+    (s * 0.2).out({0, 0}).to_graph_out();
+  });
+  const auto& table = kno::sine_wavetable_f32();
+  uint32_t inc = kno::sat_u32(double(440.f) * (16384.0 * 65536.0 * (1.0 / 48000.0)));
+  uint32_t phase = 0;
+  for (int block = 0; block < 3; ++block) {
+    processor->run_without_inputs();
+    auto out = processor->output_block();
+    for (size_t i = 0; i < 64; ++i) {
+      float want = table[(phase >> 16) & 16383] * 0.2f;
+      CHECK(out.read(0, i) == want && out.read(1, i) == want);
+      phase += inc;
+    }
+  }
+  CHECK(processor->frame_clock() == 192);
+}
+
+struct C3Voice { double freq, gain, cutoff, q, atk, rel; };
+static std::vector<C3Voice> c3_voices(int n) {
+  kno::XOrShift32Rng rng(0x9E3779B9u);
+  std::vector<C3Voice> v;
+  for (int i = 0; i < n; ++i) {
+    double u[7];
+    for (double& x : u) x = static_cast<double>(rng.gen_f32());
+    v.push_back({55.0 * std::exp2(6.0 * u[0]), 1.0 / n, 200.0 + 7800.0 * u[1], 0.5 + 3.5 * u[2], 0.002 + 0.02 * u[3], 0.05 + 0.25 * u[4]});
+  }
+  return v;
+}
+static void gpu_voice_graph_matches_reference_shaped_graph() {
+  const int N = 300, B = 128;
+  auto voices = c3_voices(N);
+  auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+  std::vector<Sig<float>::Parameter> restart, release, cutoff;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (const auto& v : voices) {
+      auto s = g.push(SinWt(v.freq).wr_mul(v.gain));
+      auto f = g.push(SvfFilter(SvfFilterType::Low, v.cutoff, v.q, 0.).precise_timing(4));
+      auto e = g.push(EnvAsr(v.atk, v.rel));
+      ((s >> f) * e).out({0, 0}).to_graph_out();
+      restart.push_back(e.param("t_restart"));
+      release.push_back(e.param("t_release"));
+      cutoff.push_back(f.param("cutoff_freq"));
+    }
+  });
+  CHECK(graph->num_banks() == 1 && graph->bank(0).n_voices == N);
+  // the same patch as the reference would build it: one node per UGen, Add chain on both outputs
+  kno::Graph<float> ref(0, 2, B, 48000);
+  std::vector<kno::NodeKey> r_env, r_svf;
+  for (const auto& v : voices) {
+    auto s = ref.push(std::make_unique<kno::WrMath<float>>(std::make_unique<kno::SinWt<float>>(float(v.freq)), kno::WrOp::Mul, float(v.gain)));
+    auto f = ref.push(std::make_unique<kno::WrPreciseTiming<float>>(4, std::make_unique<kno::SvfFilter<float>>(kno::Low, float(v.cutoff), float(v.q), 0.f)));
+    auto e = ref.push(std::make_unique<kno::EnvAsr<float>>(float(v.atk), float(v.rel)));
+    ref.connect_to_node(s, 0, 0, f, false);
+    auto m = ref.math_nodes(f, 0, kno::MathOp::Mul, e, 0);
+    ref.connect_to_output(m, 0, 0, true);
+    ref.connect_to_output(m, 0, 1, true);
+    r_env.push_back(e);
+    r_svf.push_back(f);
+  }
+  ref.commit_changes();
+  std::vector<float> want(2 * B);
+  double worst = 0, peak = 0;
+  for (int block = 0; block < 8; ++block) {
+    if (block == 0)
+      for (int i = 0; i < N; ++i) { restart[i].trig(); ref.set(r_env[i], 3, kno::ParameterValue::Trig()); }
+    if (block == 2)  // sample-accurate: absolute time 2*B + 37 frames (Time::at), lands at in-block frame 37
+      for (int i = 0; i < N; i += 2) {
+        cutoff[i].set_at(500.0 + i, Time::at(Seconds::from_samples(2 * B + 37, 48000)));
+        ref.set_at(r_svf[i], 0, kno::ParameterValue::Flt(500.0 + i), kno::Time::at(kno::Seconds::from_samples(2 * B + 37, 48000)));
+      }
+    if (block == 3)  // scheduled well ahead: due in block 5 at frame 9
+      for (int i = 1; i < N; i += 2) {
+        cutoff[i].set_at(3000.0 - i, Time::at(Seconds::from_samples(5 * B + 9, 48000)));
+        ref.set_at(r_svf[i], 0, kno::ParameterValue::Flt(3000.0 - i), kno::Time::at(kno::Seconds::from_samples(5 * B + 9, 48000)));
+      }
+    if (block == 6)
+      for (int i = 0; i < N; ++i) { release[i].trig(); ref.set(r_env[i], 2, kno::ParameterValue::Trig()); }
+    processor->run_without_inputs();
+    ref.run({}, want.data());
+    auto out = processor->output_block();
+    for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < B; ++i) {
+        worst = std::max(worst, std::fabs(double(out.read(c, i)) - double(want[c * B + i])));
+        peak = std::max(peak, std::fabs(double(want[c * B + i])));
+      }
+  }
+  std::printf("  max |gpu - reference-shaped graph| = %.3g (peak %.3g)\n", worst, peak);
+  CHECK(worst <= 1e-5);   // tree fold vs the reference's left fold: the north-star tolerance
+  CHECK(peak > 1e-3);
+}
+static void gpu_run_blocks_equals_block_by_block() {
+  const int N = 130, B = 64;
+  auto voices = c3_voices(N);
+  std::vector<std::vector<float>> results;
+  for (int mode = 0; mode < 2; ++mode) {
+    auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+    std::vector<Sig<float>::Parameter> restart, freq;
+    graph->edit([&](GraphEdit<float>& g) {
+      for (const auto& v : voices) {
+        auto s = g.push(SinWt(v.freq).wr_mul(v.gain).precise_timing(2));
+        auto e = g.push(EnvAr(v.atk, v.rel * 0.1));
+        (e * s).out({0, 0}).to_graph_out();
+        restart.push_back(e.param("t_restart"));
+        freq.push_back(s.param("freq"));
+      }
+    });
+    for (int i = 0; i < N; ++i) {
+      restart[i].trig();
+      freq[i].set_at(voices[i].freq * 2, Time::at(Seconds::from_samples(3 * B + (i % B), 48000)));
+      restart[i].trig_at(Time::at(Seconds::from_samples(5 * B, 48000)));
+    }
+    std::vector<float> all;
+    if (mode == 0) {
+      for (int b = 0; b < 8; ++b) {
+        processor->run_without_inputs();
+        auto o = processor->output_block();
+        all.insert(all.end(), o.channel_as_slice(0), o.channel_as_slice(0) + 2 * B);
+      }
+    } else {
+      processor->run_blocks(8);
+      for (uint32_t b = 0; b < 8; ++b) {
+        auto o = processor->output_block(b);
+        all.insert(all.end(), o.channel_as_slice(0), o.channel_as_slice(0) + 2 * B);
+      }
+    }
+    results.push_back(all);
+  }
+  CHECK(results[0].size() == results[1].size());
+  CHECK(std::memcmp(results[0].data(), results[1].data(), results[0].size() * sizeof(float)) == 0);
+  float peak = 0;
+  for (float x : results[0]) peak = std::max(peak, std::fabs(x));
+  CHECK(peak > 1e-3f);
+}
+
+int main(int argc, char** argv) {
+  bool plan = false, gpu = false;
+  for (int i = 1; i < argc; ++i) {
+    plan = plan || !std::strcmp(argv[i], "--plan");
+    gpu = gpu || !std::strcmp(argv[i], "--gpu");
+  }
+  if (!plan && !gpu) plan = true;
+  (void)voice_freqs;
+  if (plan) {
+    RUN(plan_readme_example);
+    RUN(plan_groups_voices_by_chain_shape);
+    RUN(plan_rejects_what_is_not_a_voice_chain);
+    RUN(time_and_seconds);
+  }
+  if (gpu) {
+    if (knh_device_count() < 1) { std::printf("no gfx950 device\n"); return 2; }
+    RUN(gpu_readme_example);
+    RUN(gpu_voice_graph_matches_reference_shaped_graph);
+    RUN(gpu_run_blocks_equals_block_by_block);
+  }
+  std::printf("%s (%d failures)\n", g_fail ? "HOST MIRROR FAILED" : "HOST MIRROR PASSED", g_fail);
+  return g_fail ? 1 : 0;
+}

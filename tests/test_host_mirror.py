@@ -1,0 +1,31 @@
+"""The C++ host mirror of the reference's graph API (knaster_amd/host/knaster_host.hpp) over the C ABI:
+tests/cpp/host_mirror_test.cpp is built by `make -C tests/cpp` (also by __graft_entry__.build())."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin", "host_mirror_test")
+
+
+def _build(knh):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True, capture_output=True)
+    assert os.path.exists(BIN)
+
+
+def test_graph_api_plans_voice_banks(knh):
+    _build(knh)
+    res = subprocess.run([BIN, "--plan"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    for name in ("plan_readme_example", "plan_groups_voices_by_chain_shape", "plan_rejects_what_is_not_a_voice_chain", "time_and_seconds"):
+        assert f"ok   {name}" in res.stdout
+
+
+@pytest.mark.gpu
+def test_graph_api_end_to_end_on_gpu(knh):
+    _build(knh)
+    res = subprocess.run([BIN, "--gpu"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    for name in ("gpu_readme_example", "gpu_voice_graph_matches_reference_shaped_graph", "gpu_run_blocks_equals_block_by_block"):
+        assert f"ok   {name}" in res.stdout
