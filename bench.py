@@ -97,9 +97,11 @@ def main():
     voices = np.arange(nv, dtype=np.uint32)
 
     stream = torch.cuda.current_stream()
-    # the mixed stereo blocks of one batch: [REDUCE_EVERY][channels][block_size], resident in HBM
-    ring = torch.zeros((REDUCE_EVERY, w_all.out_channels, bs), dtype=torch.float32, device=dev)
-    ring_ptr = ring.data_ptr()
+    # the mixed stereo blocks of a launch: [REDUCE_EVERY][channels][block_size], resident in HBM; two of them so
+    # that the RCCL reduce of one launch overlaps the next launch's kernels
+    rings = [torch.zeros((REDUCE_EVERY, w_all.out_channels, bs), dtype=torch.float32, device=dev) for _ in range(2)]
+    ring = rings[0]
+    pending = [None, None]
     CYCLE = 64  # the note cycle of SURVEY.md 8(d): t_restart at block 0, t_release at block 32 of every 64 blocks
 
     def schedule(first_step: int, n: int):
@@ -111,18 +113,32 @@ def main():
             elif phase == CYCLE // 2:
                 bank.param_apply_many(voices, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER, block_offset=i)
 
+    launch_no = [0]
+
     def run_steps(first_step: int, n: int):
-        """n steps (blocks), REDUCE_EVERY blocks per launch; one RCCL reduce of the batch's stereo blocks."""
+        """n steps (blocks), REDUCE_EVERY blocks per launch; one RCCL reduce of each launch's stereo blocks."""
         done = 0
         while done < n:
             k = min(REDUCE_EVERY, n - done)
+            half = launch_no[0] & 1
+            launch_no[0] += 1
+            if pending[half] is not None:  # the reduce that last read this buffer must be done before it is rewritten
+                pending[half].wait()
+                pending[half] = None
             schedule(first_step + done, k)
-            bank.process_blocks_device(k, ring_ptr, stream.cuda_stream)
+            bank.process_blocks_device(k, rings[half].data_ptr(), stream.cuda_stream)
             if world > 1:
-                dist.reduce(ring[:k], dst=0, op=dist.ReduceOp.SUM)
+                pending[half] = dist.reduce(rings[half][:k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
             done += k
 
+    def drain():
+        for h in range(2):
+            if pending[h] is not None:
+                pending[h].wait()
+                pending[h] = None
+
     def fence():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -161,7 +177,7 @@ def main():
             bank.process_blocks(REDUCE_EVERY)
         host_rate = float(nv) * bs * ugens * REDUCE_EVERY * n_host / (time.perf_counter() - t1)
 
-    sane = bool(torch.isfinite(ring).all().item())
+    sane = bool(torch.isfinite(rings[0]).all().item() and torch.isfinite(rings[1]).all().item())
     traffic = None  # HBM bytes per launch from the committed PMC passes, if they were taken on this launch shape
     try:
         with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:

@@ -183,8 +183,12 @@ struct Svf {
     } else {
       const F v1 = r.a1 * r.ic1 + r.a2 * v3;
       const F v2 = r.ic2 + r.a2 * r.ic1 + r.a3 * v3;
-      r.ic1 = (F)2 * v1 - r.ic1;
-      r.ic2 = (F)2 * v2 - r.ic2;
+      // 2*v is exact in binary floating point, so round(2*v - ic) is the same value whether the
+      // product is rounded first or not: one FMA gives the reference's two-instruction result bit
+      // for bit (the only exception, |v| >= 2^127 where 2*v alone would overflow, is far outside
+      // any filter state that is not already garbage).
+      r.ic1 = mad<true>((F)2, v1, -r.ic1);
+      r.ic2 = mad<true>((F)2, v2, -r.ic2);
       return r.m0 * v0 + r.m1 * v1 + r.m2 * v2;
     }
   }

@@ -29,9 +29,19 @@ template <typename F, bool FMA, int BASE, typename... S> struct GroupChain<F, FM
 
 template <typename F> struct PipeTile { static constexpr int value = sizeof(F) == 4 ? 32 : 16; };  // samples per pipeline step
 
+// Edge tiles between stage groups: [edge][2 buffers][64 lanes][kEdgeStride] -- each lane's T samples are
+// contiguous and moved with 16-byte LDS accesses; the row padding (T + 16 B) keeps both ds_write_b128
+// (8-lane groups, 32 banks) and ds_read_b128 (16-lane groups, 64 banks) conflict-free.
+template <typename F> struct EdgeLayout {
+  static constexpr int T = PipeTile<F>::value;
+  static constexpr int VW = 16 / (int)sizeof(F);          // elements per 16-byte access
+  static constexpr int stride = T + VW;                   // elements per lane row
+  static constexpr int tile = 64 * stride;                // elements per buffer
+  typedef F Vec __attribute__((ext_vector_type(16 / sizeof(F))));
+};
 template <typename F> struct PipeShared {
   float* sine;
-  F* edge;  // [n_edges][2][T][64]
+  F* edge;  // [n_edges][2][64][EdgeLayout<F>::stride]
   F* mix;   // [2][TN][TS]
 };
 
@@ -89,9 +99,16 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
       apply_events_upto(base + n);
       F x[T];
       if (I > 0) {
-        const F* in = sh.edge + ((long)((I - 1) * 2 + (g & 1)) * T) * 64 + lane;
+        typedef typename EdgeLayout<F>::Vec Vec;
+        constexpr int VW = EdgeLayout<F>::VW;
+        const Vec* in = reinterpret_cast<const Vec*>(sh.edge + (long)((I - 1) * 2 + (g & 1)) * EdgeLayout<F>::tile +
+                                                     (long)lane * EdgeLayout<F>::stride);
 #pragma unroll
-        for (int j = 0; j < T; ++j) x[j] = in[j * 64];
+        for (int j = 0; j < T / VW; ++j) {
+          const Vec v = in[j];
+#pragma unroll
+          for (int k = 0; k < VW; ++k) x[j * VW + k] = v[k];
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < T; ++j) x[j] = (F)0;
@@ -106,9 +123,16 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
         }
       }
       if (I < NG - 1) {
-        F* out = sh.edge + ((long)(I * 2 + (g & 1)) * T) * 64 + lane;
+        typedef typename EdgeLayout<F>::Vec Vec;
+        constexpr int VW = EdgeLayout<F>::VW;
+        Vec* out = reinterpret_cast<Vec*>(sh.edge + (long)(I * 2 + (g & 1)) * EdgeLayout<F>::tile + (long)lane * EdgeLayout<F>::stride);
 #pragma unroll
-        for (int j = 0; j < T; ++j) out[j * 64] = x[j];
+        for (int j = 0; j < T / VW; ++j) {
+          Vec v;
+#pragma unroll
+          for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
+          out[j] = v;
+        }
       } else {  // last chain group: column write into the transposed mix tile
         const u32 rel = (u32)ti * T;
         const u32 qg = (u32)blk * (u32)qpb + rel / TN;  // global mix-tile counter: double-buffer parity
@@ -220,7 +244,7 @@ __global__ void __launch_bounds__((sizeof...(Gs) + 1) * 64) voice_pipe_kernel(Vo
   constexpr int TS = 68;
   constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
   __shared__ float sine[kSine ? 16384 : 1];
-  __shared__ __attribute__((aligned(16))) F edge[(NG > 1 ? NG - 1 : 1) * 2 * T * 64];
+  __shared__ __attribute__((aligned(16))) F edge[(NG > 1 ? NG - 1 : 1) * 2 * EdgeLayout<F>::tile];
   __shared__ __attribute__((aligned(16))) F mix[2 * TN * TS];
 
   const int lane = threadIdx.x & 63;
