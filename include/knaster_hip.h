@@ -37,7 +37,7 @@ typedef enum knh_status {
   KNH_OK = 0,
   KNH_ERR_INVALID_ARGUMENT = 1,  /* null handle, bad enum, wrong state            */
   KNH_ERR_OUT_OF_RANGE = 2,      /* voice/stage/param index out of bounds: no-op  */
-  KNH_ERR_UNSUPPORTED_CHAIN = 3, /* no fused kernel exists for this chain         */
+  KNH_ERR_UNSUPPORTED_CHAIN = 3, /* run-time fusion (hiprtc) of the chain failed   */
   KNH_ERR_DEVICE = 4,            /* a HIP call failed; see knh_last_error          */
   KNH_ERR_NOT_INITIALISED = 5,   /* process/param before knh_bank_init             */
   KNH_ERR_NO_DEVICE = 6,         /* no gfx950 device visible: the product has no CPU path */

@@ -14,8 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libknaster_hip.so")
-SOURCES = ["kernels.hip", "bank.hip"]
-HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "kernel_registry.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
+SOURCES = ["kernels.hip", "bank.hip", "jit.hip"]
+HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "kernel_registry.hpp", "jit.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
            os.path.join("..", "build.py")]
 FLAGS = [
     "--offload-arch=gfx950",
@@ -26,6 +26,7 @@ FLAGS = [
     "-shared",
     "-Wall",
     "-Wno-unused-value",
+    "-lhiprtc",
 ]
 
 
@@ -44,10 +45,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def write_jit_source() -> None:
+    """csrc/jit_source.inc: voice_chain.hpp as C++ raw string literals, embedded in the library so that
+    chains without a pre-built kernel can be fused at run time by hiprtc (jit.hip)."""
+    text = open(os.path.join(CSRC, "voice_chain.hpp")).read()
+    chunks = [text[i:i + 8000] for i in range(0, len(text), 8000)]
+    body = "\n".join('R"KNHJIT(' + c + ')KNHJIT"' for c in chunks) + "\n"
+    path = os.path.join(CSRC, "jit_source.inc")
+    if not os.path.exists(path) or open(path).read() != body:
+        with open(path, "w") as f:
+            f.write(body)
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 into csrc/libknaster_hip.so; returns its path."""
     if not force and not needs_build():
         return LIB
+    write_jit_source()
     cmd = [_hipcc(), *FLAGS, "-o", LIB + ".tmp", *SOURCES]
     if verbose:
         print("[knaster_amd.build]", " ".join(cmd), flush=True)

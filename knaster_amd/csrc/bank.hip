@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/knaster_hip.h"
+#include "jit.hpp"
 #include "kernel_registry.hpp"
 
 using knh_dev::Event;
@@ -191,6 +192,8 @@ struct Bank final : knh_bank {
   typedef typename knh_dev::WordOf<F>::type W;
   const knh::KernelEntry* entry = nullptr;
   const knh::PipeEntry* pipe = nullptr;  // wave-specialised variant, used when built for this chain
+  const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
+  std::string signature;
   uint32_t nv = 0;
   long stride = 0;
 
@@ -277,6 +280,11 @@ struct Bank final : knh_bank {
     if (desc.device >= 0) device = desc.device;
     else KNH_HIP(hipGetDevice(&device));
     KNH_HIP(hipSetDevice(device));
+    if (!entry) {  // no pre-built kernel: fuse this chain now
+      std::string why;
+      jit = knh::jit_voice_kernel(signature.c_str(), sizeof(F) == 8, desc.allow_fma != 0, &why);
+      if (!jit) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' failed: " + why);
+    }
     sample_rate = sr;
     block_size = bs;
     stride = (static_cast<long>(nv) + 63) / 64 * 64;
@@ -713,10 +721,12 @@ struct Bank final : knh_bank {
   }
   uint32_t partials_blocks = 1, out_blocks = 1;
   hipError_t launch_voice(const VoiceKernelArgs<float>& a, unsigned n_waves, hipStream_t s) {
+    if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
     if (pipe) return pipe->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
   hipError_t launch_voice(const VoiceKernelArgs<double>& a, unsigned n_waves, hipStream_t s) {
+    if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
     if (pipe) return pipe->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
@@ -794,13 +804,16 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
 }
 
 template <typename F>
-knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry) {
+knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const std::string& sig) {
   auto* b = new Bank<F>();
   b->desc = d;
   b->entry = entry;
-  {  // KNH_PIPELINE=0 forces the single-wave kernel (A/B measurements)
+  b->signature = sig;
+  {  // KNH_PIPELINE=0 forces the single-wave kernel (A/B measurements); KNH_JIT=1 forces run-time fusion
+    const char* jit_env = std::getenv("KNH_JIT");
+    if (jit_env && jit_env[0] == '1') b->entry = nullptr;
     const char* env = std::getenv("KNH_PIPELINE");
-    if (!(env && env[0] == '0')) b->pipe = knh::find_pipe(entry->signature);
+    if (b->entry && !(env && env[0] == '0')) b->pipe = knh::find_pipe(sig.c_str());
   }
   b->nv = d.n_voices;
   int slot = 0, pbase = 0;
@@ -873,12 +886,9 @@ int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank) {
   std::string sig, why;
   int rc = build_signature(desc->stages, desc->n_stages, &sig, &why);
   if (rc != KNH_OK) { g_create_error = why; return rc; }
+  // a chain without a pre-built kernel is fused at knh_bank_init time (hiprtc); entry == nullptr marks it
   const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
-  if (!entry) {
-    g_create_error = "no pre-built fused kernel for chain signature '" + sig + "'";
-    return KNH_ERR_UNSUPPORTED_CHAIN;
-  }
-  *out_bank = desc->sample_type == KNH_F64 ? make_bank<double>(*desc, entry) : make_bank<float>(*desc, entry);
+  *out_bank = desc->sample_type == KNH_F64 ? make_bank<double>(*desc, entry, sig) : make_bank<float>(*desc, entry, sig);
   return KNH_OK;
 }
 

@@ -173,3 +173,43 @@ def test_mix_is_linear_in_the_voice_set(knh):
         a = halves[0].process_block()[0]
         b = halves[1].process_block()[0]
         assert_bit_equal(f, a + b, "mix(A u B) == mix(A) + mix(B)")
+
+
+def test_runtime_fused_chain_matches_oracle(knh, oracle):
+    """A chain with no pre-built kernel is fused at init time by hiprtc from the embedded device header."""
+    from knaster_amd.bank import Stage
+
+    n = 100
+    p = configs.voice_parameters(n)
+    w = configs.Workload("jit", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_ONEPOLE_HPF), Stage(L.STAGE_ONEPOLE_LPF), Stage(L.STAGE_SVF),
+                                 Stage(L.STAGE_MUL_ENV_AR), Stage(L.STAGE_DIV_CONST), Stage(L.STAGE_WR_ADD)], n, 96, L.F32, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 2: p["cutoff"].reshape(n, 1),
+              3: np.stack([np.full(n, float(L.SVF_BAND)), p["cutoff"] * 0.5, p["q"], np.zeros(n)], axis=1),
+              4: np.stack([p["attack"] * 0.05, p["release"] * 0.01], axis=1), 5: np.full((n, 1), 3.0), 6: np.full((n, 1), 0.001)}
+    g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    o = make_oracle(oracle, w)
+    v = np.arange(n, dtype=np.uint32)
+    for block in range(5):
+        for bank in (g, o):
+            if block in (0, 3):
+                bank.param_apply_many(v, 4, 2, L.VALUE_TRIGGER)
+            if block == 2:
+                bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, p["cutoff"] * 0.1)
+        g_out, g_voices, _ = g.process_block_voices()
+        o_out, o_voices, _, _ = o.process_block()
+        assert_bit_equal(g_voices, o_voices, f"block {block} voices")
+        assert_bit_equal(g_out, o_out, f"block {block} mix")
+    assert np.max(np.abs(g_voices)) > 1e-4
+
+
+def test_runtime_fused_kernel_equals_prebuilt_kernel(knh, monkeypatch):
+    w = configs.config("C3", n_voices=500, block_size=256)
+    outs = []
+    for jit in ("0", "1"):
+        monkeypatch.setenv("KNH_JIT", jit)
+        monkeypatch.setenv("KNH_PIPELINE", "0")
+        g = make_gpu(knh, w)
+        fire_all(g, w.n_voices, *w.restart)
+        outs.append(g.process_blocks(3)[0])
+        g.close()
+    assert_bit_equal(outs[0], outs[1], "hiprtc-built vs hipcc-built kernel")
