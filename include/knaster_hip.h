@@ -272,6 +272,9 @@ int32_t knh_bank_param_apply_many_at(knh_bank* bank, uint32_t block_offset, size
 /* Per-voice done frame of the last processed block (UGenFlags::done,
  * ugen.rs:169-175): done_frames[v] = frame in block, or UINT32_MAX. */
 int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames);
+/* Diagnostics: 16 device words of the last launch (0,1: the done/running summary; 4..8: per-role busy
+ * cycles per tile when the library was built with -DKNH_DAG_STAMPS, zero otherwise). */
+int32_t knh_bank_debug_words(knh_bank* bank, uint32_t* out16);
 /* Wait for everything enqueued by *_device calls. */
 int32_t knh_bank_synchronize(knh_bank* bank);
 

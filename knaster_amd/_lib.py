@@ -78,6 +78,7 @@ PROTOTYPES = {
     "knh_bank_param_apply_many_at": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "knh_bank_read_done_frames": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "knh_bank_debug_words": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "knh_bank_synchronize": (C.c_int32, [C.c_void_p]),
     "knh_bank_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
     "knh_bank_timing_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -193,6 +193,11 @@ class VoiceBank:
         self._check(self._lib.knh_bank_read_done_frames(self._h, d.ctypes.data_as(C.c_void_p)))
         return d
 
+    def debug_words(self) -> np.ndarray:
+        d = np.zeros(16, dtype=np.uint32)
+        self._check(self._lib.knh_bank_debug_words(self._h, d.ctypes.data_as(C.c_void_p)))
+        return d
+
     def synchronize(self):
         self._check(self._lib.knh_bank_synchronize(self._h))
 

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libknaster_hip.so")
 SOURCES = ["kernels.hip", "bank.hip", "jit.hip"]
-HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "kernel_registry.hpp", "jit.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
+HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
            os.path.join("..", "build.py")]
 FLAGS = [
     "--offload-arch=gfx950",
@@ -62,7 +62,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     write_jit_source()
-    cmd = [_hipcc(), *FLAGS, "-o", LIB + ".tmp", *SOURCES]
+    extra = ["-DKNH_DAG_STAMPS"] if os.environ.get("KNH_BUILD_STAMPS") == "1" else []  # diagnostic build only
+    cmd = [_hipcc(), *FLAGS, *extra, "-o", LIB + ".tmp", *SOURCES]
     if verbose:
         print("[knaster_amd.build]", " ".join(cmd), flush=True)
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

@@ -166,6 +166,7 @@ struct knh_bank {
                       void* voices_host, uint32_t* out_flags, void* stream, bool sync) = 0;
   virtual int read_done_frames(uint32_t* out) = 0;
   virtual int synchronize() = 0;
+  virtual int debug_read(uint32_t* out16) = 0;
   virtual int timing_reset(int enable) = 0;
   virtual int timing_read(double* ms, uint64_t* launches) = 0;
 
@@ -192,6 +193,7 @@ struct Bank final : knh_bank {
   typedef typename knh_dev::WordOf<F>::type W;
   const knh::KernelEntry* entry = nullptr;
   const knh::PipeEntry* pipe = nullptr;  // wave-specialised variant, used when built for this chain
+  const knh::DagEntry* dag = nullptr;    // five-role variant (f32, source -> SVF -> x*env -> post chains)
   const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
   std::string signature;
   uint32_t nv = 0;
@@ -376,7 +378,8 @@ struct Bank final : knh_bank {
     KNH_HIP(hipMemset(d_out, 0, desc.out_channels * bs * sizeof(F)));
     KNH_HIP(hipMalloc(&d_done, static_cast<size_t>(nv) * sizeof(uint32_t)));
     KNH_HIP(hipMemset(d_done, 0xFF, static_cast<size_t>(nv) * sizeof(uint32_t)));
-    KNH_HIP(hipMalloc(&d_flags, 2 * sizeof(uint32_t)));
+    KNH_HIP(hipMalloc(&d_flags, 16 * sizeof(uint32_t)));
+    KNH_HIP(hipMemset(d_flags, 0, 16 * sizeof(uint32_t)));
     KNH_HIP(hipHostMalloc(&h_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
     KNH_HIP(hipHostMalloc(&h_out, desc.out_channels * bs * sizeof(F) + 2 * sizeof(uint32_t)));
     KNH_HIP(hipEventCreateWithFlags(&staging_free, hipEventDisableTiming));
@@ -722,6 +725,7 @@ struct Bank final : knh_bank {
   uint32_t partials_blocks = 1, out_blocks = 1;
   hipError_t launch_voice(const VoiceKernelArgs<float>& a, unsigned n_waves, hipStream_t s) {
     if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
+    if (dag) return dag->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (pipe) return pipe->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
@@ -743,6 +747,13 @@ struct Bank final : knh_bank {
     KNH_HIP(hipSetDevice(device));
     KNH_HIP(hipStreamSynchronize(own_stream));
     KNH_HIP(hipMemcpy(out, d_done, static_cast<size_t>(nv) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return KNH_OK;
+  }
+  int debug_read(uint32_t* out16) override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    KNH_HIP(hipSetDevice(device));
+    KNH_HIP(hipDeviceSynchronize());
+    KNH_HIP(hipMemcpy(out16, d_flags, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return KNH_OK;
   }
   int synchronize() override {
@@ -812,8 +823,12 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
   {  // KNH_PIPELINE=0 forces the single-wave kernel (A/B measurements); KNH_JIT=1 forces run-time fusion
     const char* jit_env = std::getenv("KNH_JIT");
     if (jit_env && jit_env[0] == '1') b->entry = nullptr;
+    // KNH_PIPELINE: 0 = single-wave kernel, 1 (default) = linear wave pipeline, 2 = five-role pipeline
+    // (voice_dag.hpp; bit-identical, measured 5-8 % slower than level 1 on MI355X, kept for experiments)
     const char* env = std::getenv("KNH_PIPELINE");
-    if (b->entry && !(env && env[0] == '0')) b->pipe = knh::find_pipe(sig.c_str());
+    const int level = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : 1;
+    if (b->entry && level >= 1) b->pipe = knh::find_pipe(sig.c_str());
+    if (b->entry && level >= 2 && d.sample_type == KNH_F32) b->dag = knh::find_dag(sig.c_str());
   }
   b->nv = d.n_voices;
   int slot = 0, pbase = 0;
@@ -978,6 +993,10 @@ int32_t knh_bank_param_apply_many_at(knh_bank* bank, uint32_t block_offset, size
 int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   return bank->read_done_frames(done_frames);
+}
+int32_t knh_bank_debug_words(knh_bank* bank, uint32_t* out16) {
+  if (!bank || !out16) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->debug_read(out16);
 }
 int32_t knh_bank_synchronize(knh_bank* bank) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;

@@ -28,6 +28,12 @@ struct PipeEntry {
   VoiceLaunchFn<double> f64[2];
 };
 const PipeEntry* find_pipe(const char* signature);
+// Five-role (dependence-cut) pipeline for source -> SVF -> x*envelope -> post chains, f32 banks (voice_dag.hpp).
+struct DagEntry {
+  const char* signature;
+  VoiceLaunchFn<float> f32[2];
+};
+const DagEntry* find_dag(const char* signature);
 
 const KernelEntry* find_kernel(const char* signature);
 int kernel_count();

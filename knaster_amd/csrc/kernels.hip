@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "kernel_registry.hpp"
+#include "voice_dag.hpp"
 #include "voice_pipe.hpp"
 
 namespace knh {
@@ -74,6 +75,26 @@ static const PipeEntry kPipes[] = {
 };
 const PipeEntry* find_pipe(const char* signature) {
   for (const PipeEntry& e : kPipes)
+    if (std::strcmp(e.signature, signature) == 0) return &e;
+  return nullptr;
+}
+
+template <bool FMA, bool AR, typename SRC, typename POST>
+static hipError_t launch_dag(const VoiceKernelArgs<float>& args, unsigned n_wavefronts, hipStream_t stream) {
+  if (n_wavefronts == 0) return hipSuccess;
+  hipLaunchKernelGGL((voice_dag_kernel<float, FMA, AR, SRC, POST>), dim3(n_wavefronts), dim3(320), 0, stream, args);
+  return hipGetLastError();
+}
+#define KNH_DAG(sig, ar, src, post) {sig, {launch_dag<false, ar, src, post>, launch_dag<true, ar, src, post>}}
+typedef Group<> G_none;
+static const DagEntry kDags[] = {
+    KNH_DAG("WmSA", false, G_Wm, G_none),  // C3
+    KNH_DAG("WSA", false, G_W, G_none),
+    KNH_DAG("WSAm", false, G_W, G_m),
+    KNH_DAG("NSAm", false, G_N, G_m),
+};
+const DagEntry* find_dag(const char* signature) {
+  for (const DagEntry& e : kDags)
     if (std::strcmp(e.signature, signature) == 0) return &e;
   return nullptr;
 }

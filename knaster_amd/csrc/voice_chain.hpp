@@ -263,8 +263,9 @@ struct MulEnvT {
   static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
     s[0] = (W)r.state; s[st] = f_to_word(r.t); s[4 * st] = f_to_word(r.scale);
   }
-  template <typename F, bool FMA>
-  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32 frame, u32& done_frame) {
+  // One sample of the envelope itself (EnvAsr/EnvAr::next_sample, envelopes.rs:52-81 / 205-233).
+  template <typename F>
+  static __device__ __forceinline__ F env_next(Regs<F>& r, u32 frame, u32& done_frame) {
     const u32 st = r.state;
     const F t = r.t;
     // powi(3) = t*(t*t) (num-traits pow by squaring); then * release_scale
@@ -287,55 +288,62 @@ struct MulEnvT {
       // (envelopes.rs:158-162 under precise_timing.rs:104-110)
       if (nt <= (F)0) { r.state = 0u; r.t = (F)0; done_frame = frame - r.seg; }
     }
-    return x * env;
+    return env;
   }
-  // T samples at once.  State transitions are rare (at most three per note), so the tile is first
-  // evaluated branch-free under the assumption that no lane changes state inside it; every sample's
-  // transition test is still evaluated, and if any lane would have changed state the tile is redone
-  // with the exact per-sample state machine from the saved registers.  Same values either way.
-  template <typename F, bool FMA, int T>
-  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32 frame, u32& done_frame) {
+    return x * env_next<F>(r, frame, done_frame);
+  }
+  // T envelope samples at once.  State transitions are rare (at most three per note), so the tile is
+  // first evaluated branch-free under the assumption that no lane changes state inside it; every
+  // sample's transition test is still evaluated, and if any lane would have changed state the tile is
+  // redone with the exact per-sample state machine from the untouched registers.  Same values either way.
+  template <typename F, int T>
+  static __device__ __forceinline__ void env_tile(Regs<F>& r, F (&e)[T], u32 frame0, u32& done_frame) {
     const u32 st = r.state;
     const bool isA = st == 1u, isR = st == 3u;
     const bool anyA = __builtin_amdgcn_ballot_w64(isA) != 0, anyR = __builtin_amdgcn_ballot_w64(isR) != 0;
     const F konst = st == 2u ? (F)1 : (F)0;
     if (!anyA && !anyR) {  // every lane Sustaining or Stopped
 #pragma unroll
-      for (int j = 0; j < T; ++j) x[j] = x[j] * konst;
+      for (int j = 0; j < T; ++j) e[j] = konst;
       return;
     }
     const F step = isA ? r.ar : (isR ? -r.rr : (F)0);  // t - rr == t + (-rr) exactly
-    F y[T];
     F t = r.t;
     bool hit_hi = false, hit_lo = false;
     if (!anyR) {
 #pragma unroll
       for (int j = 0; j < T; ++j) {
-        const F env = isA ? t : konst;
+        e[j] = isA ? t : konst;
         t = t + step;
         hit_hi |= t >= (F)1;
-        y[j] = x[j] * env;
       }
     } else {
       const F scale = r.scale;
 #pragma unroll
       for (int j = 0; j < T; ++j) {
         const F cube = (t * (t * t)) * scale;
-        const F env = isA ? t : (isR ? cube : konst);
+        e[j] = isA ? t : (isR ? cube : konst);
         t = t + step;
         hit_hi |= t >= (F)1;
         hit_lo |= t <= (F)0;
-        y[j] = x[j] * env;
       }
     }
     const bool hit = (isA && hit_hi) || (isR && hit_lo);
     if (__builtin_amdgcn_ballot_w64(hit) == 0) {
       r.t = t;
-#pragma unroll
-      for (int j = 0; j < T; ++j) x[j] = y[j];
       return;
     }
-    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+#pragma unroll
+    for (int j = 0; j < T; ++j) e[j] = env_next<F>(r, frame0 + j, done_frame);
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx&, u32 frame0, u32& done_frame) {
+    F e[T];
+    env_tile<F, T>(r, e, frame0, done_frame);
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = x[j] * e[j];
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 frame) {

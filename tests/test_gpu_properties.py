@@ -37,7 +37,7 @@ def c3_script(w, block, bank, offset=0):
         bank.param_apply_many(v[1::2], 2, 0, L.VALUE_FLOAT, p["cutoff"][1::2] * 0.5, None, None, block_offset=offset)
 
 
-@pytest.mark.parametrize("pipeline", ["0", "1"])
+@pytest.mark.parametrize("pipeline", ["0", "1", "2"])
 def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pipeline):
     """16384 voices x 512 frames: (a) the tree mix equals the documented fold of the per-voice signals,
     (b) the left-fold mix equals the serial fold, (c) 96 sampled voices equal the oracle run on just
@@ -71,9 +71,10 @@ def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pip
 
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C4", 300, 100), ("C5", 260, 128), ("C2", 200, 48)])
 def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
+    """KNH_PIPELINE 0 = one wavefront per 64 voices, 1 = linear wave pipeline, 2 = five-role pipeline where built."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
     outs = {}
-    for pipeline in ("0", "1"):
+    for pipeline in ("0", "1", "2"):
         monkeypatch.setenv("KNH_PIPELINE", pipeline)
         g = make_gpu(knh, w)
         res = []
@@ -88,13 +89,14 @@ def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_vo
             res.append((out, voices, flags, g.read_done_frames()))
         outs[pipeline] = res
         g.close()
-    for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["0"], outs["1"]):
-        assert_bit_equal(v0, v1, "per-voice")
-        assert_bit_equal(o0, o1, "mix")
-        assert f0 == f1 and np.array_equal(d0, d1)
+    for other in ("1", "2"):
+        for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["0"], outs[other]):
+            assert_bit_equal(v0, v1, f"per-voice, pipeline {other}")
+            assert_bit_equal(o0, o1, f"mix, pipeline {other}")
+            assert f0 == f1 and np.array_equal(d0, d1)
 
 
-@pytest.mark.parametrize("pipeline", ["0", "1"])
+@pytest.mark.parametrize("pipeline", ["0", "1", "2"])
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 700, 512), ("C3", 130, 100), ("C5", 200, 128)])
 def test_many_blocks_per_launch_equals_block_by_block(knh, monkeypatch, pipeline, name, n_voices, block_size):
     monkeypatch.setenv("KNH_PIPELINE", pipeline)
@@ -130,7 +132,7 @@ def test_many_blocks_per_launch_equals_block_by_block(knh, monkeypatch, pipeline
     assert_bit_equal(np.concatenate([first, second]), multi, "3 + 4 blocks")
 
 
-@pytest.mark.parametrize("pipeline", ["0", "1"])
+@pytest.mark.parametrize("pipeline", ["0", "1", "2"])
 def test_split_block_equals_whole_block(knh, monkeypatch, pipeline):
     """ctx.block partial processing (BlockMetadata::make_partial, ugen.rs:87-93): frames [0,k) then [k,B)."""
     monkeypatch.setenv("KNH_PIPELINE", pipeline)
