@@ -194,6 +194,8 @@ struct Bank final : knh_bank {
   const knh::KernelEntry* entry = nullptr;
   const knh::PipeEntry* pipe = nullptr;  // wave-specialised variant, used when built for this chain
   const knh::DagEntry* dag = nullptr;    // five-role variant (f32, source -> SVF -> x*env -> post chains)
+  const knh::WideEntry* wide = nullptr;  // 4/8 voice groups per workgroup, for banks larger than the chip's SIMD count
+  int wide_waves = 0;                    // 0 = not used, else 4 or 8
   const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
   std::string signature;
   uint32_t nv = 0;
@@ -725,12 +727,16 @@ struct Bank final : knh_bank {
   uint32_t partials_blocks = 1, out_blocks = 1;
   hipError_t launch_voice(const VoiceKernelArgs<float>& a, unsigned n_waves, hipStream_t s) {
     if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
+    if (wide_waves == 4) return wide->f32_w4[desc.allow_fma ? 1 : 0](a, n_waves, s);
+    if (wide_waves == 8) return wide->f32_w8[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (dag) return dag->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (pipe) return pipe->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
   hipError_t launch_voice(const VoiceKernelArgs<double>& a, unsigned n_waves, hipStream_t s) {
     if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
+    if (wide_waves == 4) return wide->f64_w4[desc.allow_fma ? 1 : 0](a, n_waves, s);
+    if (wide_waves == 8) return wide->f64_w8[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (pipe) return pipe->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
@@ -829,6 +835,18 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
     const int level = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : 1;
     if (b->entry && level >= 1) b->pipe = knh::find_pipe(sig.c_str());
     if (b->entry && level >= 2 && d.sample_type == KNH_F32) b->dag = knh::find_dag(sig.c_str());
+    // Occupancy regime: the wave pipeline minimises latency when every 64-voice group can have a CU to
+    // itself (<= ~1.5 groups per CU); beyond that throughput wins and the groups are packed 4 or 8 to a
+    // workgroup (one or two wavefronts per SIMD) sharing one staged sine table.  KNH_WIDE=0/4/8 overrides.
+    b->wide = b->entry ? knh::find_wide(sig.c_str()) : nullptr;
+    if (b->wide) {
+      const unsigned groups = (d.n_voices + 63u) / 64u;
+      int ww = groups <= 384 && b->pipe ? 0 : (groups <= 1024 ? 4 : 8);
+      if (!b->pipe && groups <= 256) ww = 0;
+      const char* wenv = std::getenv("KNH_WIDE");
+      if (wenv) ww = std::atoi(wenv);
+      if (ww == 4 || ww == 8) b->wide_waves = ww;
+    }
   }
   b->nv = d.n_voices;
   int slot = 0, pbase = 0;

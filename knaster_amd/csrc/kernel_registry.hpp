@@ -34,6 +34,13 @@ struct DagEntry {
   VoiceLaunchFn<float> f32[2];
 };
 const DagEntry* find_dag(const char* signature);
+// Many-wave builds of the single-wave kernel (4 or 8 voice groups per workgroup) for large banks.
+struct WideEntry {
+  const char* signature;
+  VoiceLaunchFn<float> f32_w4[2], f32_w8[2];
+  VoiceLaunchFn<double> f64_w4[2], f64_w8[2];
+};
+const WideEntry* find_wide(const char* signature);
 
 const KernelEntry* find_kernel(const char* signature);
 int kernel_count();

@@ -99,6 +99,32 @@ const DagEntry* find_dag(const char* signature) {
   return nullptr;
 }
 
+template <typename F, bool FMA, int WAVES, typename... S>
+static hipError_t launch_wide(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
+  if (n_wavefronts == 0) return hipSuccess;
+  hipLaunchKernelGGL((voice_kernel<F, FMA, WAVES, S...>), dim3((n_wavefronts + WAVES - 1) / WAVES), dim3(WAVES * 64), 0, stream, args);
+  return hipGetLastError();
+}
+#define KNH_WIDE(sig, ...)                                                                            \
+  {sig,                                                                                               \
+   {launch_wide<float, false, 4, __VA_ARGS__>, launch_wide<float, true, 4, __VA_ARGS__>},            \
+   {launch_wide<float, false, 8, __VA_ARGS__>, launch_wide<float, true, 8, __VA_ARGS__>},            \
+   {launch_wide<double, false, 4, __VA_ARGS__>, launch_wide<double, true, 4, __VA_ARGS__>},          \
+   {launch_wide<double, false, 8, __VA_ARGS__>, launch_wide<double, true, 8, __VA_ARGS__>}}
+static const WideEntry kWides[] = {
+    KNH_WIDE("Wm", SinWt, MulVal),
+    KNH_WIDE("Nm", SinNum, MulVal),
+    KNH_WIDE("WmSA", SinWt, MulVal, Svf, MulAsr),
+    KNH_WIDE("WSAm", SinWt, Svf, MulAsr, MulVal),
+    KNH_WIDE("WmE", SinWt, MulVal, MulAr),
+    KNH_WIDE("WmaRm", SinWt, MulVal, AddVal, SinWtAr, MulVal),
+};
+const WideEntry* find_wide(const char* signature) {
+  for (const WideEntry& e : kWides)
+    if (std::strcmp(e.signature, signature) == 0) return &e;
+  return nullptr;
+}
+
 const KernelEntry* find_kernel(const char* signature) {
   for (const KernelEntry& e : kEntries)
     if (std::strcmp(e.signature, signature) == 0) return &e;

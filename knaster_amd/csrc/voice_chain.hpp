@@ -475,12 +475,15 @@ struct VoiceKernelArgs {
 constexpr int kWave = 64;
 constexpr int kTile = 8;  // samples evaluated stage-by-stage in registers
 
-// LDS: sine table (64 KiB, only if a stage uses it) + one [TN][65] transpose tile per wave.
+// LDS: sine table (64 KiB, only if a stage uses it) + one [TN][68] transpose tile per wave.
+// WAVES = wavefronts (64-voice groups) per workgroup sharing the table: 1 for small banks, 4 or 8 when
+// the bank has more 64-voice groups than the chip has SIMDs to give each its own (throughput regime).
 template <typename F, bool FMA, int WAVES, typename... S>
 __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a) {
   typedef Chain<F, FMA, 0, S...> ChainT;
   typedef typename WordOf<F>::type W;
-  constexpr int TN = sizeof(F) == 4 ? 64 : 32;  // frames per reduce tile
+  // frames per reduce tile: sized so that WAVES tiles + the sine table fit the CU's 160 KiB of LDS
+  constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 8 ? 2 : 1);
   constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
                                                 // writes (ds_write_b32) and row reads (ds_read_b128)
   __shared__ float sine[ChainT::kUsesSine ? 16384 : 1];

@@ -215,3 +215,33 @@ def test_runtime_fused_kernel_equals_prebuilt_kernel(knh, monkeypatch):
         outs.append(g.process_blocks(3)[0])
         g.close()
     assert_bit_equal(outs[0], outs[1], "hiprtc-built vs hipcc-built kernel")
+
+
+@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1500, 512), ("C4", 700, 100), ("C5", 520, 128), ("C2", 300, 48)])
+def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
+    """KNH_WIDE=4/8: four or eight 64-voice groups per workgroup (the build used for very large banks)."""
+    w = configs.config(name, n_voices=n_voices, block_size=block_size)
+    outs = {}
+    for wide in ("0", "4", "8"):
+        monkeypatch.setenv("KNH_PIPELINE", "0")
+        monkeypatch.setenv("KNH_WIDE", wide)
+        g = make_gpu(knh, w)
+        res = []
+        for block in range(5):
+            if name in ("C3", "C4"):
+                c3_script(w, block, g)
+            if name == "C5":
+                e = configs.c5_events(w, block)
+                if e is not None:
+                    g.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5])
+            out, voices, flags = g.process_block_voices()
+            res.append((out, voices, flags, g.read_done_frames()))
+        res.append((g.process_blocks(3)[0], None, 0, None))
+        outs[wide] = res
+        g.close()
+    for other in ("4", "8"):
+        for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["0"], outs[other]):
+            assert_bit_equal(o0, o1, f"mix, wide {other}")
+            if v0 is not None:
+                assert_bit_equal(v0, v1, f"per-voice, wide {other}")
+                assert f0 == f1 and np.array_equal(d0, d1)

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Times every BASELINE.json workload on one GPU (not the headline bench; see bench.py).
+Prints one JSON line per config: UGen-samples/s with outputs left in HBM, 32 blocks per launch."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import knaster_amd
+from knaster_amd import _lib as L, configs
+
+
+def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
+    w = configs.config(name, n_voices=n_voices)
+    b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE, -1, allow_fma)
+    for s, a in w.ctor.items():
+        b.set_ctor_args(s, a)
+    b.init(configs.SAMPLE_RATE, w.block_size)
+    v = np.arange(w.n_voices, dtype=np.uint32)
+    if w.restart:
+        b.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+    step = [0]
+
+    def events(k):
+        for i in range(k):
+            if name == "C5":
+                e = configs.c5_events(w, step[0] + i)
+                if e is not None:
+                    b.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5], block_offset=i)
+            elif w.release and (step[0] + i) % 64 == 32:
+                b.param_apply_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER, block_offset=i)
+            elif w.restart and (step[0] + i) % 64 == 0 and step[0] + i > 0:
+                b.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER, block_offset=i)
+        step[0] += k
+    events(blocks)
+    b.process_blocks_device(blocks)
+    b.synchronize()
+    b.timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        events(blocks)
+        b.process_blocks_device(blocks)
+    b.synchronize()
+    dt = time.perf_counter() - t0
+    kms, n = b.timing_read()
+    ugens = knaster_amd.chain_ugen_count(w.stages)
+    work = float(w.n_voices) * w.block_size * ugens * blocks * launches
+    rd, wr = b.algorithmic_bytes_per_voice_block()
+    print(json.dumps({"config": name, "voices": w.n_voices, "block_size": w.block_size, "sample_type": "f64" if w.sample_type else "f32",
+                      "ugens_per_voice": ugens, "allow_fma": allow_fma, "ugen_samples_per_s": work / dt,
+                      "kernel_only_ugen_samples_per_s": work / (kms * 1e-3), "us_per_block_kernel": kms * 1e3 / (n * blocks),
+                      "hbm_algorithmic_GBps": (rd + wr) * w.n_voices * blocks * n / (kms * 1e-3) / 1e9}), flush=True)
+    b.close()
+
+
+if __name__ == "__main__":
+    run("C1")
+    run("C2")
+    run("C3")
+    run("C3", allow_fma=True)
+    run("C3", n_voices=65536)
+    run("C3", n_voices=262144, launches=4)
+    run("C4", n_voices=8192)
+    run("C4")
+    run("C5")
