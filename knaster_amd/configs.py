@@ -31,7 +31,17 @@ def xorshift32_stream(seed: int, n: int) -> np.ndarray:
     return out
 
 
+_PARAM_CACHE: Dict[tuple, Dict[str, np.ndarray]] = {}
+
+
 def voice_parameters(n_voices: int, seed: int = SEED) -> Dict[str, np.ndarray]:
+    key = (n_voices, seed)
+    if key not in _PARAM_CACHE:
+        _PARAM_CACHE[key] = _voice_parameters(n_voices, seed)
+    return {k: v.copy() for k, v in _PARAM_CACHE[key].items()}
+
+
+def _voice_parameters(n_voices: int, seed: int) -> Dict[str, np.ndarray]:
     raw = xorshift32_stream(seed, n_voices * 7).reshape(n_voices, 7)
     u = (raw.astype(np.float32) / np.float32(0xFFFFFFFF)).astype(np.float64)  # gen_f32
     return {

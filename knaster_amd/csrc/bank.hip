@@ -18,7 +18,6 @@
 #include <cstring>
 #include <memory>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "../../include/knaster_hip.h"
@@ -212,7 +211,9 @@ struct Bank final : knh_bank {
   double f2pi = 0.0;
   // WrPreciseTiming state: next_delay per (param, voice) for wrapped stages; queues keyed by voice*n_stages+stage
   std::vector<uint16_t> next_delay;  // [n_params_total][nv], allocated only if some stage is wrapped
-  std::unordered_map<uint64_t, std::vector<QueuedChange>> queues;
+  // WrPreciseTiming::waiting_changes of every wrapped node, flattened: (key = voice * n_stages + stage, change)
+  // in arrival order; grouped per node when the block is assembled.
+  std::vector<std::pair<uint64_t, QueuedChange>> queued;
   // Device state patches of the next launch, in application order: block 0's immediate changes as they
   // arrive, then (at process time) block 0's queued changes, block 1's immediate ones, ...
   std::vector<HostEvent> pending;
@@ -424,10 +425,8 @@ struct Bank final : knh_bank {
       return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
     if (S.dcpb > 0) {  // WrPreciseTiming::param_apply, precise_timing.rs:126-135
       uint16_t d = next_delay[static_cast<size_t>(S.param_base + param) * nv + voice];
-      if (d != 0) {
-        auto& q = queues[static_cast<uint64_t>(voice) * stages.size() + stage];
-        if (q.size() < S.dcpb) q.push_back(QueuedChange{d, param, kind, f, i});
-        else warn("Not enough space for scheduled changes in WrPreciseTiming, change ignored");
+      if (d != 0) {  // capacity (DELAYED_CHANGES_PER_BLOCK) is enforced per node when the block is assembled
+        queued.emplace_back(static_cast<uint64_t>(voice) * stages.size() + stage, QueuedChange{d, param, kind, f, i});
         return KNH_OK;
       }
     }
@@ -514,15 +513,28 @@ struct Bank final : knh_bank {
   // WrPreciseTiming::process_block's change loop (precise_timing.rs:65-114) for every wrapped node
   // with queued changes: FIFO with head-of-line blocking, changes past the processed range are lost.
   void resolve_queues(uint32_t frame_begin, uint32_t frame_end) {  // block-relative range; events get frame_base added
-    for (auto& kv : queues) {
-      std::vector<QueuedChange>& q = kv.second;
-      if (q.empty()) continue;
-      const uint32_t voice = static_cast<uint32_t>(kv.first / stages.size());
-      const uint32_t stage = static_cast<uint32_t>(kv.first % stages.size());
-      uint32_t at = frame_begin;
-      for (const QueuedChange& c : q) {
+    if (queued.empty()) return;
+    // group by node, keeping arrival order inside each node's queue
+    std::stable_sort(queued.begin(), queued.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    size_t i = 0;
+    while (i < queued.size()) {
+      const uint64_t key = queued[i].first;
+      const uint32_t voice = static_cast<uint32_t>(key / stages.size());
+      const uint32_t stage = static_cast<uint32_t>(key % stages.size());
+      const uint32_t cap = stages[stage].dcpb;
+      uint32_t at = frame_begin, taken = 0;
+      bool blocked = false;
+      for (; i < queued.size() && queued[i].first == key; ++i) {
+        if (taken >= cap) {  // precise_timing.rs:129-134: the queue was full when this change arrived
+          if (taken == cap) warn("Not enough space for scheduled changes in WrPreciseTiming, change ignored");
+          ++taken;
+          continue;
+        }
+        ++taken;
+        if (blocked) continue;  // behind a change that is not due in this block: never reached
+        const QueuedChange& c = queued[i].second;
         uint32_t due = std::max<uint32_t>(c.delay, at);
-        if (due > frame_end) break;
+        if (due > frame_end) { blocked = true; continue; }
         at = due;
         const size_t first = pending.size();
         apply_now(voice, stage, c.param, c.f, c.i, frame_base + due, pending);
@@ -534,9 +546,8 @@ struct Bank final : knh_bank {
           pending_needs_sort = true;
         }
       }
-      q.clear();
     }
-    queues.clear();
+    queued.clear();
   }
 
   // ---- processing ---------------------------------------------------------------------------
