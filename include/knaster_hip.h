@@ -53,7 +53,10 @@ typedef enum knh_value_kind {
   KNH_VALUE_FLOAT = 0,
   KNH_VALUE_TRIGGER = 1,
   KNH_VALUE_INTEGER = 2,
-  KNH_VALUE_BOOL = 3
+  KNH_VALUE_BOOL = 3,
+  /* ParameterValue::Smoothing(ParameterSmoothing, Rate): fvalue = seconds of ParameterSmoothing::Linear
+   * (as f32), ivalue = 0 None, 1 Linear at Rate::BlockRate, 2 Linear at Rate::AudioRate */
+  KNH_VALUE_SMOOTHING = 4
 } knh_value_kind;
 
 /* A voice chain is a short list of stages evaluated in order on one running
@@ -117,7 +120,12 @@ typedef enum knh_svf_type {
 
 enum {
   /* SinWt pushed as .ar_params() with its "freq" linked to the running signal */
-  KNH_STAGE_FLAG_AR_FREQ = 1u << 0
+  KNH_STAGE_FLAG_AR_FREQ = 1u << 0,
+  /* the stage's parameterised node is wrapped in WrSmoothParams (innermost wrapper): a
+   * KNH_VALUE_SMOOTHING value selects linear smoothing for one Float parameter, after which new
+   * Float values are reached by a block-rate linear ramp (smooth_params.rs:12-311).  The ramp lives
+   * on the host, as it does on the reference's audio thread: one param_apply per node per block. */
+  KNH_STAGE_FLAG_SMOOTH_PARAMS = 1u << 1
 };
 
 typedef struct knh_stage_desc {

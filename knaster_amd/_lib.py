@@ -19,12 +19,13 @@ ERR_NOT_INITIALISED, ERR_NO_DEVICE, ERR_WRONG_VALUE_KIND = 5, 6, 7
 # knh_sample_type
 F32, F64 = 0, 1
 # knh_value_kind
-VALUE_FLOAT, VALUE_TRIGGER, VALUE_INTEGER, VALUE_BOOL = 0, 1, 2, 3
+VALUE_FLOAT, VALUE_TRIGGER, VALUE_INTEGER, VALUE_BOOL, VALUE_SMOOTHING = 0, 1, 2, 3, 4
 # knh_stage_kind
 (STAGE_SIN_WT, STAGE_SIN_NUMERIC, STAGE_SVF, STAGE_ONEPOLE_LPF, STAGE_ONEPOLE_HPF, STAGE_MUL_ENV_ASR,
  STAGE_MUL_ENV_AR, STAGE_MUL_CONST, STAGE_ADD_CONST, STAGE_SUB_CONST, STAGE_DIV_CONST, STAGE_WR_MUL,
  STAGE_WR_ADD, STAGE_WR_SUB) = range(14)
 STAGE_FLAG_AR_FREQ = 1
+STAGE_FLAG_SMOOTH_PARAMS = 2
 # knh_svf_type
 SVF_LOW, SVF_HIGH, SVF_BAND, SVF_NOTCH, SVF_PEAK, SVF_ALL, SVF_BELL, SVF_LOW_SHELF, SVF_HIGH_SHELF = range(9)
 # knh_mix_mode

@@ -214,6 +214,24 @@ struct Bank final : knh_bank {
   // WrPreciseTiming::waiting_changes of every wrapped node, flattened: (key = voice * n_stages + stage, change)
   // in arrival order; grouped per node when the block is assembled.
   std::vector<std::pair<uint64_t, QueuedChange>> queued;
+  // WrSmoothParams (smooth_params.rs:12-311) for stages flagged KNH_STAGE_FLAG_SMOOTH_PARAMS: the ramp state
+  // lives on the host, exactly as it lives on the reference's audio thread; once per (partial) block every
+  // ramp in flight hands its interpolated value to the wrapped node's setter.
+  struct SmoothState {
+    bool linear = false;
+    double current_value = 0, start_value = 0, end_value = 0;
+    size_t duration_frames = 0, frames_elapsed = 0;
+    uint8_t audio_rate = 0;
+    bool done = true;
+    double interpolated() const {
+      double mix = static_cast<double>(frames_elapsed) / static_cast<double>(duration_frames);
+      return (end_value - start_value) * mix + start_value;
+    }
+  };
+  std::vector<std::vector<SmoothState>> smooth;      // [stage][voice * n_params + param], flagged stages only
+  std::vector<uint64_t> smooth_active;               // nodes (voice * n_stages + stage) with a ramp possibly in flight
+  std::vector<std::vector<uint32_t>> smooth_mark;    // [stage][voice]: bit 0 = listed in smooth_active; rest = last ticked epoch
+  uint32_t smooth_epoch = 0;
   // Device state patches of the next launch, in application order: block 0's immediate changes as they
   // arrive, then (at process time) block 0's queued changes, block 1's immediate ones, ...
   std::vector<HostEvent> pending;
@@ -390,6 +408,13 @@ struct Bank final : knh_bank {
     bool any_wrapped = false;
     for (auto& S : stages) any_wrapped = any_wrapped || S.dcpb > 0;
     if (any_wrapped) next_delay.assign(static_cast<size_t>(n_params_total) * nv, 0);
+    smooth.assign(stages.size(), {});
+    smooth_mark.assign(stages.size(), {});
+    for (size_t si = 0; si < stages.size(); ++si)
+      if (stages[si].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) {
+        smooth[si].assign(static_cast<size_t>(nv) * stages[si].n_params, SmoothState{});
+        smooth_mark[si].assign(nv, 0u);
+      }
     initialised = true;
     return KNH_OK;
   }
@@ -421,8 +446,7 @@ struct Bank final : knh_bank {
     int rc = check_target(voice, stage, param);
     if (rc != KNH_OK) return rc;
     const StageInfo& S = stages[stage];
-    if (static_cast<int>(kind) != expected_value_kind(S.kind, param))
-      return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
+    if (!kind_ok(S, param, kind)) return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
     if (S.dcpb > 0) {  // WrPreciseTiming::param_apply, precise_timing.rs:126-135
       uint16_t d = next_delay[static_cast<size_t>(S.param_base + param) * nv + voice];
       if (d != 0) {  // capacity (DELAYED_CHANGES_PER_BLOCK) is enforced per node when the block is assembled
@@ -430,8 +454,79 @@ struct Bank final : knh_bank {
         return KNH_OK;
       }
     }
-    apply_now(voice, stage, param, f, i, frame_base, pending);
+    deliver(voice, stage, param, kind, f, i, frame_base);
     return KNH_OK;
+  }
+  static bool kind_ok(const StageInfo& S, uint32_t param, uint32_t kind) {
+    const int want = expected_value_kind(S.kind, param);
+    if (static_cast<int>(kind) == want) return true;
+    // ParameterValue::Smoothing is accepted by a WrSmoothParams-wrapped node for its Float parameters; without
+    // the wrapper the reference's generated param_apply panics on it (knaster_macros/src/lib.rs:601-606,752-757)
+    return kind == KNH_VALUE_SMOOTHING && (S.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && want == KNH_VALUE_FLOAT;
+  }
+  // WrSmoothParams::param_apply (smooth_params.rs:210-259) in front of the node's own setters.
+  void deliver(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t iv, uint32_t frame) {
+    const StageInfo& S = stages[stage];
+    if (!(S.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) || (kind != KNH_VALUE_FLOAT && kind != KNH_VALUE_SMOOTHING)) {
+      apply_now(voice, stage, param, f, iv, frame, pending);
+      return;
+    }
+    SmoothState& st = smooth[stage][static_cast<size_t>(voice) * S.n_params + param];
+    if (kind == KNH_VALUE_SMOOTHING) {  // set_smoothing, :30-102
+      if (iv == 0) {
+        if (st.linear) {
+          double cv = st.interpolated();
+          st = SmoothState{};
+          st.current_value = cv;
+        }
+        return;
+      }
+      const size_t dur = static_cast<size_t>(static_cast<double>(static_cast<float>(f)) * static_cast<double>(sample_rate));
+      if (!st.linear) {
+        double cv = st.current_value;
+        st.linear = true;
+        st.start_value = cv;
+        st.end_value = cv;
+        st.frames_elapsed = 0;
+      } else if (st.done) {
+        st.start_value = st.end_value;
+        st.frames_elapsed = 0;
+      } else {
+        st.start_value = st.interpolated();
+      }
+      st.duration_frames = dur;
+      st.audio_rate = iv == 2;
+      st.done = true;
+      return;
+    }
+    if (!st.linear) {  // no smoothing selected for this parameter: straight through
+      apply_now(voice, stage, param, f, iv, frame, pending);
+      return;
+    }
+    st.start_value = st.done ? st.end_value : st.interpolated();
+    st.end_value = f;
+    st.done = false;
+    st.frames_elapsed = 0;
+    uint32_t& mark = smooth_mark[stage][voice];
+    if (!(mark & 1u)) {
+      mark |= 1u;
+      smooth_active.push_back(static_cast<uint64_t>(voice) * stages.size() + stage);
+    }
+  }
+  // WrSmoothParams::process_block's block-rate step (:188-197) for one node, at the start of a (partial) block.
+  void smooth_tick(uint32_t voice, uint32_t stage, uint32_t frame) {
+    const StageInfo& S = stages[stage];
+    SmoothState* st = &smooth[stage][static_cast<size_t>(voice) * S.n_params];
+    for (int p = 0; p < S.n_params; ++p) {
+      SmoothState& x = st[p];
+      if (!x.linear || x.done) continue;  // next_value, :263-300 (frame_in_block is 0 on this path)
+      const double v = x.interpolated();
+      if (x.frames_elapsed == x.duration_frames) x.done = true;
+      else if (x.audio_rate) x.frames_elapsed += 1;
+      else x.frames_elapsed = std::min(x.frames_elapsed + block_size, x.duration_frames);
+      apply_now(voice, stage, static_cast<uint32_t>(p), v, 0, frame_base + frame, pending);
+    }
+    smooth_mark[stage][voice] = (smooth_mark[stage][voice] & 1u) | (smooth_epoch << 1);
   }
   // The same two calls addressed to block `block_offset` of the next multi-block launch: validated now,
   // replayed in order when that block is assembled.
@@ -441,7 +536,7 @@ struct Bank final : knh_bank {
     int rc = check_target(voice, stage, param);
     if (rc != KNH_OK) return rc;
     if (block_offset >= 65536) return fail(KNH_ERR_OUT_OF_RANGE, "block_offset too large");
-    if (!is_delay && static_cast<int>(kind) != expected_value_kind(stages[stage].kind, param))
+    if (!is_delay && !kind_ok(stages[stage], param, kind))
       return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
     if (future.size() <= block_offset) future.resize(block_offset + 1);
     future[block_offset].push_back(Call{static_cast<uint8_t>(is_delay), delay, voice, stage, param, kind, f, i});
@@ -513,41 +608,79 @@ struct Bank final : knh_bank {
   // WrPreciseTiming::process_block's change loop (precise_timing.rs:65-114) for every wrapped node
   // with queued changes: FIFO with head-of-line blocking, changes past the processed range are lost.
   void resolve_queues(uint32_t frame_begin, uint32_t frame_end) {  // block-relative range; events get frame_base added
-    if (queued.empty()) return;
-    // group by node, keeping arrival order inside each node's queue
-    std::stable_sort(queued.begin(), queued.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-    size_t i = 0;
-    while (i < queued.size()) {
-      const uint64_t key = queued[i].first;
-      const uint32_t voice = static_cast<uint32_t>(key / stages.size());
-      const uint32_t stage = static_cast<uint32_t>(key % stages.size());
-      const uint32_t cap = stages[stage].dcpb;
-      uint32_t at = frame_begin, taken = 0;
-      bool blocked = false;
-      for (; i < queued.size() && queued[i].first == key; ++i) {
-        if (taken >= cap) {  // precise_timing.rs:129-134: the queue was full when this change arrived
-          if (taken == cap) warn("Not enough space for scheduled changes in WrPreciseTiming, change ignored");
+    smooth_epoch = (smooth_epoch + 1) & 0x7FFFFFFFu;
+    if (!queued.empty()) {
+      // group by node, keeping arrival order inside each node's queue
+      std::stable_sort(queued.begin(), queued.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      size_t i = 0;
+      std::vector<std::pair<uint32_t, const QueuedChange*>> due_list;
+      while (i < queued.size()) {
+        const uint64_t key = queued[i].first;
+        const uint32_t voice = static_cast<uint32_t>(key / stages.size());
+        const uint32_t stage = static_cast<uint32_t>(key % stages.size());
+        const uint32_t cap = stages[stage].dcpb;
+        const bool smoothed = (stages[stage].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) != 0;
+        uint32_t at = frame_begin, taken = 0;
+        bool blocked = false;
+        due_list.clear();
+        for (; i < queued.size() && queued[i].first == key; ++i) {
+          if (taken >= cap) {  // precise_timing.rs:129-134: the queue was full when this change arrived
+            if (taken == cap) warn("Not enough space for scheduled changes in WrPreciseTiming, change ignored");
+            ++taken;
+            continue;
+          }
           ++taken;
-          continue;
+          if (blocked) continue;  // behind a change that is not due in this block: never reached
+          const QueuedChange& c = queued[i].second;
+          uint32_t due = std::max<uint32_t>(c.delay, at);
+          if (due > frame_end) { blocked = true; continue; }
+          at = due;
+          due_list.emplace_back(due, &c);
         }
-        ++taken;
-        if (blocked) continue;  // behind a change that is not due in this block: never reached
-        const QueuedChange& c = queued[i].second;
-        uint32_t due = std::max<uint32_t>(c.delay, at);
-        if (due > frame_end) { blocked = true; continue; }
-        at = due;
-        const size_t first = pending.size();
-        apply_now(voice, stage, c.param, c.f, c.i, frame_base + due, pending);
-        // a queued change splits the node's block at `due` (precise_timing.rs:104-110)
-        if (due > frame_begin) {
-          if (pending.size() == first)  // the setter emitted no patch (value unchanged): still a split
-            pending.push_back(HostEvent{voice, frame_base + due, knh_dev::EV_NOP, static_cast<uint32_t>(stages[stage].slot_base), 0});
-          for (size_t k = first; k < pending.size(); ++k) pending[k].op |= knh_dev::EV_SPLIT;
-          pending_needs_sort = true;
+        // WrPreciseTiming::process_block (precise_timing.rs:65-114): apply what is due, run the inner
+        // (partial) block from there, repeat.  An inner WrSmoothParams steps its ramps at the start of
+        // every one of those partial blocks.
+        size_t k = 0;
+        uint32_t seg = frame_begin;
+        bool first = true;
+        while (true) {
+          const size_t first_ev = pending.size();
+          while (k < due_list.size() && due_list[k].first <= seg) {
+            const QueuedChange& c = *due_list[k].second;
+            deliver(voice, stage, c.param, c.kind, c.f, c.i, frame_base + seg);
+            ++k;
+          }
+          if (seg < frame_end && smoothed) smooth_tick(voice, stage, seg);
+          if (!first) {  // a split point: the node's block restarts here (precise_timing.rs:104-110)
+            if (pending.size() == first_ev)
+              pending.push_back(HostEvent{voice, frame_base + seg, knh_dev::EV_NOP, static_cast<uint32_t>(stages[stage].slot_base), 0});
+            for (size_t e = first_ev; e < pending.size(); ++e) pending[e].op |= knh_dev::EV_SPLIT;
+            pending_needs_sort = true;
+          }
+          if (k >= due_list.size()) break;
+          seg = due_list[k].first;
+          first = false;
         }
       }
+      queued.clear();
     }
-    queued.clear();
+    // nodes with a ramp in flight that were not stepped above: one step at the start of the block
+    if (!smooth_active.empty()) {
+      size_t w = 0;
+      for (size_t r = 0; r < smooth_active.size(); ++r) {
+        const uint64_t key = smooth_active[r];
+        const uint32_t voice = static_cast<uint32_t>(key / stages.size());
+        const uint32_t stage = static_cast<uint32_t>(key % stages.size());
+        if ((smooth_mark[stage][voice] >> 1) != smooth_epoch) smooth_tick(voice, stage, frame_begin);
+        bool alive = false;
+        const SmoothState* st = &smooth[stage][static_cast<size_t>(voice) * stages[stage].n_params];
+        for (int p = 0; p < stages[stage].n_params; ++p) alive = alive || (st[p].linear && !st[p].done);
+        if (alive) smooth_active[w++] = key;
+        else smooth_mark[stage][voice] &= ~1u;
+      }
+      smooth_active.resize(w);
+      pending_needs_sort = true;
+    }
   }
 
   // ---- processing ---------------------------------------------------------------------------
@@ -821,7 +954,9 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if (st[i].kind >= KNH_STAGE_KIND_COUNT) { *why = "unknown stage kind"; return KNH_ERR_INVALID_ARGUMENT; }
     const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
-    if (st[i].flags & ~KNH_STAGE_FLAG_AR_FREQ) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
+    if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ)) { *why = "SMOOTH_PARAMS and AR_FREQ cannot be combined"; return KNH_ERR_INVALID_ARGUMENT; }
+    if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && st[i].kind >= KNH_STAGE_WR_MUL) { *why = "SMOOTH_PARAMS applies to a node, not to a wrapper stage"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
     if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }

@@ -92,7 +92,7 @@ struct UGenSpec {
   uint16_t kind = 0;                 // knh_stage_kind of the core UGen
   std::vector<double> args;          // constructor arguments
   std::vector<std::pair<uint16_t, double>> wrappers;  // (KNH_STAGE_WR_*, value) in application order
-  bool ar_params_ = false;
+  bool ar_params_ = false, smooth_params_ = false;
   uint16_t precise_timing_ = 0;
   bool is_constant = false, is_env = false;
   // wrappers_core.rs:26-111
@@ -100,6 +100,7 @@ struct UGenSpec {
   UGenSpec wr_add(double v) && { wrappers.emplace_back(KNH_STAGE_WR_ADD, v); return std::move(*this); }
   UGenSpec wr_sub(double v) && { wrappers.emplace_back(KNH_STAGE_WR_SUB, v); return std::move(*this); }
   UGenSpec ar_params() && { ar_params_ = true; return std::move(*this); }
+  UGenSpec smooth_params() && { smooth_params_ = true; return std::move(*this); }
   UGenSpec precise_timing(uint16_t max_changes_per_block) && { precise_timing_ = max_changes_per_block; return std::move(*this); }
 };
 inline UGenSpec SinWt(double freq) { return UGenSpec(KNH_STAGE_SIN_WT, {freq}); }
@@ -187,6 +188,9 @@ class Sig {  // SH / DH of graph_edit.rs:266-277: one or more output channels of
     void set(int64_t v) { graph_->schedule({node_, index_, KNH_VALUE_INTEGER, 0, v, false, {}}); }
     void set_at(double v, Time t) { graph_->schedule({node_, index_, KNH_VALUE_FLOAT, v, 0, true, t}); }
     void trig() { graph_->schedule({node_, index_, KNH_VALUE_TRIGGER, 0, 0, false, {}}); }
+    // param.smooth(ParameterSmoothing::Linear(seconds)) / ::None (graph_edit.rs:1773-1786); needs .smooth_params()
+    void smooth_linear(float seconds) { graph_->schedule({node_, index_, KNH_VALUE_SMOOTHING, seconds, 1, false, {}}); }
+    void smooth_none() { graph_->schedule({node_, index_, KNH_VALUE_SMOOTHING, 0, 0, false, {}}); }
     void trig_at(Time t) { graph_->schedule({node_, index_, KNH_VALUE_TRIGGER, 0, 0, true, t}); }
     void set(PTrigger) { trig(); }
    private:
@@ -273,7 +277,7 @@ class Graph {
       if (n.math_kind != 0xFFFF) {  // signal (op) Constant: graph_edit.rs:1036-1066
         trace(n.in0, p, visited);
         const NodeRec& c = nodes_[static_cast<size_t>(n.in1)];
-        push_stage(p, n.math_kind, 0, c.spec.precise_timing_, n.in1, c.spec.args);
+        push_stage(p, n.math_kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, n.in1, c.spec.args);
         visited.push_back(n.in1);
         return;
       }
@@ -285,7 +289,7 @@ class Graph {
       trace(env == n.in1 ? n.in0 : n.in1, p, visited);
       const NodeRec& e = nodes_[static_cast<size_t>(env)];
       if (!e.spec.wrappers.empty()) throw GraphError("wrappers on an envelope inside a product are not fused");
-      push_stage(p, e.spec.kind, 0, e.spec.precise_timing_, env, e.spec.args);
+      push_stage(p, e.spec.kind, e.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, e.spec.precise_timing_, env, e.spec.args);
       visited.push_back(env);
       return;
     }
@@ -303,6 +307,7 @@ class Graph {
     } else {
       trace(n.in0, p, visited);
     }
+    if (s.smooth_params_) flags |= KNH_STAGE_FLAG_SMOOTH_PARAMS;
     push_stage(p, s.kind, flags, s.precise_timing_, node, s.args);
     for (auto& w : s.wrappers) push_stage(p, w.first, 0, 0, node, {w.second});
   }

@@ -185,11 +185,25 @@ struct UGenFlags {
 // ---------------------------------------------------------------------------
 // ParameterValue -- knaster_core/src/parameters/types.rs:25-36
 // ---------------------------------------------------------------------------
+enum class Rate : uint8_t { BlockRate = 0, AudioRate = 1 };  // knaster_core/src/lib.rs:54-61 (default BlockRate)
+struct ParameterSmoothing {  // knaster_core/src/parameters/types.rs:107-114
+  bool linear = false;       // false = ParameterSmoothing::None
+  float seconds = 0.f;       // Linear(f32)
+};
 struct ParameterValue {
   enum Kind : uint8_t { Float = 0, Trigger = 1, Integer = 2, Bool = 3, Smoothing = 4 } kind = Float;
   PFloat f = 0.0;
   uint64_t i = 0;
   bool b = false;
+  ParameterSmoothing smoothing;
+  Rate rate = Rate::BlockRate;
+  static ParameterValue Smooth(ParameterSmoothing s, Rate r = Rate::BlockRate) {
+    ParameterValue p;
+    p.kind = Smoothing;
+    p.smoothing = s;
+    p.rate = r;
+    return p;
+  }
   static ParameterValue Flt(PFloat v) {
     ParameterValue p;
     p.kind = Float;
@@ -1057,6 +1071,121 @@ struct WrPreciseTiming : UGen<F> {
   void set_delay_within_block_for_param(AudioCtx&, size_t index, uint16_t delay) override {
     next_delay[index] = delay;
   }
+};
+
+// ---------------------------------------------------------------------------
+// WrSmoothParams -- knaster_core_dsp/src/wrappers_core/smooth_params.rs:12-311
+// The per-parameter `Rate` table (`parameters`) is never written in the reference ("TODO: set the Rate
+// of a parameter", :149), so the audio-rate branch of process_block is unreachable; only the
+// block-rate path is restated.  Note next_value() advances by ctx.block_size() per process_block CALL,
+// also when the call covers a partial block.
+// ---------------------------------------------------------------------------
+struct ParameterSmoothingState {
+  bool linear = false;
+  PFloat current_value = 0.0;  // None { current_value }
+  PFloat start_value = 0.0, end_value = 0.0;
+  size_t duration_frames = 0, frames_elapsed = 0;
+  Rate rate = Rate::BlockRate;
+  bool done = true;
+  PFloat interpolated() const {
+    PFloat current_mix = static_cast<PFloat>(frames_elapsed) / static_cast<PFloat>(duration_frames);
+    return (end_value - start_value) * current_mix + start_value;
+  }
+  bool next_value(size_t block_size, size_t frame_in_block, PFloat* out) {  // :263-300
+    if (!linear) return false;
+    if (rate == Rate::BlockRate && frame_in_block != 0) return false;
+    if (done) return false;
+    PFloat current_value_ = interpolated();
+    if (frames_elapsed == duration_frames) done = true;
+    else if (rate == Rate::BlockRate) frames_elapsed = std::min(frames_elapsed + block_size, duration_frames);
+    else frames_elapsed += 1;
+    *out = current_value_;
+    return true;
+  }
+};
+template <typename F>
+struct WrSmoothParams : UGen<F> {
+  UGenPtr<F> ugen;
+  std::vector<ParameterSmoothingState> smoothing_state;
+  explicit WrSmoothParams(UGenPtr<F> inner) : ugen(std::move(inner)), smoothing_state(ugen->parameters()) {}
+  size_t inputs() const override { return ugen->inputs(); }
+  size_t outputs() const override { return ugen->outputs(); }
+  size_t parameters() const override { return ugen->parameters(); }
+  std::vector<std::string> param_descriptions() const override { return ugen->param_descriptions(); }
+  void init(uint32_t sr, size_t bs) override { ugen->init(sr, bs); }
+  void set_smoothing(size_t index, ParameterSmoothing smoothing, Rate new_rate, double sample_rate) {  // :30-102
+    ParameterSmoothingState& st = smoothing_state[index];
+    if (!smoothing.linear) {
+      if (st.linear) {
+        PFloat cv = st.interpolated();
+        st = ParameterSmoothingState{};
+        st.current_value = cv;
+      }
+      return;
+    }
+    size_t new_duration = static_cast<size_t>(static_cast<double>(smoothing.seconds) * sample_rate);
+    if (!st.linear) {
+      PFloat cv = st.current_value;
+      st.linear = true;
+      st.start_value = cv;
+      st.end_value = cv;
+      st.duration_frames = new_duration;
+      st.frames_elapsed = 0;
+      st.rate = new_rate;
+      st.done = true;
+    } else if (st.done) {
+      st.start_value = st.end_value;
+      st.duration_frames = new_duration;
+      st.frames_elapsed = 0;
+      st.rate = new_rate;
+      st.done = true;
+    } else {
+      PFloat cv = st.interpolated();
+      st.start_value = cv;
+      st.duration_frames = new_duration;
+      st.rate = new_rate;
+      st.done = true;  // (sic) :96 -- the ramp in flight is frozen until the next value arrives
+    }
+  }
+  void process(AudioCtx& ctx, UGenFlags& flags, const F* in, F* out) override {  // :116-131
+    for (size_t j = 0; j < smoothing_state.size(); ++j) {
+      PFloat v;
+      if (smoothing_state[j].next_value(1, 0, &v)) ugen->param_apply(ctx, j, ParameterValue::Flt(v));
+    }
+    ugen->process(ctx, flags, in, out);
+  }
+  void process_block(AudioCtx& ctx, UGenFlags& flags, const BlockView<F>& input, BlockView<F>& output) override {
+    for (size_t j = 0; j < smoothing_state.size(); ++j) {  // :188-197
+      PFloat v;
+      if (smoothing_state[j].next_value(ctx.block_size(), 0, &v)) ugen->param_apply(ctx, j, ParameterValue::Flt(v));
+    }
+    ugen->process_block(ctx, flags, input, output);
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue value) override {  // :210-259
+    if (index >= ugen->parameters()) return;
+    switch (value.kind) {
+      case ParameterValue::Integer: case ParameterValue::Trigger: case ParameterValue::Bool:
+        ugen->param_apply(ctx, index, value);
+        break;
+      case ParameterValue::Float: {
+        ParameterSmoothingState& st = smoothing_state[index];
+        if (!st.linear) {
+          ugen->param_apply(ctx, index, value);
+        } else {
+          if (st.done) st.start_value = st.end_value;
+          else st.start_value = st.interpolated();
+          st.end_value = value.f;
+          st.done = false;
+          st.frames_elapsed = 0;
+        }
+      } break;
+      case ParameterValue::Smoothing:
+        set_smoothing(index, value.smoothing, value.rate, static_cast<double>(ctx.sample_rate()));
+        break;
+    }
+  }
+  // set_ar_param_buffer / set_delay_within_block_for_param are NOT forwarded by the reference wrapper
+  // (they fall to the trait defaults, ugen.rs:322-341): WrPreciseTiming and WrArParams must sit outside.
 };
 
 // ---------------------------------------------------------------------------

@@ -73,6 +73,10 @@ struct VoiceChainBuilder {
       const bool two_node = st.kind >= KNH_STAGE_MUL_ENV_ASR && st.kind <= KNH_STAGE_DIV_CONST;
       targets[s].n_params = core->parameters();
       if (st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ)) core = std::make_unique<WrArParams<F>>(std::move(core));
+      if (st.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) {
+        if (st.flags & KNH_STAGE_FLAG_AR_FREQ) throw std::runtime_error("SMOOTH_PARAMS and AR_FREQ cannot be combined");
+        core = std::make_unique<WrSmoothParams<F>>(std::move(core));
+      }
       // Wrapper stages that follow wrap the node producing x.  For single-node
       // stages that is `core`; for two-node stages it is the MathUGen.
       UGenPtr<F> math;

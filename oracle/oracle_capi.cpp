@@ -78,6 +78,12 @@ ParameterValue make_value(uint32_t kind, double f, int64_t i) {
     case KNH_VALUE_FLOAT: return ParameterValue::Flt(f);
     case KNH_VALUE_TRIGGER: return ParameterValue::Trig();
     case KNH_VALUE_INTEGER: return ParameterValue::Int(static_cast<uint64_t>(i));
+    case KNH_VALUE_SMOOTHING: {
+      ParameterSmoothing sm;
+      sm.linear = i != 0;
+      sm.seconds = static_cast<float>(f);
+      return ParameterValue::Smooth(sm, i == 2 ? Rate::AudioRate : Rate::BlockRate);
+    }
     default: {
       ParameterValue p;
       p.kind = ParameterValue::Bool;

@@ -269,3 +269,38 @@ def test_error_behaviour_on_device(knh):
     out, _ = g.process_block()  # still usable after errors ("log and continue")
     assert out.shape == (2, 32)
     g.close()
+
+
+def test_smooth_params_block_rate_ramps(knh, oracle):
+    """WrSmoothParams (smooth_params.rs): linear block-rate ramps on SinWt freq, SVF cutoff/q and a constant,
+    retargeted mid-ramp, switched off mid-ramp, and combined with sample-accurate changes (precise timing
+    outside: every partial block steps the ramp, as in the reference)."""
+    n = 70
+    p = configs.voice_parameters(n)
+    SM = L.STAGE_FLAG_SMOOTH_PARAMS
+    w = configs.Workload("smooth", [Stage(L.STAGE_SIN_WT, flags=SM), Stage(L.STAGE_SVF, flags=SM, delayed_changes_per_block=4),
+                                    Stage(L.STAGE_MUL_CONST, flags=SM)], n, 64, L.F32, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.stack([np.zeros(n), p["cutoff"], p["q"], np.zeros(n)], axis=1),
+              2: np.full((n, 1), 1.0 / n)}
+    v = np.arange(n, dtype=np.uint32)
+    KS = L.VALUE_SMOOTHING
+
+    def ev(block, bank):
+        if block == 0:
+            bank.param_apply_many(v, 0, 0, KS, np.full(n, 0.01), np.ones(n, dtype=np.int64))     # freq: 10 ms linear
+            bank.param_apply_many(v, 1, 0, KS, np.full(n, 0.004), np.ones(n, dtype=np.int64))    # cutoff: 4 ms
+            bank.param_apply_many(v, 2, 0, KS, np.full(n, 0.02), np.ones(n, dtype=np.int64))     # gain
+            # the wrapper starts from current_value 0 (smooth_params.rs:26 "TODO: Initialise state to default"):
+            bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, p["freq"] * 2)
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, p["cutoff"] * 0.25)
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, np.full(n, 2.0 / n))
+        if block == 2:   # retarget mid-ramp
+            bank.param_apply_many(v[::2], 0, 0, L.VALUE_FLOAT, p["freq"][::2] * 0.5)
+        if block == 3:   # q is not smoothed (no Smoothing value sent): passes straight through; delayed, so it splits the block
+            bank.param_apply_many(v, 1, 1, L.VALUE_FLOAT, p["q"] + 0.5, None, np.full(n, 17, dtype=np.uint16))
+            bank.param_apply_many(v[1::2], 1, 0, L.VALUE_FLOAT, p["cutoff"][1::2], None, np.full(len(v[1::2]), 40, dtype=np.uint16))
+        if block == 5:   # smoothing off mid-ramp on a third of the voices, new duration on another third
+            bank.param_apply_many(v[::3], 2, 0, KS, np.zeros(len(v[::3])), np.zeros(len(v[::3]), dtype=np.int64))
+            bank.param_apply_many(v[1::3], 2, 0, KS, np.full(len(v[1::3]), 0.002), np.full(len(v[1::3]), 2, dtype=np.int64))
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, np.full(n, 0.5 / n))
+    run_pair(knh, oracle, w, 12, ev, L.MIX_LEFT_FOLD)
