@@ -50,3 +50,15 @@ def test_sine_table_definition(oracle):
     want = np.sin((i / 16384.0) * np.pi * 2.0).astype(np.float32)
     assert np.array_equal(t.view(np.uint32), want.view(np.uint32))
     assert t[0] == 0.0 and t[4096] == 1.0 and t[12288] == -1.0
+
+
+def test_known_answer_tests_under_asan_ubsan(oracle):
+    """The oracle's graph/scheduler code uses raw buffers the way the reference's raw-pointer blocks do
+    (knaster_graph/src/block.rs; the reference runs Miri on it, .github/workflows/rust.yml:51-78)."""
+    import os
+    here = os.path.dirname(oracle.KAT_PATH)
+    res = subprocess.run(["make", "-C", here, "oracle_kat_san"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    res = subprocess.run([os.path.join(here, "oracle_kat_san")], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "KAT PASSED" in res.stdout and "runtime error" not in res.stderr
