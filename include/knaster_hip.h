@@ -268,6 +268,17 @@ int32_t knh_bank_process_blocks(knh_bank* bank, uint32_t n_blocks, uint64_t fram
                                 uint32_t* out_flags);
 int32_t knh_bank_process_blocks_device(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock,
                                        void* out_device, void* hip_stream);
+/* As knh_bank_process_blocks_device, but the bank's mix is ADDED to what `out_device` already holds
+ * (out = out + mix): a further additive source on the same graph outputs, the MathUGen<Add> that
+ * connect_to_output_internal inserts (knaster_graph/src/graph.rs:850-864).  Lets a host with several
+ * banks (voices of different shapes) keep one output buffer in HBM and read it back once. */
+int32_t knh_bank_process_blocks_device_add(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock,
+                                           void* out_device, void* hip_stream);
+/* Device-memory helpers for hosts that do not link HIP themselves (the library owns the allocations):
+ * zero-initialised allocation on `device` (-1: current), free, and a synchronising device-to-host read. */
+void* knh_device_malloc(size_t bytes, int32_t device);
+void knh_device_free(void* device_ptr);
+int32_t knh_device_read(void* dst_host, const void* src_device, size_t bytes, void* hip_stream);
 /* knh_bank_param_apply_many addressed to block `block_offset` (0 = the next block) of the next
  * launch: what GraphGen does with a SchedulingEvent whose Time is not yet due -- it keeps it and
  * applies it in the block where to_samples_until_due() < block_size

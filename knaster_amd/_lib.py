@@ -76,6 +76,10 @@ PROTOTYPES = {
                                                  C.POINTER(C.c_uint32)]),
     "knh_bank_process_blocks": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]),
     "knh_bank_process_blocks_device": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "knh_bank_process_blocks_device_add": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "knh_device_malloc": (C.c_void_p, [C.c_size_t, C.c_int32]),
+    "knh_device_free": (None, [C.c_void_p]),
+    "knh_device_read": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "knh_bank_param_apply_many_at": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "knh_bank_read_done_frames": (C.c_int32, [C.c_void_p, C.c_void_p]),

@@ -162,7 +162,7 @@ struct knh_bank {
   virtual int call_at(uint32_t block_offset, bool is_delay, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f,
                       int64_t i, uint16_t delay) = 0;
   virtual int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t clock, void* out_host, void* out_device,
-                      void* voices_host, uint32_t* out_flags, void* stream, bool sync) = 0;
+                      void* voices_host, uint32_t* out_flags, void* stream, bool sync, bool accumulate = false) = 0;
   virtual int read_done_frames(uint32_t* out) = 0;
   virtual int synchronize() = 0;
   virtual int debug_read(uint32_t* out16) = 0;
@@ -736,7 +736,8 @@ struct Bank final : knh_bank {
   std::vector<uint32_t> cursor;
 
   int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t /*clock*/, void* out_host, void* out_device, void* voices_host,
-              uint32_t* out_flags, void* stream, bool sync) override {
+              uint32_t* out_flags, void* stream, bool sync, bool accumulate) override {
+    if (accumulate && !out_device) return fail(KNH_ERR_INVALID_ARGUMENT, "accumulation needs a device output buffer");
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
     if (offset + ftp > block_size) return fail(KNH_ERR_INVALID_ARGUMENT, "block_start_offset + frames_to_process exceeds block_size");
     if (n_blocks == 0 || n_blocks > 4096) return fail(KNH_ERR_INVALID_ARGUMENT, "n_blocks must be in 1..4096");
@@ -836,9 +837,9 @@ struct Bank final : knh_bank {
 
     F* dst = out_device ? static_cast<F*>(out_device) : d_out;
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
-      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), 1, s));
+      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), 1, accumulate, s));
     else
-      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), n_blocks, s));
+      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), n_blocks, accumulate, s));
 
     if (!sync) return KNH_OK;
     const size_t blk_elems = desc.out_channels * block_size;
@@ -884,11 +885,11 @@ struct Bank final : knh_bank {
     if (pipe) return pipe->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
-  static hipError_t launch_fold(bool tree, const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, unsigned nb, hipStream_t s) {
-    return knh::launch_fold_f32(tree, rows, n, len, fb, fe, out, ch, os, nb, s);
+  static hipError_t launch_fold(bool tree, const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, unsigned nb, bool acc, hipStream_t s) {
+    return knh::launch_fold_f32(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, s);
   }
-  static hipError_t launch_fold(bool tree, const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, unsigned nb, hipStream_t s) {
-    return knh::launch_fold_f64(tree, rows, n, len, fb, fe, out, ch, os, nb, s);
+  static hipError_t launch_fold(bool tree, const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, unsigned nb, bool acc, hipStream_t s) {
+    return knh::launch_fold_f64(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, s);
   }
 
   int read_done_frames(uint32_t* out) override {
@@ -1136,6 +1137,26 @@ int32_t knh_bank_process_blocks(knh_bank* bank, uint32_t n_blocks, uint64_t fram
 int32_t knh_bank_process_blocks_device(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out_device, void* hip_stream) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+}
+int32_t knh_bank_process_blocks_device_add(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out_device, void* hip_stream) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false, true);
+}
+void* knh_device_malloc(size_t bytes, int32_t device) {
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+  return p;
+}
+void knh_device_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+int32_t knh_device_read(void* dst_host, const void* src_device, size_t bytes, void* hip_stream) {
+  // the banks enqueue on their own non-blocking streams unless told otherwise: wait for the device first
+  if (hipDeviceSynchronize() != hipSuccess) return KNH_ERR_DEVICE;
+  (void)hip_stream;
+  return hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost) == hipSuccess ? KNH_OK : KNH_ERR_DEVICE;
 }
 int32_t knh_bank_param_apply_many_at(knh_bank* bank, uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stages,
                                      const uint32_t* params, const uint32_t* kinds, const double* fvalues, const int64_t* ivalues,

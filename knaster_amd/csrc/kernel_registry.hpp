@@ -49,8 +49,8 @@ const KernelEntry* kernel_at(int i);
 // n_blocks consecutive [n_rows][row_len] row sets -> n_blocks consecutive [channels][out_stride] blocks.
 // tree = false: exact left fold of the rows in order; tree = true: 16-ary two-level fold (deterministic)
 hipError_t launch_fold_f32(bool tree, const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
-                           unsigned frame_end, float* out, unsigned channels, unsigned out_stride, unsigned n_blocks, hipStream_t s);
+                           unsigned frame_end, float* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate, hipStream_t s);
 hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
-                           unsigned frame_end, double* out, unsigned channels, unsigned out_stride, unsigned n_blocks, hipStream_t s);
+                           unsigned frame_end, double* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate, hipStream_t s);
 
 }  // namespace knh

@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
 // 16 rows ahead of the adds.  out: [channels][out_stride]; frames [frame_begin, frame_end) are written.
 template <typename F>
 __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
-                                                        u32 frame_end, F* out, u32 channels, u32 out_stride) {
+                                                        u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate) {
   const u32 n = frame_begin + blockIdx.x * 64u + threadIdx.x;
   if (n >= frame_end) return;
   rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
@@ -633,7 +633,11 @@ __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows
     for (int k = 0; k < 16; ++k) acc = acc + v[k];
   }
   for (; r < n_rows; ++r) acc = acc + p[(long)r * row_len];
-  for (u32 c = 0; c < channels; ++c) out[(long)c * out_stride + n] = acc;
+  // accumulate: this bank is a further additive source on the same output (existing + new, graph.rs:850-864)
+  for (u32 c = 0; c < channels; ++c) {
+    F* o = out + (long)c * out_stride + n;
+    *o = accumulate ? *o + acc : acc;
+  }
 }
 
 // Deterministic tree fold of the per-wavefront partial rows (KNH_MIX_TREE):
@@ -641,7 +645,7 @@ __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows
 // One 256-thread workgroup handles 16 frames: thread (g, f) folds group g (+16, +32, ...) for frame f.
 template <typename F>
 __global__ void __launch_bounds__(256) fold_tree_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
-                                                         u32 frame_end, F* out, u32 channels, u32 out_stride) {
+                                                         u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate) {
   __shared__ F part[16][17];
   rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
   out += (long)blockIdx.y * channels * out_stride;
@@ -680,7 +684,10 @@ __global__ void __launch_bounds__(256) fold_tree_kernel(const F* rows, u32 n_row
     __syncthreads();
   }
   if (g == 0 && in_range)
-    for (u32 c = 0; c < channels; ++c) out[(long)c * out_stride + n] = total;
+    for (u32 c = 0; c < channels; ++c) {
+      F* o = out + (long)c * out_stride + n;
+      *o = accumulate ? *o + total : total;
+    }
 }
 
 }  // namespace knh_dev

@@ -501,6 +501,9 @@ class AudioProcessor {
     auto p = std::unique_ptr<AudioProcessor<F>>(new AudioProcessor<F>(g.get()));
     return {std::move(g), std::move(p)};
   }
+  ~AudioProcessor() { if (dev_out_) knh_device_free(dev_out_); }
+  AudioProcessor(const AudioProcessor&) = delete;
+  AudioProcessor& operator=(const AudioProcessor&) = delete;
   size_t block_size() const { return graph_->block_size(); }
   uint16_t inputs() const { return 0; }
   uint16_t outputs() const { return static_cast<uint16_t>(graph_->outputs()); }
@@ -529,16 +532,28 @@ class AudioProcessor {
         for (SchedulingEvent& ev : fresh)
           if (!apply_parameter_change(ev, b, clock)) waiting_.emplace_back(ev, 0);
     }
-    // (iv) run the banks, (v) sum their blocks in bank order into the output block
-    out_.assign(static_cast<size_t>(k) * g.outputs() * bs, F(0));
-    for (auto& bank : g.banks_) {
-      if (!bank.h) continue;
-      bank.out.resize(static_cast<size_t>(k) * g.outputs() * bs);
-      uint32_t flags = 0;
-      int rc = k == 1 ? knh_bank_process_block(bank.h, bs, 0, frame_clock_, bank.out.data(), &flags)
-                      : knh_bank_process_blocks(bank.h, k, frame_clock_, bank.out.data(), &flags);
-      if (rc != KNH_OK) throw GraphError(std::string("knaster_hip: ") + knh_last_error(bank.h));
-      for (size_t i = 0; i < out_.size(); ++i) out_[i] = out_[i] + bank.out[i];
+    // (iv) run the banks, (v) sum their blocks in bank order: the mix stays in one HBM buffer that every
+    // bank after the first adds into (the Add chain of graph.rs:850-864), and is read back once.
+    const size_t n_out = static_cast<size_t>(k) * g.outputs() * bs;
+    out_.assign(n_out, F(0));
+    if (!g.banks_.empty() && g.banks_[0].h) {
+      if (n_out > dev_out_elems_) {
+        if (dev_out_) knh_device_free(dev_out_);
+        dev_out_ = knh_device_malloc(n_out * sizeof(F), -1);
+        if (!dev_out_) throw GraphError("knaster_hip: device allocation failed");
+        dev_out_elems_ = n_out;
+      }
+      bool first = true;
+      for (auto& bank : g.banks_) {
+        if (!bank.h) continue;
+        int rc = first ? knh_bank_process_blocks_device(bank.h, k, frame_clock_, dev_out_, nullptr)
+                       : knh_bank_process_blocks_device_add(bank.h, k, frame_clock_, dev_out_, nullptr);
+        if (rc != KNH_OK) throw GraphError(std::string("knaster_hip: ") + knh_last_error(bank.h));
+        // each bank enqueues on its own stream: order them (the next bank adds to what this one wrote)
+        if (knh_bank_synchronize(bank.h) != KNH_OK) throw GraphError(std::string("knaster_hip: ") + knh_last_error(bank.h));
+        first = false;
+      }
+      if (knh_device_read(out_.data(), dev_out_, n_out * sizeof(F), nullptr) != KNH_OK) throw GraphError("knaster_hip: read back failed");
     }
     frame_clock_ += static_cast<uint64_t>(k) * bs;
     last_blocks_ = k;
@@ -588,6 +603,8 @@ class AudioProcessor {
   uint64_t frame_clock_ = 0;
   uint32_t last_blocks_ = 0;
   std::vector<F> out_;
+  void* dev_out_ = nullptr;
+  size_t dev_out_elems_ = 0;
   std::deque<std::pair<SchedulingEvent, uint32_t>> waiting_;
 };
 

@@ -256,6 +256,69 @@ static void gpu_run_blocks_equals_block_by_block() {
   CHECK(peak > 1e-3f);
 }
 
+// Voices of three different shapes in one graph: three banks, one device-resident mix (bank 2 and 3 add
+// into the buffer bank 1 wrote), compared with the reference-shaped graph holding all of them.
+static void gpu_heterogeneous_voices_mix_on_device() {
+  const int B = 96;
+  auto voices = c3_voices(90);
+  auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+  kno::Graph<float> ref(0, 2, B, 48000);
+  std::vector<Sig<float>::Parameter> trig;
+  std::vector<std::pair<kno::NodeKey, size_t>> ref_trig;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int i = 0; i < 90; ++i) {
+      const auto& v = voices[i];
+      if (i % 3 == 0) {  // plain sine * gain
+        (g.push(SinWt(v.freq)) * v.gain).out({0, 0}).to_graph_out();
+        auto s = ref.push(std::make_unique<kno::SinWt<float>>(float(v.freq)));
+        auto m = ref.math_with_constant(s, 0, kno::MathOp::Mul, float(v.gain));
+        ref.connect_to_output(m, 0, 0, true); ref.connect_to_output(m, 0, 1, true);
+      } else if (i % 3 == 1) {  // many_sines shape
+        auto e = g.push(EnvAr(v.atk, v.rel * 0.05));
+        auto s = g.push(SinWt(v.freq).wr_mul(v.gain));
+        (e * s).out({0, 0}).to_graph_out();
+        trig.push_back(e.param("t_restart"));
+        auto re = ref.push(std::make_unique<kno::EnvAr<float>>(float(v.atk), float(v.rel * 0.05)));
+        auto rs = ref.push(std::make_unique<kno::WrMath<float>>(std::make_unique<kno::SinWt<float>>(float(v.freq)), kno::WrOp::Mul, float(v.gain)));
+        auto m = ref.math_nodes(re, 0, kno::MathOp::Mul, rs, 0);
+        ref.connect_to_output(m, 0, 0, true); ref.connect_to_output(m, 0, 1, true);
+        ref_trig.emplace_back(re, 2);
+      } else {  // filtered voice
+        auto s = g.push(SinWt(v.freq).wr_mul(v.gain));
+        auto f = g.push(OnePoleLpf(v.cutoff));
+        auto e = g.push(EnvAsr(v.atk, v.rel));
+        ((s >> f) * e).out({0, 0}).to_graph_out();
+        trig.push_back(e.param("t_restart"));
+        auto rs = ref.push(std::make_unique<kno::WrMath<float>>(std::make_unique<kno::SinWt<float>>(float(v.freq)), kno::WrOp::Mul, float(v.gain)));
+        auto rf = ref.push(std::make_unique<kno::OnePoleLpf<float>>(float(v.cutoff)));
+        auto re = ref.push(std::make_unique<kno::EnvAsr<float>>(float(v.atk), float(v.rel)));
+        ref.connect_to_node(rs, 0, 0, rf, false);
+        auto m = ref.math_nodes(rf, 0, kno::MathOp::Mul, re, 0);
+        ref.connect_to_output(m, 0, 0, true); ref.connect_to_output(m, 0, 1, true);
+        ref_trig.emplace_back(re, 3);
+      }
+    }
+  });
+  ref.commit_changes();
+  CHECK(graph->num_banks() == 3);
+  for (auto& t : trig) t.trig();
+  for (auto& rt : ref_trig) ref.set(rt.first, rt.second, kno::ParameterValue::Trig());
+  std::vector<float> want(2 * B);
+  double worst = 0, peak = 0;
+  for (int block = 0; block < 6; ++block) {
+    processor->run_without_inputs();
+    ref.run({}, want.data());
+    auto out = processor->output_block();
+    for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < B; ++i) {
+        worst = std::max(worst, std::fabs(double(out.read(c, i)) - double(want[c * B + i])));
+        peak = std::max(peak, std::fabs(double(want[c * B + i])));
+      }
+  }
+  std::printf("  3 banks: max |gpu - reference-shaped graph| = %.3g (peak %.3g)\n", worst, peak);
+  CHECK(worst <= 1e-5 && peak > 1e-3);
+}
+
 int main(int argc, char** argv) {
   bool plan = false, gpu = false;
   for (int i = 1; i < argc; ++i) {
@@ -275,6 +338,7 @@ int main(int argc, char** argv) {
     RUN(gpu_readme_example);
     RUN(gpu_voice_graph_matches_reference_shaped_graph);
     RUN(gpu_run_blocks_equals_block_by_block);
+    RUN(gpu_heterogeneous_voices_mix_on_device);
   }
   std::printf("%s (%d failures)\n", g_fail ? "HOST MIRROR FAILED" : "HOST MIRROR PASSED", g_fail);
   return g_fail ? 1 : 0;

@@ -27,5 +27,6 @@ def test_graph_api_end_to_end_on_gpu(knh):
     _build(knh)
     res = subprocess.run([BIN, "--gpu"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
-    for name in ("gpu_readme_example", "gpu_voice_graph_matches_reference_shaped_graph", "gpu_run_blocks_equals_block_by_block"):
+    for name in ("gpu_readme_example", "gpu_voice_graph_matches_reference_shaped_graph", "gpu_run_blocks_equals_block_by_block",
+                 "gpu_heterogeneous_voices_mix_on_device"):
         assert f"ok   {name}" in res.stdout
