@@ -82,6 +82,12 @@ typedef enum knh_value_kind {
  *     params: 0 attack_time, 1 release_time, 2 t_release(trigger), 3 t_restart(trigger)
  * KNH_STAGE_MUL_ENV_AR      x * g.push(EnvAr::new(a, r))        envelopes.rs:174-303 2    attack_s, release_s
  *     params: 0 attack_time, 1 release_time, 2 t_restart(trigger)
+ * KNH_STAGE_MUL_ENVELOPE    x * g.push(Envelope::new(start, segments).time_scale(ts).looping(l))
+ *                           envelopes.rs:359-527                                    2    start_value, time_scale,
+ *     looping (0/1), n_segments, then n_max x (duration_s, value); n_max = (n_args - 4) / 2 is the same for
+ *     every voice of the bank, n_segments <= n_max per voice.  All of its state is f64 for any F, as in the
+ *     reference.  At most one per chain.
+ *     params: 0 time_scale, 1 jump_to_segment(integer), 2 t_restart(trigger), 3 t_stop(trigger)
  * KNH_STAGE_MUL_CONST       x * c   (Constant + MathUGen Mul)   graph_edit.rs:1036-1066, util.rs:37-64   2   c
  * KNH_STAGE_ADD_CONST       x + c   (Constant + MathUGen Add)                        2    c
  * KNH_STAGE_SUB_CONST       x - c   (Constant + MathUGen Sub)                        2    c
@@ -108,7 +114,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_WR_MUL = 11,
   KNH_STAGE_WR_ADD = 12,
   KNH_STAGE_WR_SUB = 13,
-  KNH_STAGE_KIND_COUNT = 14
+  KNH_STAGE_MUL_ENVELOPE = 14,
+  KNH_STAGE_KIND_COUNT = 15
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

@@ -52,6 +52,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* WR_MUL      */ {1, 1, 1, 0, 'm', {"wr_mul"}},
     /* WR_ADD      */ {1, 0, 1, 0, 'a', {nullptr}},
     /* WR_SUB      */ {1, 0, 1, 0, 's', {nullptr}},
+    /* MUL_ENVELOPE*/ {11, 4, -1, 2, 'V', {"time_scale", "jump_to_segment", "t_restart", "t_stop"}},  // n_ctor: 4 + 2 * n_max
 };
 
 // 0 float, 1 trigger, 2 integer : expected ParameterValue kind per (stage kind, param)
@@ -61,6 +62,7 @@ int expected_value_kind(uint16_t kind, uint32_t param) {
     case KNH_STAGE_SVF: return param == 3 ? KNH_VALUE_INTEGER : param == 4 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
     case KNH_STAGE_MUL_ENV_ASR: return param >= 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
     case KNH_STAGE_MUL_ENV_AR: return param == 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
+    case KNH_STAGE_MUL_ENVELOPE: return param == 0 ? KNH_VALUE_FLOAT : param == 1 ? KNH_VALUE_INTEGER : KNH_VALUE_TRIGGER;
     default: return KNH_VALUE_FLOAT;
   }
 }
@@ -245,6 +247,10 @@ struct Bank final : knh_bank {
   hipStream_t own_stream = nullptr;
   W* d_state = nullptr;
   float* d_sine = nullptr;
+  double* d_seg_table = nullptr;  // segment Envelope: [voice][seg_max][3]
+  uint32_t seg_max = 0;
+  std::vector<double> env_start;  // Envelope::start_value per voice (t_restart restores it)
+  std::vector<uint32_t> env_nseg;
   uint32_t* d_ev_start = nullptr;
   Event* d_events = nullptr;
   size_t d_events_cap = 0;
@@ -270,7 +276,7 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_ev_start, d_events, d_partials, d_out, d_voices, d_done, d_flags};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_ev_start, d_events, d_partials, d_out, d_voices, d_done, d_flags};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
     void* host_ptrs[] = {h_ev_start, h_events, h_out};
@@ -288,6 +294,12 @@ struct Bank final : knh_bank {
     if (initialised) return fail(KNH_ERR_INVALID_ARGUMENT, "constructor arguments must be set before init");
     if (stage >= stages.size()) return fail(KNH_ERR_OUT_OF_RANGE, "stage out of range");
     if (static_cast<uint64_t>(first) + count > nv) return fail(KNH_ERR_OUT_OF_RANGE, "voice range out of range");
+    if (stages[stage].kind == KNH_STAGE_MUL_ENVELOPE && stages[stage].n_ctor < 0) {
+      // Envelope::new(start, segments): the first call fixes the bank-wide segment capacity
+      if (n_args < 6 || (n_args - 4) % 2 != 0) return fail(KNH_ERR_INVALID_ARGUMENT, "Envelope takes 4 + 2 * n_max constructor arguments");
+      stages[stage].n_ctor = static_cast<int>(n_args);
+      ctor[stage].assign(static_cast<size_t>(nv) * n_args, 0.0);
+    }
     if (static_cast<int>(n_args) != stages[stage].n_ctor) return fail(KNH_ERR_INVALID_ARGUMENT, "wrong number of constructor arguments");
     if (n_args && !args) return fail(KNH_ERR_INVALID_ARGUMENT, "null args");
     std::copy(args, args + static_cast<size_t>(count) * n_args, ctor[stage].begin() + static_cast<size_t>(first) * n_args);
@@ -316,6 +328,7 @@ struct Bank final : knh_bank {
     const F sr_as_f32 = static_cast<F>(static_cast<float>(sr));  // F::new(sample_rate as f32)
 
     std::vector<W> st(static_cast<size_t>(n_slots) * stride, W(0));
+    std::vector<double> seg_rows;
     auto slot = [&](int s, uint32_t v) -> W& { return st[static_cast<size_t>(s) * stride + v]; };
     auto fw = [](F x) { return static_cast<W>(to_bits(x)); };
     shadow.assign(stages.size(), Shadow{});
@@ -375,6 +388,34 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 3, v) = fw(rr);
             slot(S.slot_base + 4, v) = fw(F(1));   // release_scale
           } break;
+          case KNH_STAGE_MUL_ENVELOPE: {  // envelopes.rs:373-400 (+ builder methods), init :404-406
+            if (S.n_ctor < 0) return fail(KNH_ERR_INVALID_ARGUMENT, "Envelope stage without constructor arguments");
+            const uint32_t n_max = static_cast<uint32_t>((S.n_ctor - 4) / 2);
+            if (v == 0) { env_start.assign(nv, 0.0); env_nseg.assign(nv, 0); seg_max = n_max; seg_rows.assign(static_cast<size_t>(nv) * n_max * 3, 0.0); }
+            uint32_t n_seg = a[3] >= 1 ? static_cast<uint32_t>(a[3]) : 1u;
+            if (n_seg > n_max) n_seg = n_max;
+            env_start[v] = a[0];
+            env_nseg[v] = n_seg;
+            const double dt = a[1] * (1.0 / static_cast<double>(sr));  // time_scale * base_scale
+            auto put2 = [&](int rel, double d) {
+              uint64_t b = to_bits(d);
+              slot(S.slot_base + rel, v) = static_cast<W>(static_cast<uint32_t>(b));
+              slot(S.slot_base + rel + 1, v) = static_cast<W>(static_cast<uint32_t>(b >> 32));
+            };
+            slot(S.slot_base + 0, v) = 0;  // Stopped
+            slot(S.slot_base + 1, v) = 0;
+            put2(2, 0.0);
+            put2(4, a[0]);  // from_value = start_value
+            put2(6, dt);
+            slot(S.slot_base + 8, v) = n_seg;
+            slot(S.slot_base + 9, v) = a[2] != 0.0 ? 1u : 0u;
+            slot(S.slot_base + 10, v) = v;
+            for (uint32_t k = 0; k < n_max; ++k) {
+              const double dur = a[4 + 2 * k], val = a[5 + 2 * k];
+              double* row = &seg_rows[(static_cast<size_t>(v) * n_max + k) * 3];
+              row[0] = dur; row[1] = 1.0 / dur; row[2] = val;  // EnvelopeSegment::new, envelopes.rs:327-333
+            }
+          } break;
           default:  // Constant / wrapper value: util.rs:43-45, wrappers_core/math.rs:21-23
             slot(S.slot_base, v) = fw(static_cast<F>(a[0]));
             break;
@@ -391,6 +432,10 @@ struct Bank final : knh_bank {
       for (int i = 0; i < 16384; ++i) table[i] = static_cast<float>(std::sin((static_cast<double>(i) / 16384.0) * PI * 2.0));
       KNH_HIP(hipMalloc(&d_sine, 16384 * sizeof(float)));
       KNH_HIP(hipMemcpy(d_sine, table.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (!seg_rows.empty()) {
+      KNH_HIP(hipMalloc(&d_seg_table, seg_rows.size() * sizeof(double)));
+      KNH_HIP(hipMemcpy(d_seg_table, seg_rows.data(), seg_rows.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     const size_t n_waves = (nv + 63) / 64;
     KNH_HIP(hipMalloc(&d_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
@@ -599,6 +644,29 @@ struct Bank final : knh_bank {
           set(0, 1);  // t_restart: state = Attacking, t untouched (envelopes.rs:47-49,131-133)
         }
         break;
+      case KNH_STAGE_MUL_ENVELOPE: {  // envelopes.rs:478-524
+        auto set2 = [&](int rel, double d) {
+          uint64_t b = to_bits(d);
+          set(rel, static_cast<uint32_t>(b));
+          set(rel + 1, static_cast<uint32_t>(b >> 32));
+        };
+        if (param == 0) {  // time_scale = F::new(value).to_f64()
+          set2(6, static_cast<double>(static_cast<F>(f)) * (1.0 / static_cast<double>(sample_rate)));
+        } else if (param == 1) {  // jump_to_segment (clamped), state = Running { segment, 0.0 }
+          uint64_t j = iv < 0 ? 0 : static_cast<uint64_t>(iv);
+          if (j >= env_nseg[v]) j = env_nseg[v] - 1;
+          set(0, 1);
+          set2(2, 0.0);
+          set(1, j);
+        } else if (param == 2) {  // t_restart
+          set(0, 1);
+          set2(2, 0.0);
+          set2(4, env_start[v]);
+          set(1, 0);
+        } else {  // t_stop needs the live time: device op
+          out.push_back(HostEvent{v, frame, knh_dev::EV_SEGENV_STOP, static_cast<uint32_t>(S.slot_base), 0});
+        }
+      } break;
       default:  // Constant::value (util.rs:47-50) / WrMul "wr_mul" (wrappers_core/math.rs:92-98)
         set(0, to_bits(static_cast<F>(f)));
         break;
@@ -810,6 +878,8 @@ struct Bank final : knh_bank {
     a.frame_end = fe;
     a.sine_table = d_sine;
     a.f2pi = f2pi;
+    a.seg_table = d_seg_table;
+    a.seg_max = seg_max;
     a.ev_start = have_events ? d_ev_start : nullptr;
     a.events = d_events;
     a.partials = d_partials;
@@ -863,7 +933,7 @@ struct Bank final : knh_bank {
       uint32_t fl = 0;
       if (h_flags[0]) fl |= KNH_FLAG_ANY_DONE;
       bool has_env = false;
-      for (const StageInfo& st : stages) has_env = has_env || st.kind == KNH_STAGE_MUL_ENV_ASR || st.kind == KNH_STAGE_MUL_ENV_AR;
+      for (const StageInfo& st : stages) has_env = has_env || st.kind == KNH_STAGE_MUL_ENV_ASR || st.kind == KNH_STAGE_MUL_ENV_AR || st.kind == KNH_STAGE_MUL_ENVELOPE;
       if (has_env && h_flags[1] == 0) fl |= KNH_FLAG_ALL_DONE;  // a chain without an envelope never finishes
       *out_flags = fl;
     }
@@ -961,6 +1031,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
     if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (st[i].kind == KNH_STAGE_MUL_ENVELOPE && sig->find('V') != std::string::npos) { *why = "at most one Envelope stage per chain"; return KNH_ERR_INVALID_ARGUMENT; }
     sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
     have_x = true;
   }
@@ -1001,7 +1072,7 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
     const KindInfo& k = kKinds[d.stages[i].kind];
     StageInfo s{d.stages[i].kind, d.stages[i].flags, d.stages[i].delayed_changes_per_block, slot, k.n_slots, k.n_params, k.n_ctor, pbase};
     b->stages.push_back(s);
-    b->ctor.emplace_back(static_cast<size_t>(d.n_voices) * k.n_ctor, 0.0);
+    b->ctor.emplace_back(static_cast<size_t>(d.n_voices) * (k.n_ctor > 0 ? k.n_ctor : 0), 0.0);
     slot += k.n_slots;
     pbase += k.n_params;
   }
@@ -1208,6 +1279,7 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_SVF: w += word * 2; break;
       case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: w += word; break;
       case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: w += word * 3; break;
+      case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
       default: break;
     }
   }

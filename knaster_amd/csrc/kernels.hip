@@ -41,6 +41,7 @@ static const KernelEntry kEntries[] = {
     KNH_CHAIN("WHEm", SinWt, OnePoleHp, MulAr, MulVal),
     KNH_CHAIN("NSAm", SinNum, Svf, MulAsr, MulVal),
     KNH_CHAIN("Wasd", SinWt, AddVal, SubVal, DivVal),
+    KNH_CHAIN("WmV", SinWt, MulVal, MulSegEnv),                 // SinWt.wr_mul * segment Envelope
 };
 
 template <typename F, bool FMA, typename... Gs>

@@ -51,7 +51,7 @@ __device__ __forceinline__ u32 sat_u32(double v) {
 }
 
 // Event opcodes (host -> device state patches, applied at an in-block frame).
-enum { EV_SET = 0, EV_ENV_ASR_RELEASE = 1, EV_NOP = 2, EV_SPLIT = 0x80 /* flag: change came out of a WrPreciseTiming queue */ };
+enum { EV_SET = 0, EV_ENV_ASR_RELEASE = 1, EV_NOP = 2, EV_SEGENV_STOP = 3, EV_SPLIT = 0x80 /* flag: change came out of a WrPreciseTiming queue */ };
 
 struct Event {   // 16 bytes
   u32 frame;     // absolute frame within the launch: block_index * block_size + frame_in_block
@@ -62,8 +62,10 @@ struct Event {   // 16 bytes
 
 // Uniform per-launch context.
 struct Ctx {
-  const float* sine;  // LDS copy of the 16384-entry sine table
-  double f2pi;        // SinWt::freq_to_phase_inc (osc.rs:144-145)
+  const float* sine;        // LDS copy of the 16384-entry sine table
+  double f2pi;              // SinWt::freq_to_phase_inc (osc.rs:144-145)
+  const double* seg_table;  // segment Envelope: [voice][seg_max][3] = (duration, 1/duration, value)
+  u32 seg_max;
 };
 
 // ---------------------------------------------------------------------------
@@ -79,6 +81,7 @@ struct SinWtT {
   static constexpr u32 kMutableMask = AR_FREQ ? 0b101u : 0b001u;
   static constexpr bool kUsesSine = true;
   static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
   template <typename F> struct Regs { u32 phase, off, inc; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
@@ -121,6 +124,7 @@ struct SinNum {
   static constexpr u32 kMutableMask = 0b001u;
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
   template <typename F> struct Regs { F phase, off, inc; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
@@ -160,6 +164,7 @@ struct Svf {
   static constexpr u32 kMutableMask = 0b11u;
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
   template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m0, m1, m2; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -215,6 +220,7 @@ struct OnePoleT {
   static constexpr u32 kMutableMask = 0b1u;
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
   template <typename F> struct Regs { F y, a0, b1; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -252,7 +258,9 @@ struct MulEnvT {
   static constexpr u32 kMutableMask = 0b10011u;
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = true;
+  static constexpr bool kNeedsBind = false;
   template <typename F> struct Regs { u32 state; F t, ar, rr, scale; u32 seg; };
+  template <typename F> static __device__ __forceinline__ bool is_stopped(const Regs<F>& r) { return r.state == 0u; }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
     r.state = (u32)s[0]; r.t = word_to_f<F>(s[st]); r.ar = word_to_f<F>(s[2 * st]);
@@ -363,6 +371,120 @@ struct MulEnvT {
 typedef MulEnvT<false> MulAsr;
 typedef MulEnvT<true> MulAr;
 
+// x * Envelope (segment envelope) -- envelopes.rs:359-527 with MathUGen Mul.  Every quantity is f64 whatever F is.
+// slots (one word each; doubles take two, low word first):
+//   0 running  1 current_segment  2,3 current_time  4,5 from_value  6,7 dt (= time_scale * base_scale)
+//   8 n_segments  9 looping  10 row of this voice in the segment table
+struct MulSegEnv {
+  static constexpr int kSlots = 11;
+  static constexpr u32 kMutableMask = 0b111111u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = true;
+  static constexpr bool kNeedsBind = true;
+  template <typename F> struct Regs {
+    u32 running, cur, n_seg, looping, seg;
+    double time, from, dt, dur, recip, val;
+    const double* rows;
+  };
+  template <typename F> static __device__ __forceinline__ bool is_stopped(const Regs<F>& r) { return r.running == 0u; }
+  template <typename W> static __device__ __forceinline__ double ld2(const W* s, long st, int k) {
+    const u64 lo = (u32)s[(long)k * st], hi = (u32)s[(long)(k + 1) * st];
+    return __builtin_bit_cast(double, lo | (hi << 32));
+  }
+  template <typename W> static __device__ __forceinline__ void st2(W* s, long st, int k, double v) {
+    const u64 b = __builtin_bit_cast(u64, v);
+    s[(long)k * st] = (W)(u32)b;
+    s[(long)(k + 1) * st] = (W)(u32)(b >> 32);
+  }
+  template <typename F> static __device__ __forceinline__ void fetch(Regs<F>& r) {
+    const double* p = r.rows + (long)r.cur * 3;
+    r.dur = p[0]; r.recip = p[1]; r.val = p[2];
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.running = (u32)s[0]; r.cur = (u32)s[st];
+    r.time = ld2(s, st, 2); r.from = ld2(s, st, 4); r.dt = ld2(s, st, 6);
+    r.n_seg = (u32)s[8 * st]; r.looping = (u32)s[9 * st];
+    r.seg = 0;
+    r.rows = nullptr;  // bound on first use (needs the launch context)
+    r.dur = r.recip = r.val = 0.0;
+    r.seg = (u32)s[10 * st];  // table row, consumed by bind()
+  }
+  template <typename F>
+  static __device__ __forceinline__ void bind(Regs<F>& r, const Ctx& c) {
+    if (r.rows == nullptr) {
+      r.rows = c.seg_table + (long)r.seg * c.seg_max * 3;
+      fetch<F>(r);
+    }
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    s[0] = (W)r.running; s[st] = (W)r.cur;
+    st2(s, st, 2, r.time); st2(s, st, 4, r.from);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx& c, u32, u32& done_frame) {
+    bind<F>(r, c);
+    F out;
+    if (!r.running) {
+      out = (F)r.from;
+    } else {
+      const double t = r.time;
+      if (t < r.dur) {
+        out = (F)(r.from + (t * r.recip) * (r.val - r.from));
+        r.time = t + r.dt;
+      } else if (r.cur + 1u < r.n_seg) {
+        r.from = r.val;
+        out = (F)(r.from + (t * r.recip) * (r.val - r.from));
+        r.time = t - r.dur + r.dt;
+        r.cur += 1u;
+        fetch<F>(r);
+      } else {
+        r.from = r.val;
+        out = (F)r.from;
+        if (r.looping) {
+          r.cur = 0u;
+          r.time = 0.0;
+          fetch<F>(r);
+        } else {
+          r.running = 0u;
+          done_frame = 0u;  // flags.mark_done(0), envelopes.rs:458
+        }
+      }
+    }
+    return x * out;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    op &= 0x7Fu;
+    if (op == EV_SEGENV_STOP) {  // t_stop, envelopes.rs:510-522
+      if (r.running && r.rows) r.from = r.from + (r.time * r.recip) * (r.val - r.from);
+      r.running = 0u;
+      return;
+    }
+    if (op != EV_SET) return;
+    const u32 w = (u32)bits;
+    auto lo = [](double d, u32 v) { return __builtin_bit_cast(double, (__builtin_bit_cast(u64, d) & 0xFFFFFFFF00000000ull) | (u64)v); };
+    auto hi = [](double d, u32 v) { return __builtin_bit_cast(double, (__builtin_bit_cast(u64, d) & 0x00000000FFFFFFFFull) | ((u64)v << 32)); };
+    switch (rel) {
+      case 0: r.running = w; break;
+      case 1: r.cur = w; if (r.rows) fetch<F>(r); break;
+      case 2: r.time = lo(r.time, w); break;
+      case 3: r.time = hi(r.time, w); break;
+      case 4: r.from = lo(r.from, w); break;
+      case 5: r.from = hi(r.from, w); break;
+      case 6: r.dt = lo(r.dt, w); break;
+      case 7: r.dt = hi(r.dt, w); break;
+      default: break;
+    }
+  }
+};
+
 // x (op) value: Constant + MathUGen (util.rs:61-63, math.rs:22-85) and WrMul/WrAdd/WrSub
 // (wrappers_core/math.rs:62-67).  slot 0: value.  OP: 0 mul, 1 add, 2 sub, 3 div
 template <int OP>
@@ -371,6 +493,7 @@ struct ValT {
   static constexpr u32 kMutableMask = 0u;
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
   template <typename F> struct Regs { F v; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.v = word_to_f<F>(s[0]); }
@@ -412,7 +535,7 @@ struct Chain<F, FMA, BASE> {
   template <int T> __device__ __forceinline__ void tick_tile(F (&)[T], const Ctx&, u32, u32&) {}
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
-  __device__ __forceinline__ void begin_block(u32) {}
+  __device__ __forceinline__ void begin_block(u32, const Ctx&) {}
 };
 template <typename F, bool FMA, int BASE, typename S0, typename... Rest>
 struct Chain<F, FMA, BASE, S0, Rest...> {
@@ -442,12 +565,13 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
     else rest.on_event(op, slot, bits, frame);
   }
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const {
-    if constexpr (S0::kIsEnv) return rest.last_env_stopped(r.state == 0u);
+    if constexpr (S0::kIsEnv) return rest.last_env_stopped(S0::template is_stopped<F>(r));
     else return rest.last_env_stopped(dflt);
   }
-  __device__ __forceinline__ void begin_block(u32 frame_begin) {
-    if constexpr (S0::kIsEnv) r.seg = frame_begin;
-    rest.begin_block(frame_begin);
+  __device__ __forceinline__ void begin_block(u32 frame_begin, const Ctx& c) {
+    if constexpr (S0::kNeedsBind) S0::template bind<F>(r, c);
+    else if constexpr (S0::kIsEnv) r.seg = frame_begin;
+    rest.begin_block(frame_begin, c);
   }
 };
 
@@ -464,6 +588,8 @@ struct VoiceKernelArgs {
   u32 frame_begin, frame_end;       // frames [begin, end) of each block are processed ([0, block_size) unless n_blocks == 1)
   const float* sine_table;          // 16384 floats in HBM (staged to LDS)
   double f2pi;
+  const double* seg_table;          // segment Envelope table [n_voices][seg_max][3], or null
+  u32 seg_max;
   const u32* ev_start;              // [n_voices + 1] or null when the block has no events
   const Event* events;
   F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its 64 voices
@@ -507,6 +633,8 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   Ctx ctx;
   ctx.sine = sine;
   ctx.f2pi = a.f2pi;
+  ctx.seg_table = a.seg_table;
+  ctx.seg_max = a.seg_max;
 
   const u32 wave_global = blockIdx.x * WAVES + wave;
   const u32 v0 = wave_global * 64u;
@@ -541,7 +669,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   F(*my)[TS] = tile[wave];
   for (u32 b = 0; b < a.n_blocks; ++b, base += a.block_size) {
-    chain.begin_block(a.frame_begin);
+    chain.begin_block(a.frame_begin, ctx);
     F* partial_row = a.partials + ((long)b * n_waves_total + wave_global) * a.block_size;
     for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {
       const u32 len = a.frame_end - n0 < (u32)TN ? a.frame_end - n0 : (u32)TN;

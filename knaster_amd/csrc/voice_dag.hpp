@@ -198,6 +198,8 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
   Ctx ctx;
   ctx.sine = sine;
   ctx.f2pi = a.f2pi;
+  ctx.seg_table = a.seg_table;
+  ctx.seg_max = a.seg_max;
 
   // Each role walks the same (block, tile) sequence, `lag` steps behind wave 0.
   auto role_loop = [&](int lag, auto&& body, auto&& block_end) {
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
     auto on = [&](u32 op, u32 slot, u64 bits, u32 rel) { chain.on_event(op, slot, bits, rel); };
     role_loop(0,
               [&](int g, int, int ti, u32 base, u32 n, u32 m) {
-                if (ti == 0) chain.begin_block(a.frame_begin);
+                if (ti == 0) chain.begin_block(a.frame_begin, ctx);
                 ev.upto(base + n, base, 0, SRC_SLOTS, on);
                 F* xt = ring_x + (long)(g % 3) * LY::tile;
                 if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev.next_frame < base + n + T)) {
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
     };
     role_loop(2,
               [&](int g, int blk, int ti, u32 base, u32 n, u32 m) {
-                if (ti == 0) post.begin_block(a.frame_begin);
+                if (ti == 0) post.begin_block(a.frame_begin, ctx);
                 events_upto(base + n, base);
                 const F* xt = ring_x + (long)(g % 3) * LY::tile;
                 const F* v1t = ring_v1 + (long)(g & 1) * LY::tile;

@@ -59,6 +59,8 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   Ctx ctx;
   ctx.sine = sh.sine;
   ctx.f2pi = a.f2pi;
+  ctx.seg_table = a.seg_table;
+  ctx.seg_max = a.seg_max;
   const bool live = (u32)lane < nv;
   const u32 voice = live ? v0 + lane : v0 + nv - 1;
   ChainT chain;
@@ -93,7 +95,7 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   for (int s = 0; s < n_steps; ++s) {
     const int g = s - I;
     if (g >= 0 && g < n_tiles) {
-      if (ti == 0) chain.begin_block(a.frame_begin);
+      if (ti == 0) chain.begin_block(a.frame_begin, ctx);
       const u32 n = a.frame_begin + (u32)ti * T;
       const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
       apply_events_upto(base + n);

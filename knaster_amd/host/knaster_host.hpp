@@ -112,6 +112,16 @@ inline UGenSpec OnePoleLpf(double cutoff) { return UGenSpec(KNH_STAGE_ONEPOLE_LP
 inline UGenSpec OnePoleHpf() { return UGenSpec(KNH_STAGE_ONEPOLE_HPF, {}); }
 inline UGenSpec EnvAsr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_ASR, {attack, release}); s.is_env = true; return s; }
 inline UGenSpec EnvAr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_AR, {attack, release}); s.is_env = true; return s; }
+// Envelope::new(start_value, segments).time_scale(..).looping(..) -- envelopes.rs:373-400
+struct EnvelopeSegment { double duration, value; };
+inline UGenSpec Envelope(double start_value, const std::vector<EnvelopeSegment>& segments, double time_scale = 1.0, bool looping = false) {
+  if (segments.empty()) throw std::runtime_error("Envelope needs at least one segment");
+  std::vector<double> a{start_value, time_scale, looping ? 1.0 : 0.0, static_cast<double>(segments.size())};
+  for (const EnvelopeSegment& sg : segments) { a.push_back(sg.duration); a.push_back(sg.value); }
+  UGenSpec s(KNH_STAGE_MUL_ENVELOPE, std::move(a));
+  s.is_env = true;
+  return s;
+}
 inline UGenSpec Constant(double value) { UGenSpec s(KNH_STAGE_MUL_CONST, {value}); s.is_constant = true; return s; }
 
 struct GraphError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -215,7 +225,9 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
   static const char* asr[] = {"attack_time", "release_time", "t_release", "t_restart"};
   static const char* ar[] = {"attack_time", "release_time", "t_restart"};
   static const char* val[] = {"value"};
+  static const char* seg[] = {"time_scale", "jump_to_segment", "t_restart", "t_stop"};
   switch (kind) {
+    case KNH_STAGE_MUL_ENVELOPE: *n = 4; return seg;
     case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: *n = 3; return sin;
     case KNH_STAGE_SVF: *n = 5; return svf;
     case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: *n = 1; return op;
@@ -370,9 +382,11 @@ class Graph {
         d.allow_fma = 0;
         if (knh_bank_create(&d, &b.h) != KNH_OK) throw GraphError(std::string("knh_bank_create: ") + knh_last_error(nullptr));
         for (size_t s = 0; s < b.plan.stages.size(); ++s) {
-          const size_t n_args = b.plan.stage_args[s].size();
+          // voices of one bank may hold Envelopes of different lengths: pad to the longest (unused rows, duration 1)
+          size_t n_args = 0;
+          for (size_t vi = 0; vi < members.size(); ++vi) n_args = std::max(n_args, voices[members[vi]].plan.stage_args[s].size());
           if (!n_args) continue;
-          std::vector<double> args(members.size() * n_args);
+          std::vector<double> args(members.size() * n_args, 1.0);
           for (size_t vi = 0; vi < members.size(); ++vi)
             std::copy(voices[members[vi]].plan.stage_args[s].begin(), voices[members[vi]].plan.stage_args[s].end(), args.begin() + static_cast<long>(vi * n_args));
           check(b, knh_bank_set_ctor_args(b.h, static_cast<uint32_t>(s), 0, b.n_voices, args.data(), static_cast<uint32_t>(n_args)));

@@ -795,6 +795,89 @@ struct EnvAr : UGen<F> {
 };
 
 // ---------------------------------------------------------------------------
+// Envelope (segment envelope) -- knaster_core_dsp/src/ugens/envelopes.rs:319-527
+// All state is f64 regardless of F; only `process` exists (default frame loop).
+// params: 0 time_scale, 1 jump_to_segment (integer), 2 t_restart, 3 t_stop
+// ---------------------------------------------------------------------------
+struct EnvelopeSegment {
+  double reciprocal_duration, duration, value;
+  EnvelopeSegment(double duration_, double value_) : reciprocal_duration(1.0 / duration_), duration(duration_), value(value_) {}
+};
+template <typename F>
+struct Envelope : UGen<F> {
+  bool running = false;
+  size_t run_segment = 0;     // EnvelopeState::Running { current_segment, current_time }
+  double run_time = 0.0;
+  std::vector<EnvelopeSegment> segments;
+  double start_value, from_value;
+  size_t current_segment = 0;
+  double time_scale = 1.0, base_scale = 0.0;
+  bool looping = false;
+  Envelope(double start, std::vector<EnvelopeSegment> segs) : segments(std::move(segs)), start_value(start), from_value(start) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 4; }
+  std::vector<std::string> param_descriptions() const override { return {"time_scale", "jump_to_segment", "t_restart", "t_stop"}; }
+  void init(uint32_t sample_rate, size_t) override { base_scale = 1.0 / static_cast<double>(sample_rate); }
+  void process(AudioCtx&, UGenFlags& flags, const F*, F* out) override {  // envelopes.rs:407-463
+    if (!running) {
+      out[0] = fnew<F>(from_value);
+      return;
+    }
+    const double t = run_time;
+    const size_t cs = run_segment;
+    if (t < segments[cs].duration) {
+      const EnvelopeSegment& seg = segments[cs];
+      out[0] = fnew<F>(from_value + (t * seg.reciprocal_duration) * (seg.value - from_value));
+      run_time = t + (time_scale * base_scale);
+    } else if (cs + 1 < segments.size()) {
+      from_value = segments[cs].value;
+      const EnvelopeSegment& seg = segments[cs];
+      out[0] = fnew<F>(from_value + (t * seg.reciprocal_duration) * (seg.value - from_value));
+      run_segment = cs + 1;
+      run_time = t - seg.duration + (time_scale * base_scale);
+    } else {
+      from_value = segments[cs].value;
+      out[0] = fnew<F>(from_value);
+      if (looping) {
+        run_segment = 0;
+        run_time = 0.0;
+      } else {
+        running = false;
+        flags.mark_done(0);
+      }
+    }
+  }
+  void param_apply(AudioCtx&, size_t index, ParameterValue v) override {  // envelopes.rs:478-524
+    switch (index) {
+      case 0: time_scale = static_cast<double>(fnew<F>(v.float_or_panic())); break;
+      case 1: {
+        size_t j = static_cast<size_t>(v.integer_or_panic());
+        if (j >= segments.size()) j = segments.size() - 1;
+        running = true;
+        run_segment = j;
+        run_time = 0.0;
+        current_segment = j;
+      } break;
+      case 2:
+        running = true;
+        run_segment = 0;
+        run_time = 0.0;
+        from_value = start_value;
+        break;
+      case 3:
+        if (running) {
+          const EnvelopeSegment& seg = segments[run_segment];
+          from_value = from_value + (run_time * seg.reciprocal_duration) * (seg.value - from_value);
+        }
+        running = false;
+        break;
+      default: break;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
 // Constant -- knaster_core_dsp/src/ugens/util.rs:37-64
 // ---------------------------------------------------------------------------
 template <typename F>

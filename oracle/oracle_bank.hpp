@@ -23,6 +23,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: return 2;
     case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: return 1;
     case KNH_STAGE_WR_MUL: case KNH_STAGE_WR_ADD: case KNH_STAGE_WR_SUB: return 1;
+    case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
 }
@@ -65,12 +66,22 @@ struct VoiceChainBuilder {
         case KNH_STAGE_ONEPOLE_HPF: core = std::make_unique<OnePoleHpf<F>>(); break;
         case KNH_STAGE_MUL_ENV_ASR: core = std::make_unique<EnvAsr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
         case KNH_STAGE_MUL_ENV_AR: core = std::make_unique<EnvAr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
+        case KNH_STAGE_MUL_ENVELOPE: {
+          std::vector<EnvelopeSegment> segs;
+          size_t n_max = (a.size() - 4) / 2, n = a[3] >= 1 ? static_cast<size_t>(a[3]) : 1;
+          if (n > n_max) n = n_max;
+          for (size_t k = 0; k < n; ++k) segs.emplace_back(a[4 + 2 * k], a[5 + 2 * k]);
+          auto e = std::make_unique<Envelope<F>>(a[0], std::move(segs));
+          e->time_scale = a[1];
+          e->looping = a[2] != 0.0;
+          core = std::move(e);
+        } break;
         case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST:
           core = std::make_unique<Constant<F>>(fnew<F>(a[0]));
           break;
         default: throw std::runtime_error("unknown stage kind");
       }
-      const bool two_node = st.kind >= KNH_STAGE_MUL_ENV_ASR && st.kind <= KNH_STAGE_DIV_CONST;
+      const bool two_node = (st.kind >= KNH_STAGE_MUL_ENV_ASR && st.kind <= KNH_STAGE_DIV_CONST) || st.kind == KNH_STAGE_MUL_ENVELOPE;
       targets[s].n_params = core->parameters();
       if (st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ)) core = std::make_unique<WrArParams<F>>(std::move(core));
       if (st.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) {
@@ -159,7 +170,7 @@ struct OracleBank {
       : stages(st, st + n_stages), n_voices(nv), out_channels(oc), want_mix(mix), want_voices(voices) {
     ctor.assign(nv, std::vector<std::vector<double>>(n_stages));
     for (uint32_t v = 0; v < nv; ++v)
-      for (uint32_t s = 0; s < n_stages; ++s) ctor[v][s].assign(static_cast<size_t>(stage_n_ctor_args(stages[s].kind)), 0.0);
+      for (uint32_t s = 0; s < n_stages; ++s) ctor[v][s].assign(static_cast<size_t>(std::max(0, stage_n_ctor_args(stages[s].kind))), 0.0);
   }
   void init(uint32_t sr, size_t bs) {
     sample_rate = sr;

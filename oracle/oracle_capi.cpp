@@ -29,9 +29,13 @@ struct BankImpl : BankBase {
       : b(st, ns, nv, oc, mix, voices) {}
   int set_ctor(uint32_t stage, uint32_t first, uint32_t count, const double* args, uint32_t n_args) override {
     if (stage >= b.stages.size() || first + count > b.n_voices) return KNH_ERR_OUT_OF_RANGE;
-    if (static_cast<int>(n_args) != stage_n_ctor_args(b.stages[stage].kind)) return KNH_ERR_INVALID_ARGUMENT;
-    for (uint32_t i = 0; i < count; ++i)
+    const int want = stage_n_ctor_args(b.stages[stage].kind);
+    if (want >= 0 && static_cast<int>(n_args) != want) return KNH_ERR_INVALID_ARGUMENT;
+    if (want < 0 && (n_args < 6 || (n_args - 4) % 2 != 0)) return KNH_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < count; ++i) {
+      b.ctor[first + i][stage].assign(n_args, 0.0);
       for (uint32_t a = 0; a < n_args; ++a) b.ctor[first + i][stage][a] = args[static_cast<size_t>(i) * n_args + a];
+    }
     return KNH_OK;
   }
   int init(uint32_t sr, size_t bs) override {
@@ -197,7 +201,8 @@ double kno_baseline_run(const knh_stage_desc* stages, uint32_t n_stages, uint32_
     if (sample_type == KNH_F64) b.reset(new BankImpl<double>(stages, n_stages, nv, out_channels, true, false));
     else b.reset(new BankImpl<float>(stages, n_stages, nv, out_channels, true, false));
     for (uint32_t s = 0; s < n_stages; ++s) {
-      uint32_t na = static_cast<uint32_t>(stage_n_ctor_args(stages[s].kind));
+      int na_i = stage_n_ctor_args(stages[s].kind);
+      uint32_t na = na_i > 0 ? static_cast<uint32_t>(na_i) : 0;
       if (na) b->set_ctor(s, 0, nv, ctor_args[s] + static_cast<size_t>(first[t]) * na, na);
     }
     if (b->init(sample_rate, block_size) != KNH_OK) return -1.0;

@@ -319,6 +319,57 @@ static void gpu_heterogeneous_voices_mix_on_device() {
   CHECK(worst <= 1e-5 && peak > 1e-3);
 }
 
+// Segment Envelopes of different lengths share one bank (constructor rows padded to the longest).
+static void gpu_segment_envelopes_of_ragged_length() {
+  const int B = 64, N = 40;
+  auto voices = c3_voices(N);
+  auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+  kno::Graph<float> ref(0, 2, B, 48000);
+  std::vector<Sig<float>::Parameter> trig;
+  std::vector<kno::NodeKey> ref_env;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int i = 0; i < N; ++i) {
+      const auto& v = voices[i];
+      std::vector<EnvelopeSegment> segs;
+      std::vector<kno::EnvelopeSegment> rsegs;
+      for (int k = 0; k < 1 + i % 4; ++k) {
+        segs.push_back({0.0008 * (k + 1) + v.atk * 0.01, k % 2 ? 0.1 : 1.0});
+        rsegs.emplace_back(segs.back().duration, segs.back().value);
+      }
+      auto s = g.push(SinWt(v.freq).wr_mul(v.gain));
+      auto e = g.push(Envelope(0.0, segs, 1.0 + 0.1 * (i % 3), i % 5 == 0));
+      (s * e).out({0, 0}).to_graph_out();
+      trig.push_back(e.param("t_restart"));
+      auto rs = ref.push(std::make_unique<kno::WrMath<float>>(std::make_unique<kno::SinWt<float>>(float(v.freq)), kno::WrOp::Mul, float(v.gain)));
+      auto env = std::make_unique<kno::Envelope<float>>(0.0, rsegs);
+      env->time_scale = 1.0 + 0.1 * (i % 3);
+      env->looping = i % 5 == 0;
+      auto re = ref.push(std::move(env));
+      auto m = ref.math_nodes(rs, 0, kno::MathOp::Mul, re, 0);
+      ref.connect_to_output(m, 0, 0, true); ref.connect_to_output(m, 0, 1, true);
+      ref_env.push_back(re);
+    }
+  });
+  ref.commit_changes();
+  CHECK(graph->num_banks() == 1);
+  for (auto& t : trig) t.trig();
+  for (auto k : ref_env) ref.set(k, 2, kno::ParameterValue::Trig());
+  std::vector<float> want(2 * B);
+  double worst = 0, peak = 0;
+  for (int block = 0; block < 8; ++block) {
+    processor->run_without_inputs();
+    ref.run({}, want.data());
+    auto out = processor->output_block();
+    for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < B; ++i) {
+        worst = std::max(worst, std::fabs(double(out.read(c, i)) - double(want[c * B + i])));
+        peak = std::max(peak, std::fabs(double(want[c * B + i])));
+      }
+  }
+  std::printf("  ragged Envelopes: max |gpu - reference-shaped graph| = %.3g (peak %.3g)\n", worst, peak);
+  CHECK(worst <= 1e-5 && peak > 1e-3);
+}
+
 int main(int argc, char** argv) {
   bool plan = false, gpu = false;
   for (int i = 1; i < argc; ++i) {
@@ -339,6 +390,7 @@ int main(int argc, char** argv) {
     RUN(gpu_voice_graph_matches_reference_shaped_graph);
     RUN(gpu_run_blocks_equals_block_by_block);
     RUN(gpu_heterogeneous_voices_mix_on_device);
+    RUN(gpu_segment_envelopes_of_ragged_length);
   }
   std::printf("%s (%d failures)\n", g_fail ? "HOST MIRROR FAILED" : "HOST MIRROR PASSED", g_fail);
   return g_fail ? 1 : 0;

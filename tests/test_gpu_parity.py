@@ -304,3 +304,56 @@ def test_smooth_params_block_rate_ramps(knh, oracle):
             bank.param_apply_many(v[1::3], 2, 0, KS, np.full(len(v[1::3]), 0.002), np.full(len(v[1::3]), 2, dtype=np.int64))
             bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, np.full(n, 0.5 / n))
     run_pair(knh, oracle, w, 12, ev, L.MIX_LEFT_FOLD)
+
+
+def _segment_envelope_args(n, n_max, rng, looping=False):
+    """[start, time_scale, looping, n_segments, (duration, value) * n_max] per voice; ragged segment counts."""
+    a = np.zeros((n, 4 + 2 * n_max))
+    a[:, 0] = rng.uniform(-0.5, 0.5, n)
+    a[:, 1] = rng.uniform(0.5, 2.0, n)
+    a[:, 2] = 1.0 if looping else 0.0
+    a[:, 3] = rng.integers(1, n_max + 1, n)
+    a[:, 4::2] = rng.uniform(0.0005, 0.004, (n, n_max))  # 24 .. 192 samples at 48 kHz
+    a[:, 5::2] = rng.uniform(-1.0, 1.0, (n, n_max))
+    return a
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+@pytest.mark.parametrize("looping", [False, True])
+def test_segment_envelope(knh, oracle, sample_type, looping):
+    """Envelope (envelopes.rs:359-527): f64 segment state, ragged segment counts, every parameter, done at frame 0."""
+    n, n_max = 100, 5
+    rng = np.random.default_rng(5)
+    p = configs.voice_parameters(n)
+    w = configs.Workload("segenv", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_MUL_ENVELOPE, delayed_changes_per_block=2)],
+                         n, 64, sample_type, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 1.0 / n), 2: _segment_envelope_args(n, n_max, rng, looping)}
+    v = np.arange(n, dtype=np.uint32)
+
+    def ev(block, bank):
+        if block == 1:
+            fire_all(bank, n, 2, 2)  # t_restart
+        if block == 3:  # t_stop mid-segment for a third of the voices, at a sample-accurate offset
+            sel = v[::3]
+            bank.param_apply_many(sel, 2, 3, L.VALUE_TRIGGER, delays=(sel % 64).astype(np.uint16))
+        if block == 4:  # jump (clamped to the last segment for most voices) and a new time_scale
+            bank.param_apply_many(v, 2, 1, L.VALUE_INTEGER, ivalues=(v % 7).astype(np.int64))
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, 0.25 + (v % 5) * 0.6)
+        if block == 9:
+            bank.param_apply_many(v[1::2], 2, 2, L.VALUE_TRIGGER, delays=np.full(n // 2, 33, dtype=np.uint16))
+    run_pair(knh, oracle, w, 14, ev, L.MIX_LEFT_FOLD)
+
+
+def test_segment_envelope_in_a_jit_fused_chain(knh, oracle):
+    n, n_max = 70, 3
+    rng = np.random.default_rng(11)
+    p = configs.voice_parameters(n)
+    w = configs.Workload("segenv_jit", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SVF), Stage(L.STAGE_MUL_ENVELOPE), Stage(L.STAGE_MUL_CONST)],
+                         n, 128, L.F32, 2)
+    svf = np.stack([np.full(n, float(L.SVF_LOW)), p["cutoff"], p["q"], np.zeros(n)], axis=1)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: svf, 2: _segment_envelope_args(n, n_max, rng), 3: np.full((n, 1), 1.0 / n)}
+
+    def ev(block, bank):
+        if block in (0, 5):
+            fire_all(bank, n, 2, 2)
+    run_pair(knh, oracle, w, 8, ev, L.MIX_LEFT_FOLD)
