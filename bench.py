@@ -78,11 +78,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the voice-bank path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    # KNH_BENCH_REHEARSE=1: several ranks share the visible GPUs and talk over gloo, to rehearse the N>1 control
+    # flow on a one-GPU box.  Never set for a measurement: the reported line then says "rehearsal".
+    rehearse = os.environ.get("KNH_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     nv, bs = args.voices_per_gpu, args.block_size
     # every rank owns a contiguous range of the global voice list: parameters are drawn for the whole
@@ -127,8 +135,10 @@ def main():
                 pending[half] = None
             schedule(first_step + done, k)
             bank.process_blocks_device(k, rings[half].data_ptr(), stream.cuda_stream)
-            if world > 1:
+            if world > 1 and not rehearse:
                 pending[half] = dist.reduce(rings[half][:k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            elif world > 1:  # gloo has no device-tensor reduce
+                pending[half] = dist.all_reduce(rings[half][:k], op=dist.ReduceOp.SUM, async_op=True)
             done += k
 
     def drain():
@@ -209,7 +219,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: ranks share GPUs, gloo; not a measurement)",
             "config": {
                 "workload": "C3: SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, stereo mix",
                 "voices_per_gpu": nv, "voices_total": total_voices, "block_size": bs, "sample_rate": 48000,
