@@ -96,8 +96,16 @@ typedef enum knh_value_kind {
  * KNH_STAGE_WR_MUL          previous_node.wr_mul(v)             wrappers_core/math.rs:15-113   0   v
  * KNH_STAGE_WR_ADD          previous_node.wr_add(v)             wrappers_core/math.rs:116-191  0   v
  * KNH_STAGE_WR_SUB          previous_node.wr_sub(v)             wrappers_core/math.rs:194-269  0   v
+ * KNH_STAGE_WR_VSUB         previous_node.wr_v_sub_gen(v)  v - x   wrappers_core/math.rs:272-348  0   v
+ * KNH_STAGE_WR_DIV          previous_node.wr_div(v)        x / v   wrappers_core/math.rs:351-426  0   v
+ * KNH_STAGE_WR_VDIV         previous_node.wr_v_div_gen(v)  v / x   wrappers_core/math.rs:429-505  0   v
+ * KNH_STAGE_WR_POWF         previous_node.wr_powf(v)       x.powf(v)  wrappers_core/math.rs:508-584  0   v
+ * KNH_STAGE_WR_POWI         previous_node.wr_powi(n)       x.powi(n)  wrappers_core/math.rs:587-661  0   n (i32)
+ * KNH_STAGE_POW_CONST       x.powf(c) (Constant + MathUGen Pow, math.rs:75-85)      2    c
  *     WrMul: params: 0 = the reference's "wr_mul" (index T::Parameters of the
- *     wrapped node, math.rs:69-98).  WrAdd/WrSub add no parameter.
+ *     wrapped node, math.rs:69-98).  No other wrapper adds a parameter.  POW_CONST: params: 0 value.
+ *     powi is the multiply-by-squaring loop of compiler-builtins (exact, bit-identical to the oracle);
+ *     powf runs the device libm: within a few ulp of the host's powf, never bit-exact by contract.
  */
 typedef enum knh_stage_kind {
   KNH_STAGE_SIN_WT = 0,
@@ -115,7 +123,13 @@ typedef enum knh_stage_kind {
   KNH_STAGE_WR_ADD = 12,
   KNH_STAGE_WR_SUB = 13,
   KNH_STAGE_MUL_ENVELOPE = 14,
-  KNH_STAGE_KIND_COUNT = 15
+  KNH_STAGE_WR_VSUB = 15,
+  KNH_STAGE_WR_DIV = 16,
+  KNH_STAGE_WR_VDIV = 17,
+  KNH_STAGE_WR_POWF = 18,
+  KNH_STAGE_WR_POWI = 19,
+  KNH_STAGE_POW_CONST = 20,
+  KNH_STAGE_KIND_COUNT = 21
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

@@ -53,7 +53,16 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* WR_ADD      */ {1, 0, 1, 0, 'a', {nullptr}},
     /* WR_SUB      */ {1, 0, 1, 0, 's', {nullptr}},
     /* MUL_ENVELOPE*/ {11, 4, -1, 2, 'V', {"time_scale", "jump_to_segment", "t_restart", "t_stop"}},  // n_ctor: 4 + 2 * n_max
+    /* WR_VSUB     */ {1, 0, 1, 0, 'v', {nullptr}},
+    /* WR_DIV      */ {1, 0, 1, 0, 'd', {nullptr}},
+    /* WR_VDIV     */ {1, 0, 1, 0, 'q', {nullptr}},
+    /* WR_POWF     */ {1, 0, 1, 0, 'p', {nullptr}},
+    /* WR_POWI     */ {1, 0, 1, 0, 'i', {nullptr}},
+    /* POW_CONST   */ {1, 1, 1, 2, 'p', {"value"}},
 };
+inline bool is_wrapper_kind(uint16_t kind) {
+  return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
+}
 
 // 0 float, 1 trigger, 2 integer : expected ParameterValue kind per (stage kind, param)
 int expected_value_kind(uint16_t kind, uint32_t param) {
@@ -416,6 +425,9 @@ struct Bank final : knh_bank {
               row[0] = dur; row[1] = 1.0 / dur; row[2] = val;  // EnvelopeSegment::new, envelopes.rs:327-333
             }
           } break;
+          case KNH_STAGE_WR_POWI:  // WrPowi::new(ugen, value: i32), wrappers_core/math.rs:591-595
+            slot(S.slot_base, v) = static_cast<W>(static_cast<uint32_t>(static_cast<int32_t>(a[0])));
+            break;
           default:  // Constant / wrapper value: util.rs:43-45, wrappers_core/math.rs:21-23
             slot(S.slot_base, v) = fw(static_cast<F>(a[0]));
             break;
@@ -1027,7 +1039,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ)) { *why = "SMOOTH_PARAMS and AR_FREQ cannot be combined"; return KNH_ERR_INVALID_ARGUMENT; }
-    if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && st[i].kind >= KNH_STAGE_WR_MUL) { *why = "SMOOTH_PARAMS applies to a node, not to a wrapper stage"; return KNH_ERR_INVALID_ARGUMENT; }
+    if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && is_wrapper_kind(st[i].kind)) { *why = "SMOOTH_PARAMS applies to a node, not to a wrapper stage"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
     if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }

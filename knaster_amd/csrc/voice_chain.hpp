@@ -17,6 +17,8 @@
 // Accurate (not v_sin_f32) sine from the ROCm device library, linked by hipcc and hiprtc alike.
 extern "C" __device__ float __ocml_sin_f32(float);
 extern "C" __device__ double __ocml_sin_f64(double);
+extern "C" __device__ float __ocml_pow_f32(float, float);
+extern "C" __device__ double __ocml_pow_f64(double, double);
 
 namespace knh_dev {
 
@@ -487,6 +489,8 @@ struct MulSegEnv {
 
 // x (op) value: Constant + MathUGen (util.rs:61-63, math.rs:22-85) and WrMul/WrAdd/WrSub
 // (wrappers_core/math.rs:62-67).  slot 0: value.  OP: 0 mul, 1 add, 2 sub, 3 div
+static __device__ __forceinline__ float dev_pow(float a, float b) { return __ocml_pow_f32(a, b); }
+static __device__ __forceinline__ double dev_pow(double a, double b) { return __ocml_pow_f64(a, b); }
 template <int OP>
 struct ValT {
   static constexpr int kSlots = 1;
@@ -504,7 +508,10 @@ struct ValT {
     if (OP == 0) return x * r.v;
     if (OP == 1) return x + r.v;
     if (OP == 2) return x - r.v;
-    return x / r.v;
+    if (OP == 3) return x / r.v;
+    if (OP == 4) return r.v - x;  // WrVSub, wrappers_core/math.rs:297-299
+    if (OP == 5) return r.v / x;  // WrVDiv, wrappers_core/math.rs:454-456
+    return dev_pow(x, r.v);       // WrPowf / MathUGen Pow: device libm, tolerance only
   }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
@@ -520,6 +527,45 @@ typedef ValT<0> MulVal;
 typedef ValT<1> AddVal;
 typedef ValT<2> SubVal;
 typedef ValT<3> DivVal;
+typedef ValT<4> VSubVal;
+typedef ValT<5> VDivVal;
+typedef ValT<6> PowVal;
+
+// x.powi(n): WrPowi (wrappers_core/math.rs:587-661).  f32::powi / f64::powi with a run-time exponent lower to
+// compiler-builtins' __powisf2 / __powidf2: multiply by squaring, reciprocal at the end for n < 0.  slot 0: n (i32)
+struct PowiVal {
+  static constexpr int kSlots = 1;
+  static constexpr u32 kMutableMask = 0u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  template <typename F> struct Regs { int n; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.n = (int)(u32)s[0]; }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32, u32&) {
+    u32 p = r.n < 0 ? 0u - (u32)r.n : (u32)r.n;
+    F a = x, m = (F)1;
+    for (;;) {
+      if (p & 1u) m *= a;
+      p >>= 1;
+      if (p == 0u) break;
+      a *= a;
+    }
+    return r.n < 0 ? (F)1 / m : m;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32, u64 bits, u32) {
+    if ((op & 0x7Fu) == EV_SET) r.n = (int)(u32)bits;
+  }
+};
 
 // ---------------------------------------------------------------------------
 // Chain = compile-time stage list with all registers inline.

@@ -99,6 +99,11 @@ struct UGenSpec {
   UGenSpec wr_mul(double v) && { wrappers.emplace_back(KNH_STAGE_WR_MUL, v); return std::move(*this); }
   UGenSpec wr_add(double v) && { wrappers.emplace_back(KNH_STAGE_WR_ADD, v); return std::move(*this); }
   UGenSpec wr_sub(double v) && { wrappers.emplace_back(KNH_STAGE_WR_SUB, v); return std::move(*this); }
+  UGenSpec wr_v_sub_gen(double v) && { wrappers.emplace_back(KNH_STAGE_WR_VSUB, v); return std::move(*this); }
+  UGenSpec wr_div(double v) && { wrappers.emplace_back(KNH_STAGE_WR_DIV, v); return std::move(*this); }
+  UGenSpec wr_v_div_gen(double v) && { wrappers.emplace_back(KNH_STAGE_WR_VDIV, v); return std::move(*this); }
+  UGenSpec wr_powf(double v) && { wrappers.emplace_back(KNH_STAGE_WR_POWF, v); return std::move(*this); }
+  UGenSpec wr_powi(int32_t n) && { wrappers.emplace_back(KNH_STAGE_WR_POWI, static_cast<double>(n)); return std::move(*this); }
   UGenSpec ar_params() && { ar_params_ = true; return std::move(*this); }
   UGenSpec smooth_params() && { smooth_params_ = true; return std::move(*this); }
   UGenSpec precise_timing(uint16_t max_changes_per_block) && { precise_timing_ = max_changes_per_block; return std::move(*this); }
@@ -175,6 +180,7 @@ class Sig {  // SH / DH of graph_edit.rs:266-277: one or more output channels of
   Sig operator+(double c) const { return g_->math_const(*this, KNH_STAGE_ADD_CONST, c); }
   Sig operator-(double c) const { return g_->math_const(*this, KNH_STAGE_SUB_CONST, c); }
   Sig operator/(double c) const { return g_->math_const(*this, KNH_STAGE_DIV_CONST, c); }
+  Sig pow(double c) const { return g_->math_const(*this, KNH_STAGE_POW_CONST, c); }  // graph_edit.rs:451 with a Constant
   Sig operator*(const Sig& o) const { return g_->math_sig(*this, o); }
   Sig operator>>(const Sig& sink) const { return g_->connect(*this, sink); }  // graph_edit.rs:1347-1417
   // .out([0,0]): the same channel twice (graph_edit.rs:280-292)

@@ -23,12 +23,15 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: return 2;
     case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: return 1;
     case KNH_STAGE_WR_MUL: case KNH_STAGE_WR_ADD: case KNH_STAGE_WR_SUB: return 1;
+    case KNH_STAGE_WR_VSUB: case KNH_STAGE_WR_DIV: case KNH_STAGE_WR_VDIV: case KNH_STAGE_WR_POWF: case KNH_STAGE_WR_POWI:
+    case KNH_STAGE_POW_CONST: return 1;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
 }
 inline bool stage_is_wrapper(uint16_t kind) {
-  return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB;
+  return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB ||
+         (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
 }
 
 // Where a (voice, stage) parameter lives in a built graph.
@@ -77,11 +80,13 @@ struct VoiceChainBuilder {
           core = std::move(e);
         } break;
         case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST:
+        case KNH_STAGE_POW_CONST:
           core = std::make_unique<Constant<F>>(fnew<F>(a[0]));
           break;
         default: throw std::runtime_error("unknown stage kind");
       }
-      const bool two_node = (st.kind >= KNH_STAGE_MUL_ENV_ASR && st.kind <= KNH_STAGE_DIV_CONST) || st.kind == KNH_STAGE_MUL_ENVELOPE;
+      const bool two_node = (st.kind >= KNH_STAGE_MUL_ENV_ASR && st.kind <= KNH_STAGE_DIV_CONST) || st.kind == KNH_STAGE_MUL_ENVELOPE ||
+                            st.kind == KNH_STAGE_POW_CONST;
       targets[s].n_params = core->parameters();
       if (st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ)) core = std::make_unique<WrArParams<F>>(std::move(core));
       if (st.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) {
@@ -96,6 +101,7 @@ struct VoiceChainBuilder {
         if (st.kind == KNH_STAGE_ADD_CONST) op = MathOp::Add;
         if (st.kind == KNH_STAGE_SUB_CONST) op = MathOp::Sub;
         if (st.kind == KNH_STAGE_DIV_CONST) op = MathOp::Div;
+        if (st.kind == KNH_STAGE_POW_CONST) op = MathOp::Pow;
         math = std::make_unique<MathUGen<F>>(1, op);
       }
       UGenPtr<F>& wrapped = two_node ? math : core;
@@ -103,8 +109,19 @@ struct VoiceChainBuilder {
       std::vector<std::pair<size_t, size_t>> wr_targets;  // (stage, param offset)
       while (s2 < stages.size() && stage_is_wrapper(stages[s2].kind)) {
         size_t off = wrapped->parameters();
-        WrOp op = stages[s2].kind == KNH_STAGE_WR_MUL ? WrOp::Mul : stages[s2].kind == KNH_STAGE_WR_ADD ? WrOp::Add : WrOp::Sub;
-        wrapped = std::make_unique<WrMath<F>>(std::move(wrapped), op, fnew<F>(args[s2][0]));
+        WrOp op = WrOp::Mul;
+        switch (stages[s2].kind) {
+          case KNH_STAGE_WR_ADD: op = WrOp::Add; break;
+          case KNH_STAGE_WR_SUB: op = WrOp::Sub; break;
+          case KNH_STAGE_WR_VSUB: op = WrOp::VSub; break;
+          case KNH_STAGE_WR_DIV: op = WrOp::Div; break;
+          case KNH_STAGE_WR_VDIV: op = WrOp::VDiv; break;
+          case KNH_STAGE_WR_POWF: op = WrOp::Powf; break;
+          case KNH_STAGE_WR_POWI: op = WrOp::Powi; break;
+          default: break;
+        }
+        if (op == WrOp::Powi) wrapped = std::make_unique<WrMath<F>>(std::move(wrapped), static_cast<int32_t>(args[s2][0]));
+        else wrapped = std::make_unique<WrMath<F>>(std::move(wrapped), op, fnew<F>(args[s2][0]));
         wr_targets.emplace_back(s2, off);
         ++s2;
       }

@@ -357,3 +357,34 @@ def test_segment_envelope_in_a_jit_fused_chain(knh, oracle):
         if block in (0, 5):
             fire_all(bank, n, 2, 2)
     run_pair(knh, oracle, w, 8, ev, L.MIX_LEFT_FOLD)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_remaining_math_wrappers_exact(knh, oracle, sample_type):
+    """WrVSub / WrDiv / WrVDiv / WrPowi (wrappers_core/math.rs:272-505, 587-661): + - * / only, so bit-exact.
+    powi exponents cover 0, 1, negative and large values (multiply-by-squaring order matters for the bits)."""
+    n = 80
+    p = configs.voice_parameters(n)
+    v = np.arange(n)
+    w = configs.Workload("wrappers", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_VSUB), Stage(L.STAGE_WR_DIV), Stage(L.STAGE_WR_POWI),
+                                      Stage(L.STAGE_WR_VDIV), Stage(L.STAGE_MUL_CONST)], n, 96, sample_type, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: (1.5 + 0.01 * v).reshape(n, 1), 2: (0.3 + 0.02 * v).reshape(n, 1),
+              3: ((v % 13) - 4).astype(np.float64).reshape(n, 1), 4: (2.0 + 0.1 * v).reshape(n, 1), 5: np.full((n, 1), 1e-3 / n)}
+    run_pair(knh, oracle, w, 3, None, L.MIX_LEFT_FOLD)
+
+
+def test_powf_wrapper_and_pow_node_within_tolerance(knh, oracle):
+    """WrPowf (wrappers_core/math.rs:508-584) and MathUGen Pow with a Constant (math.rs:75-85): device libm pow,
+    a few ulp from the host's powf -- tolerance, like SinNumeric."""
+    n = 64
+    p = configs.voice_parameters(n)
+    v = np.arange(n)
+    w = configs.Workload("powf", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_WR_ADD), Stage(L.STAGE_WR_POWF),
+                                  Stage(L.STAGE_POW_CONST), Stage(L.STAGE_MUL_CONST)], n, 128, L.F32, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.4), 2: np.full((n, 1), 1.0), 3: (0.5 + 0.05 * v).reshape(n, 1),
+              4: (1.0 + 0.02 * v).reshape(n, 1), 5: np.full((n, 1), 1.0 / n)}
+
+    def ev(block, bank):
+        if block == 1:
+            bank.param_apply_many(v.astype(np.uint32), 4, 0, L.VALUE_FLOAT, 2.0 - 0.01 * v)
+    run_pair(knh, oracle, w, 3, ev, voice_tol=2e-6)
