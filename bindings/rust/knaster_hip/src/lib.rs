@@ -1,0 +1,254 @@
+//! `GpuVoiceBank`: one Knaster node (`Inputs = U0`, `Outputs = U2`) that evaluates N independent voice
+//! chains on an MI355X through `libknaster_hip.so` (C ABI: `include/knaster_hip.h`).
+//!
+//! It implements `knaster_core::UGen` (knaster_core/src/ugen.rs:232-369) by forwarding every call of the
+//! audio thread to one FFI call.  Pushed like any UGen:
+//!
+//! ```ignore
+//! let bank = graph.edit(|g| { let b = g.push(GpuVoiceBank::<f32>::new(&chain, n, &ctor)?); b.to_graph_out(); b });
+//! ```
+//!
+//! It stands for the ~6·N nodes the same patch costs on the CPU (per voice: SinWt, SvfFilter, EnvAsr,
+//! MathUGen Mul, plus the MathUGen Add output chain, knaster_graph/src/graph.rs:827-872).
+//!
+//! ## Parameters
+//! A bank holds N voices × S stages × up to `MAX_PARAMS` parameters; `UGen::Parameters` is a compile-time
+//! typenum and the graph stores it as `u16` (`node.data.parameters`, graph.rs:1368), so the bank declares
+//! `Parameters = U0` and is addressed through a *flat index*
+//! `index = (voice * S + stage) * MAX_PARAMS + param`.  The audio-thread path does not bound-check indices
+//! (`apply_parameter_change`, graph_gen.rs:269-305 → `DynUGen::param_apply`, dynugen.rs:99-101), and neither does
+//! the typed `Handle<T>` returned by `Graph::push` (graph.rs:370) for `Param::Index` (`HandleTrait::set`,
+//! handle.rs:218-222).  `graph.set(node, index, ..)` (graph.rs:1368) and `GraphEdit`'s `Parameter` (a `u16`
+//! index checked against `Parameters::USIZE`, graph_edit.rs:769-781) do check, and therefore cannot reach a bank:
+//!
+//! ```ignore
+//! let i = bank.index(voice, stage, "cutoff_freq")?;     // before the bank is moved into the graph
+//! let handle = graph.push(bank);
+//! handle.set((i, 800.0))?;
+//! ```
+//!
+//! Lifting that restriction needs one of two small changes on the Knaster side: widen `Parameter::param_index`
+//! to `usize`, or let a UGen report its parameter count at run time (`DynUGen::parameters()` instead of the
+//! typenum).  Neither touches the audio path.
+//!
+//! ## Realtime
+//! `process_block` blocks on a stream sync and a 4-KiB device-to-host copy: use it under the non-realtime
+//! driver (`AudioProcessor::run_without_inputs` in a loop, processor.rs:142-179).  It never allocates.
+//!
+//! NOT compiled in this repository's build image (no Rust toolchain); see bindings/rust/README.md.
+#![allow(clippy::missing_safety_doc)]
+
+use core::ffi::c_void;
+use core::marker::PhantomData;
+
+use knaster_core::{
+    AudioCtx, Block, BlockRead, Float, Frame, ParameterHint, ParameterSmoothing, ParameterValue, Rate, UGen, UGenFlags,
+    numeric_array::NumericArray,
+    rt_log,
+    typenum::{U0, U2},
+};
+
+pub mod ffi;
+use ffi::*;
+
+/// Upper bound of parameters per stage (SvfFilter has 5: svf.rs:244-270).
+pub const MAX_PARAMS: usize = 5;
+
+/// One stage of a voice chain (`knh_stage_desc`); the table of kinds is in `include/knaster_hip.h`.
+pub type Stage = knh_stage_desc;
+
+pub fn stage(kind: u16) -> Stage {
+    Stage { kind, flags: 0, delayed_changes_per_block: 0, reserved: 0 }
+}
+pub trait StageExt {
+    /// `.precise_timing::<N>()` on the stage's node (wrappers_core.rs:106-111)
+    fn precise_timing(self, max_changes_per_block: u16) -> Self;
+    /// `.ar_params()` + `.link("freq", running_signal)` (SinWt only)
+    fn ar_freq(self) -> Self;
+    /// `.smooth_params()` (wrappers_core.rs:63-65)
+    fn smooth_params(self) -> Self;
+}
+impl StageExt for Stage {
+    fn precise_timing(mut self, n: u16) -> Self {
+        self.delayed_changes_per_block = n;
+        self
+    }
+    fn ar_freq(mut self) -> Self {
+        self.flags |= KNH_STAGE_FLAG_AR_FREQ;
+        self
+    }
+    fn smooth_params(mut self) -> Self {
+        self.flags |= KNH_STAGE_FLAG_SMOOTH_PARAMS;
+        self
+    }
+}
+
+#[derive(Debug)]
+pub struct BankError(pub String);
+impl core::fmt::Display for BankError {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        write!(f, "knaster_hip: {}", self.0)
+    }
+}
+impl std::error::Error for BankError {}
+
+fn last_error(h: *const knh_bank) -> BankError {
+    BankError(unsafe { std::ffi::CStr::from_ptr(knh_last_error(h)) }.to_string_lossy().into_owned())
+}
+
+pub struct GpuVoiceBank<F: Float> {
+    h: *mut knh_bank,
+    n_stages: usize,
+    n_voices: u32,
+    _f: PhantomData<F>,
+}
+// knaster requires `Node: Send` (knaster_graph/src/node.rs:194).  The handle is single-caller: the graph moves
+// it between threads (control thread at push, audio thread afterwards, control thread again for the drop,
+// task.rs:105-130) but never shares it.
+unsafe impl<F: Float> Send for GpuVoiceBank<F> {}
+
+impl<F: Float> GpuVoiceBank<F> {
+    /// `ctor[stage]` = row-major `[n_voices][n_args]` constructor arguments (`SinWt::new(freq)` → `[freq]`,
+    /// `SvfFilter::new(ty, cutoff, q, gain)` → `[ty as f64, cutoff, q, gain]`, ...; table in knaster_hip.h).
+    pub fn new(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>]) -> Result<Self, BankError> {
+        let desc = knh_bank_desc {
+            abi_version: KNH_ABI_VERSION,
+            n_voices,
+            sample_type: if core::mem::size_of::<F>() == 8 { KNH_F64 } else { KNH_F32 },
+            n_stages: stages.len() as u32,
+            stages: stages.as_ptr(),
+            out_channels: 2,
+            mix_mode: KNH_MIX_TREE,
+            device: -1,
+            allow_fma: 0,
+        };
+        let mut h = core::ptr::null_mut();
+        if unsafe { knh_bank_create(&desc, &mut h) } != KNH_OK {
+            return Err(last_error(core::ptr::null()));
+        }
+        for (s, args) in ctor.iter().enumerate() {
+            let n_args = (args.len() / n_voices as usize) as u32;
+            if n_args > 0 && unsafe { knh_bank_set_ctor_args(h, s as u32, 0, n_voices, args.as_ptr(), n_args) } != KNH_OK {
+                let e = last_error(h);
+                unsafe { knh_bank_destroy(h) };
+                return Err(e);
+            }
+        }
+        Ok(Self { h, n_stages: stages.len(), n_voices, _f: PhantomData })
+    }
+
+    /// Flat parameter index of (`voice`, `stage`, parameter name), e.g. `"cutoff_freq"`, `"t_restart"`, `"wr_mul"`.
+    pub fn index(&self, voice: u32, stage: usize, name: &str) -> Result<usize, BankError> {
+        if voice >= self.n_voices || stage >= self.n_stages {
+            return Err(BankError("voice or stage out of range".into()));
+        }
+        let n = unsafe { knh_bank_stage_parameters(self.h, stage as u32) } as usize;
+        for p in 0..n {
+            let d = unsafe { knh_bank_stage_param_description(self.h, stage as u32, p as u32) };
+            if !d.is_null() && unsafe { std::ffi::CStr::from_ptr(d) }.to_bytes() == name.as_bytes() {
+                return Ok(flat_index(voice as usize, self.n_stages, stage, p));
+            }
+        }
+        Err(BankError(format!("DescriptionNotFound({name})"))) // ParameterError::DescriptionNotFound, ugen.rs:365
+    }
+    /// The number of reference UGen nodes one voice of this chain stands for (the unit of UGen-samples/s).
+    pub fn ugens_per_voice(stages: &[Stage]) -> i32 {
+        unsafe { knh_chain_ugen_count(stages.as_ptr(), stages.len() as u32) }
+    }
+    /// Offline rendering: `n_blocks` consecutive blocks in one launch (events of those blocks must already be
+    /// scheduled through `knh_bank_param_apply_many_at`).  `out` = `[n_blocks][2][block_size]`.
+    pub fn process_blocks(&mut self, n_blocks: u32, frame_clock: u64, out: &mut [F]) -> Result<u32, BankError> {
+        let mut flags = 0u32;
+        let rc = unsafe { knh_bank_process_blocks(self.h, n_blocks, frame_clock, out.as_mut_ptr() as *mut c_void, &mut flags) };
+        if rc != KNH_OK { Err(last_error(self.h)) } else { Ok(flags) }
+    }
+    pub fn raw(&self) -> *mut knh_bank {
+        self.h
+    }
+    #[inline]
+    fn split(&self, index: usize) -> (u32, u32, u32) {
+        let (param, rest) = (index % MAX_PARAMS, index / MAX_PARAMS);
+        ((rest / self.n_stages) as u32, (rest % self.n_stages) as u32, param as u32)
+    }
+}
+
+#[inline]
+pub const fn flat_index(voice: usize, n_stages: usize, stage: usize, param: usize) -> usize {
+    (voice * n_stages + stage) * MAX_PARAMS + param
+}
+
+impl<F: Float> Drop for GpuVoiceBank<F> {
+    fn drop(&mut self) {
+        unsafe { knh_bank_destroy(self.h) }
+    }
+}
+
+impl<F: Float> UGen for GpuVoiceBank<F> {
+    type Sample = F;
+    type Inputs = U0;
+    type Outputs = U2;
+    type Parameters = U0; // addressed through the flat index (module docs)
+
+    // graph.rs:462-475 calls init on the control thread at push time; allocating is allowed (ugen.rs:242-246)
+    fn init(&mut self, sample_rate: u32, block_size: usize) {
+        if unsafe { knh_bank_init(self.h, sample_rate, block_size) } != KNH_OK {
+            log::error!("{}", last_error(self.h));
+        }
+    }
+
+    fn process(&mut self, ctx: &mut AudioCtx, _flags: &mut UGenFlags, _input: Frame<F, U0>) -> Frame<F, U2> {
+        // A bank is only ever run block-wise (as GraphGen itself, graph_gen.rs:241-249).
+        rt_log!(ctx.logger(); "knaster_hip: GpuVoiceBank::process called; only process_block is supported");
+        Frame::default()
+    }
+
+    fn process_block<InBlock, OutBlock>(&mut self, ctx: &mut AudioCtx, flags: &mut UGenFlags, _input: &InBlock, output: &mut OutBlock)
+    where
+        InBlock: BlockRead<Sample = F> + ?Sized,
+        OutBlock: Block<Sample = F> + ?Sized,
+    {
+        // RawContiguousBlock is channel-major and contiguous (knaster_graph/src/block.rs:19-78): the start of
+        // channel 0 is the base of [2][block_size].  The library writes frames
+        // [block_start_offset, block_start_offset + frames_to_process) of both channels.
+        let out = output.channel_as_slice_mut(0).as_mut_ptr() as *mut c_void;
+        let mut f = 0u32;
+        let rc = unsafe {
+            knh_bank_process_block(self.h, ctx.frames_to_process(), ctx.block_start_offset(), ctx.frame_clock(), out, &mut f)
+        };
+        if rc != KNH_OK {
+            rt_log!(ctx.logger(); "knaster_hip: process_block failed, status ", rc as f64);
+        }
+        if f & KNH_FLAG_ALL_DONE != 0 {
+            flags.mark_done(0); // every voice's envelope has stopped: the bank as a whole is done (done.rs:33-45)
+        }
+    }
+
+    fn param_hints() -> NumericArray<ParameterHint, U0> {
+        NumericArray::default()
+    }
+
+    fn param_apply(&mut self, ctx: &mut AudioCtx, index: usize, value: ParameterValue) {
+        let (voice, stage, param) = self.split(index);
+        let (kind, f, i) = match value {
+            ParameterValue::Float(v) => (KNH_VALUE_FLOAT, v as f64, 0),
+            ParameterValue::Trigger => (KNH_VALUE_TRIGGER, 0.0, 0),
+            ParameterValue::Integer(v) => (KNH_VALUE_INTEGER, 0.0, v.0 as i64),
+            ParameterValue::Bool(b) => (KNH_VALUE_BOOL, 0.0, b as i64),
+            // needs KNH_STAGE_FLAG_SMOOTH_PARAMS on the stage (WrSmoothParams, smooth_params.rs:12-311)
+            ParameterValue::Smoothing(ParameterSmoothing::None, _) => (KNH_VALUE_SMOOTHING, 0.0, 0),
+            ParameterValue::Smoothing(ParameterSmoothing::Linear(s), Rate::BlockRate) => (KNH_VALUE_SMOOTHING, s as f64, 1),
+            ParameterValue::Smoothing(ParameterSmoothing::Linear(s), Rate::AudioRate) => (KNH_VALUE_SMOOTHING, s as f64, 2),
+        };
+        if unsafe { knh_bank_param_apply(self.h, voice, stage, param, kind, f, i) } != KNH_OK {
+            rt_log!(ctx.logger(); "knaster_hip: param_apply rejected, index ", index as f64);
+        }
+    }
+
+    // GraphGen::apply_parameter_change (graph_gen.rs:269-305) calls this first when the event's Time gives
+    // 0 < delay < block_size, then param_apply: the same pair the C ABI mirrors, so `param.set_at(v, Time::..)`
+    // is sample accurate for stages declared with `.precise_timing(n)`.
+    fn set_delay_within_block_for_param(&mut self, _ctx: &mut AudioCtx, index: usize, delay: u16) {
+        let (voice, stage, param) = self.split(index);
+        unsafe { knh_bank_set_delay_within_block_for_param(self.h, voice, stage, param, delay) };
+    }
+}

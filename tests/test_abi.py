@@ -111,3 +111,51 @@ def test_workload_inputs_are_deterministic():
     w = configs.config("C3")
     assert (w.n_voices, w.block_size, w.sample_type) == (16384, 512, L.F32)
     assert abs(float(w.ctor[1].sum()) - 1.0) < 1e-9  # sum of gains = 1
+
+
+def _header_decls():
+    """name -> number of arguments, from the header's function declarations."""
+    text = open(os.path.join(ROOT, "include", "knaster_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for name, args in re.findall(r"\b(knh_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        args = args.strip()
+        out[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def _header_constants():
+    text = open(os.path.join(ROOT, "include", "knaster_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    vals = {}
+    for name, v in re.findall(r"\b(KNH_[A-Z0-9_]+)\s*=\s*(1u\s*<<\s*[0-9]+|[0-9]+)", text):
+        vals[name] = eval(v.replace("u", ""))
+    vals["KNH_ABI_VERSION"] = int(re.search(r"#define KNH_ABI_VERSION (\d+)", text).group(1))
+    return vals
+
+
+def test_rust_ffi_matches_header():
+    """bindings/rust/knaster_hip/src/ffi.rs cannot be compiled here (no rustc): keep it honest by comparing every
+    declared function (name, argument count) and every constant with include/knaster_hip.h."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "knaster_hip", "src", "ffi.rs")).read()
+    rust_fns = {}
+    for name, args in re.findall(r"pub fn (knh_[a-z0-9_]+)\(([^)]*)\)", src):
+        args = args.strip()
+        rust_fns[name] = 0 if not args else args.count(":")
+    assert rust_fns == _header_decls()
+    rust_consts = {n: eval(v) for n, v in re.findall(r"pub const (KNH_[A-Z0-9_]+): [iu](?:16|32) = ([0-9]+|1 << [0-9]+);", src)}
+    header = _header_constants()
+    assert rust_consts, "no constants parsed"
+    for name, value in rust_consts.items():
+        assert header.get(name) == value, f"{name}: ffi.rs {value} vs header {header.get(name)}"
+    for name in header:
+        assert name in rust_consts, f"{name} missing from ffi.rs"
+    # struct layouts: field order of the two repr(C) structs
+    text = open(os.path.join(ROOT, "include", "knaster_hip.h")).read()
+    for struct in ("knh_stage_desc", "knh_bank_desc"):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        c_fields = re.findall(r"\b([a-z_]+)\s*;", body)
+        r_body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, src, flags=re.S).group(1)
+        r_fields = re.findall(r"pub ([a-z_]+):", r_body)
+        assert c_fields == r_fields, struct
