@@ -199,10 +199,45 @@ struct Svf {
       return r.m0 * v0 + r.m1 * v1 + r.m2 * v2;
     }
   }
+  // f32, exact arithmetic: the same fifteen roundings as tick(), issued as ten instructions.  Independent
+  // pairs share a packed instruction -- (a1*ic1, a2*ic1), (a2*v3, a3*v3), (v1, v2), (ic1', ic2'), (m1*v1, m2*v2) --
+  // with the state kept in aligned register pairs so that no moves are needed.  A wavefront alone on its SIMD is
+  // issue-bound (tools/micro/valu_issue.hip: a packed f32 op costs 1.2x a scalar one and does two), so the
+  // instruction count of this loop is the block time of the filter wave.  The one scalar add that feeds the high
+  // half of a pair goes through `asm` only to stop the vectoriser from widening it into pk_add + mov.
+  template <int T>
+  static __device__ __forceinline__ void tick_tile_packed(Regs<float>& r, float (&x)[T]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 ic = {r.ic1, r.ic2};
+    const f2 a12 = {r.a1, r.a2}, a23 = {r.a2, r.a3}, m12 = {r.m1, r.m2}, two = {2.0f, 2.0f};
+    const float m0 = r.m0;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const float v3 = x[j] - ic.y;
+      f2 p1 = a12 * ic.xx;                  // (a1*ic1, a2*ic1)
+      const f2 p2 = a23 * (f2){v3, v3};     // (a2*v3, a3*v3)
+      float u;
+      asm("v_add_f32 %0, %1, %2" : "=v"(u) : "v"(ic.y), "v"(p1.y));  // ic2 + a2*ic1
+      p1.y = u;
+      const f2 v = p1 + p2;                 // (v1, v2)
+      ic = __builtin_elementwise_fma(v, two, -ic);  // 2*v - ic: exact product, one rounding (see tick)
+      const f2 q = m12 * v;
+      // (m0*x + m1*v1) + m2*v2; scalar on purpose: paired across samples these two adds cost three moves
+      float o = m0 * x[j];
+      asm("v_add_f32 %0, %1, %2" : "=v"(o) : "v"(o), "v"(q.x));
+      asm("v_add_f32 %0, %1, %2" : "=v"(o) : "v"(o), "v"(q.y));
+      x[j] = o;
+    }
+    r.ic1 = ic.x; r.ic2 = ic.y;
+  }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    if constexpr (sizeof(F) == 4 && !FMA) {
+      tick_tile_packed<T>(r, x);
+    } else {
 #pragma unroll
-    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+      for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+    }
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
@@ -348,12 +383,48 @@ struct MulEnvT {
 #pragma unroll
     for (int j = 0; j < T; ++j) e[j] = env_next<F>(r, frame0 + j, done_frame);
   }
+  // x[j] *= envelope, T samples at once.  The tile is first run under the assumption that no lane changes state
+  // inside it, as straight-line code with no per-sample select: in a tile without Releasing lanes every lane's
+  // envelope is its t (lanes that are not Attacking hold t = 1 or 0 with step 0); in a tile without Attacking
+  // lanes it is (t*(t*t))*scale (holding lanes use t = scale = 1 or 0, which gives exactly 1 or 0).  t moves by
+  // a constant step, so the sequence is monotone and a threshold is crossed inside the tile iff it is crossed at
+  // its first or its last sample.  If any lane would change state (or Attacking and Releasing lanes share the
+  // tile) the exact per-sample state machine runs instead, from the untouched registers.  Same values either way.
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx&, u32 frame0, u32& done_frame) {
-    F e[T];
-    env_tile<F, T>(r, e, frame0, done_frame);
+    const u32 st = r.state;
+    const bool isA = st == 1u, isR = st == 3u;
+    const bool anyA = __builtin_amdgcn_ballot_w64(isA) != 0, anyR = __builtin_amdgcn_ballot_w64(isR) != 0;
+    const F konst = st == 2u ? (F)1 : (F)0;
+    if (!anyA && !anyR) {  // every lane Sustaining or Stopped
 #pragma unroll
-    for (int j = 0; j < T; ++j) x[j] = x[j] * e[j];
+      for (int j = 0; j < T; ++j) x[j] = x[j] * konst;
+      return;
+    }
+    if (!(anyA && anyR)) {
+      const bool moving = isA || isR;
+      const F step = isA ? r.ar : (isR ? -r.rr : (F)0);  // t - rr == t + (-rr) exactly
+      const F scale = isR ? r.scale : konst;
+      F t = moving ? r.t : konst;
+      F tt[T];
+#pragma unroll
+      for (int j = 0; j < T; ++j) { tt[j] = t; t = t + step; }
+      const F t1 = T > 1 ? tt[1] : t;
+      const bool hit = isA ? (t1 >= (F)1 || t >= (F)1) : (isR ? (t1 <= (F)0 || t <= (F)0) : false);
+      if (__builtin_amdgcn_ballot_w64(hit) == 0) {
+        if (anyR) {
+#pragma unroll
+          for (int j = 0; j < T; ++j) x[j] = x[j] * ((tt[j] * (tt[j] * tt[j])) * scale);
+        } else {
+#pragma unroll
+          for (int j = 0; j < T; ++j) x[j] = x[j] * tt[j];
+        }
+        if (moving) r.t = t;
+        return;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = x[j] * env_next<F>(r, frame0 + j, done_frame);
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 frame) {

@@ -92,9 +92,15 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   const int n_tiles = tpb * (int)a.n_blocks;
   const int n_steps = n_tiles + NG;
   int blk = 0, ti = 0;                                      // position of this group's next tile
+#ifdef KNH_DAG_STAMPS  // diagnostic build only: cycles this wavefront is busy per tile (tools/pipe_stamps.py)
+  u64 busy = 0, busy_in = 0, busy_out = 0;
+#endif
   for (int s = 0; s < n_steps; ++s) {
     const int g = s - I;
     if (g >= 0 && g < n_tiles) {
+#ifdef KNH_DAG_STAMPS
+      const u64 t0 = __builtin_amdgcn_s_memtime();
+#endif
       if (ti == 0) chain.begin_block(a.frame_begin, ctx);
       const u32 n = a.frame_begin + (u32)ti * T;
       const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
@@ -116,6 +122,11 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
         for (int j = 0; j < T; ++j) x[j] = (F)0;
       }
       const bool ev_inside = next_frame < base + n + T;
+#ifdef KNH_DAG_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const u64 t1 = __builtin_amdgcn_s_memtime();
+      busy_in += t1 - t0;
+#endif
       if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev_inside)) {
         chain.template tick_tile<T>(x, ctx, n, done_frame);
       } else {
@@ -124,6 +135,10 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
           x[j] = chain.tick(x[j], ctx, n + j, done_frame);
         }
       }
+#ifdef KNH_DAG_STAMPS
+      asm volatile("" ::: "memory");
+      const u64 t2 = __builtin_amdgcn_s_memtime();
+#endif
       if (I < NG - 1) {
         typedef typename EdgeLayout<F>::Vec Vec;
         constexpr int VW = EdgeLayout<F>::VW;
@@ -148,9 +163,22 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
         ++blk;
         base += a.block_size;
       }
+#ifdef KNH_DAG_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const u64 t3 = __builtin_amdgcn_s_memtime();
+      busy += t3 - t0;
+      busy_out += t3 - t2;
+#endif
     }
     __syncthreads();
   }
+#ifdef KNH_DAG_STAMPS
+  if (blockIdx.x == 0 && lane == 0) {
+    const u64 d = (u64)(n_tiles > 0 ? n_tiles : 1);
+    a.flags[4 + I] = (u32)(busy / d);
+    if (8 + 2 * I + 1 < 16) { a.flags[8 + 2 * I] = (u32)(busy_in / d); a.flags[9 + 2 * I] = (u32)(busy_out / d); }
+  }
+#endif
   if (live) chain.store(a.state + voice, a.stride);
   if (GroupInfo<G>::has_env) {
     const bool any_done = live && done_frame != 0xFFFFFFFFu;
@@ -179,9 +207,15 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
   const int n_steps = n_tiles + NG;
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   int blk = 0, ti = 0;
+#ifdef KNH_DAG_STAMPS
+  u64 busy = 0;
+#endif
   for (int s = 0; s < n_steps; ++s) {
     const int g = s - NG;  // the tile the last chain group finished in the previous step
     if (g >= 0 && g < n_tiles) {
+#ifdef KNH_DAG_STAMPS
+      const u64 t0 = __builtin_amdgcn_s_memtime();
+#endif
       const u32 rel_end = (u32)(ti + 1) * T < n_frames ? (u32)(ti + 1) * T : n_frames;  // frames of this block written so far
       if (rel_end % TN == 0 || ti == tpb - 1) {
         const u32 q = ((u32)ti * T) / TN;
@@ -214,9 +248,16 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
         }
       }
       if (++ti == tpb) { ti = 0; ++blk; }
+#ifdef KNH_DAG_STAMPS
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      busy += __builtin_amdgcn_s_memtime() - t0;
+#endif
     }
     __syncthreads();
   }
+#ifdef KNH_DAG_STAMPS
+  if (blockIdx.x == 0 && lane == 0) a.flags[4 + NG] = (u32)(busy / (u64)(n_tiles > 0 ? n_tiles : 1));
+#endif
 }
 
 template <typename F, bool FMA, int NG, int I, int BASE, int LAST_ENV, typename G, typename... Rest>

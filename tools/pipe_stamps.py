@@ -1,0 +1,29 @@
+"""Busy cycles per 32-sample tile of every wavefront of the default pipeline kernel (C3).
+Needs the diagnostic build: KNH_BUILD_STAMPS=1 python -m knaster_amd.build --force"""
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+import numpy as np
+
+import knaster_amd
+from knaster_amd import _lib as L, configs
+
+w = configs.config("C3")
+b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, 2, L.MIX_TREE)
+for s, a in w.ctor.items():
+    b.set_ctor_args(s, a)
+b.init(48000, 512)
+v = np.arange(w.n_voices, dtype=np.uint32)
+b.param_apply_many(v, 3, 3, L.VALUE_TRIGGER)
+for phase in ["attack (blocks 0-8)", "sustain (8-16)"]:
+    b.process_blocks(8)
+    print(phase, "busy cycles per tile [osc+gain, svf, env, mixer]:", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
+b.param_apply_many(v, 3, 2, L.VALUE_TRIGGER)
+b.process_blocks(8)
+print("release", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
+b.process_blocks(32)
+print("stopped", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
+b.timing_reset(True)
+b.process_blocks(64)
+print("kernel ms for 64 blocks", b.timing_read())
