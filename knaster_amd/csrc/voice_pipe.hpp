@@ -41,8 +41,7 @@ template <typename F> struct EdgeLayout {
 };
 template <typename F> struct PipeShared {
   float* sine;
-  F* edge;  // [n_edges][2][64][EdgeLayout<F>::stride]
-  F* mix;   // [2][TN][TS]
+  F* edge;  // [NG][2][64][EdgeLayout<F>::stride]; edge i carries group i's output, the last one to the mixer
 };
 
 // One stage group = one wavefront.  I: group index, NG: number of chain groups (mixer excluded),
@@ -52,8 +51,6 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   typedef typename GroupChain<F, FMA, BASE, G>::type ChainT;
   typedef typename WordOf<F>::type W;
   constexpr int T = PipeTile<F>::value;
-  constexpr int TN = sizeof(F) == 4 ? 64 : 32;
-  constexpr int TS = 68;
   constexpr u32 SLOT_LO = (u32)BASE, SLOT_HI = (u32)(BASE + GroupInfo<G>::slots);
 
   Ctx ctx;
@@ -88,7 +85,6 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   // The pipeline runs continuously over all blocks of the launch: global tile g = (block, tile in block).
   const u32 n_frames = a.frame_end - a.frame_begin;
   const int tpb = (int)((n_frames + T - 1) / T);           // tiles per block
-  const int qpb = (int)((n_frames + TN - 1) / TN);         // mix tiles per block
   const int n_tiles = tpb * (int)a.n_blocks;
   const int n_steps = n_tiles + NG;
   int blk = 0, ti = 0;                                      // position of this group's next tile
@@ -135,11 +131,7 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
           x[j] = chain.tick(x[j], ctx, n + j, done_frame);
         }
       }
-#ifdef KNH_DAG_STAMPS
-      asm volatile("" ::: "memory");
-      const u64 t2 = __builtin_amdgcn_s_memtime();
-#endif
-      if (I < NG - 1) {
+      {  // every group, the last one included, hands its tile on as 64 rows of T samples (16-byte LDS stores)
         typedef typename EdgeLayout<F>::Vec Vec;
         constexpr int VW = EdgeLayout<F>::VW;
         Vec* out = reinterpret_cast<Vec*>(sh.edge + (long)(I * 2 + (g & 1)) * EdgeLayout<F>::tile + (long)lane * EdgeLayout<F>::stride);
@@ -150,13 +142,11 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
           for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
           out[j] = v;
         }
-      } else {  // last chain group: column write into the transposed mix tile
-        const u32 rel = (u32)ti * T;
-        const u32 qg = (u32)blk * (u32)qpb + rel / TN;  // global mix-tile counter: double-buffer parity
-        F* out = sh.mix + ((long)(qg & 1u) * TN + (rel % TN)) * TS + lane;
-#pragma unroll
-        for (int j = 0; j < T; ++j) out[j * TS] = x[j];
       }
+#ifdef KNH_DAG_STAMPS
+      asm volatile("" ::: "memory");
+      const u64 t2 = __builtin_amdgcn_s_memtime();
+#endif
       if (++ti == tpb) {  // block finished for this group
         apply_events_upto(base + a.frame_end);  // changes due exactly at the end (precise_timing.rs:85-103)
         ti = 0;
@@ -193,16 +183,17 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   }
 }
 
-// The mixer wavefront: lane j folds frame j of a finished mix tile over the wave's voices in voice order.
+// The mixer wavefront: lane j folds frame j of the tile the last chain group finished in the previous step over
+// the wave's voices, in voice order (a left fold, like the reference's chain of Add nodes over those voices).
+// The tile is stored voice-major ([voice][T], the common edge format), so a read of one voice's row by lanes
+// 0..T-1 is conflict-free and the transposition costs nothing.
 template <typename F, int NG>
 __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global,
                                                u32 v0, u32 nv) {
   constexpr int T = PipeTile<F>::value;
-  constexpr int TN = sizeof(F) == 4 ? 64 : 32;
-  constexpr int TS = 68;
+  constexpr int ST = EdgeLayout<F>::stride;
   const u32 n_frames = a.frame_end - a.frame_begin;
   const int tpb = (int)((n_frames + T - 1) / T);
-  const int qpb = (int)((n_frames + TN - 1) / TN);
   const int n_tiles = tpb * (int)a.n_blocks;
   const int n_steps = n_tiles + NG;
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
@@ -216,35 +207,30 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
 #ifdef KNH_DAG_STAMPS
       const u64 t0 = __builtin_amdgcn_s_memtime();
 #endif
-      const u32 rel_end = (u32)(ti + 1) * T < n_frames ? (u32)(ti + 1) * T : n_frames;  // frames of this block written so far
-      if (rel_end % TN == 0 || ti == tpb - 1) {
-        const u32 q = ((u32)ti * T) / TN;
-        const u32 qg = (u32)blk * (u32)qpb + q;
-        const u32 len = rel_end - q * TN;
-        const F* my = sh.mix + (long)(qg & 1u) * TN * TS;
-        const u32 n0 = a.frame_begin + q * TN;
-        if ((u32)lane < len) {
-          const F* row = my + (long)lane * TS;
-          F acc;
-          if (nv == 64u) {
+      const u32 rel = (u32)ti * T;
+      const u32 len = n_frames - rel < (u32)T ? n_frames - rel : (u32)T;
+      const u32 n0 = a.frame_begin + rel;
+      const F* tile = sh.edge + (long)((NG - 1) * 2 + (g & 1)) * EdgeLayout<F>::tile;
+      if ((u32)lane < len) {
+        const F* col = tile + lane;
+        F acc;
+        if (nv == 64u) {
 #pragma unroll
-            for (int vb = 0; vb < 64; vb += 16) {
-              F t[16];
+          for (int vb = 0; vb < 64; vb += 16) {
+            F t[16];
 #pragma unroll
-              for (int k = 0; k < 16; ++k) t[k] = row[vb + k];
-              if (vb == 0) acc = t[0];
+            for (int k = 0; k < 16; ++k) t[k] = col[(vb + k) * ST];
+            if (vb == 0) acc = t[0];
 #pragma unroll
-              for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
-            }
-          } else {
-            acc = row[0];
-            for (u32 v = 1; v < nv; ++v) acc = acc + row[v];
+            for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
           }
-          a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
+        } else {
+          acc = col[0];
+          for (u32 v = 1; v < nv; ++v) acc = acc + col[v * ST];
         }
+        a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
         if (a.voices_out) {
-          for (u32 v = 0; v < nv; ++v)
-            if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[(long)lane * TS + v];
+          for (u32 v = 0; v < nv; ++v) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = col[v * ST];
         }
       }
       if (++ti == tpb) { ti = 0; ++blk; }
@@ -283,12 +269,9 @@ __global__ void __launch_bounds__((sizeof...(Gs) + 1) * 64) voice_pipe_kernel(Vo
   constexpr int NG = (int)sizeof...(Gs);
   constexpr int WAVES = NG + 1;
   constexpr int T = PipeTile<F>::value;
-  constexpr int TN = sizeof(F) == 4 ? 64 : 32;
-  constexpr int TS = 68;
   constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
   __shared__ float sine[kSine ? 16384 : 1];
-  __shared__ __attribute__((aligned(16))) F edge[(NG > 1 ? NG - 1 : 1) * 2 * EdgeLayout<F>::tile];
-  __shared__ __attribute__((aligned(16))) F mix[2 * TN * TS];
+  __shared__ __attribute__((aligned(16))) F edge[NG * 2 * EdgeLayout<F>::tile];  // the last edge feeds the mixer
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -306,7 +289,6 @@ __global__ void __launch_bounds__((sizeof...(Gs) + 1) * 64) voice_pipe_kernel(Vo
   PipeShared<F> sh;
   sh.sine = sine;
   sh.edge = edge;
-  sh.mix = mix;
   const u32 wave_global = blockIdx.x;  // one 64-voice wavefront-group per workgroup
   const u32 v0 = wave_global * 64u;
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
