@@ -97,10 +97,7 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
 #ifdef KNH_DAG_STAMPS
       const u64 t0 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ti == 0) chain.begin_block(a.frame_begin, ctx);
-      const u32 n = a.frame_begin + (u32)ti * T;
-      const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
-      apply_events_upto(base + n);
+      // the tile's LDS reads go out first, so that their latency runs under the block/event bookkeeping below
       F x[T];
       if (I > 0) {
         typedef typename EdgeLayout<F>::Vec Vec;
@@ -117,6 +114,10 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
 #pragma unroll
         for (int j = 0; j < T; ++j) x[j] = (F)0;
       }
+      if (ti == 0) chain.begin_block(a.frame_begin, ctx);
+      const u32 n = a.frame_begin + (u32)ti * T;
+      const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
+      apply_events_upto(base + n);
       const bool ev_inside = next_frame < base + n + T;
 #ifdef KNH_DAG_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

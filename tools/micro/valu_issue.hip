@@ -34,6 +34,26 @@ __global__ void k(float* out, int iters) {
     } else if (MODE == 6) {  // packed, pairs
 #pragma unroll
       for (int u = 0; u < 16; ++u) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[u & 1]) : "v"(pb));
+    } else if (MODE == 9) {  // scalar, independent, an s_nop 0 after every instruction
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_mul_f32 %0, %0, %1\n\ts_nop 0" : "+v"(a[u & 7]) : "v"(b));
+    } else if (MODE == 10) {  // packed dependent with the s_nop 0 the hazard recogniser inserts
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_pk_mul_f32 %0, %0, %1\n\ts_nop 0" : "+v"(p[0]) : "v"(pb));
+    } else if (MODE == 11) {  // 10-instruction SVF-like mix: 5 packed + 5 scalar, one dependent chain of 4
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        asm volatile(
+            "v_sub_f32 %0, %4, %1\n\t"
+            "v_pk_mul_f32 %2, %6, %3\n\t"
+            "v_mul_f32 %5, %4, %4\n\t"
+            "v_pk_mul_f32 %3, %6, %2\n\t"
+            "v_add_f32 %4, %4, %5\n\t"
+            "v_pk_add_f32 %2, %2, %3\n\t"
+            "v_add_f32 %5, %5, %4\n\t"
+            "v_pk_fma_f32 %3, %2, %6, %3\n\t"
+            : "+v"(a[0]), "+v"(a[1]), "+v"(p[0]), "+v"(p[1]), "+v"(a[2]), "+v"(a[3]) : "v"(pb));
+      }
     } else if (MODE == 7) {  // f64 mul dependent
       double d = a[0];
 #pragma unroll
@@ -71,7 +91,7 @@ void run(const char* name, float* d, int waves) {
 int main() {
   float* d;
   (void)hipMalloc(&d, 256 * 1024 * 4);
-  for (int waves : {1, 4, 8}) {
+  for (int waves : {1, 8}) {
     run<0>("v_mul_f32 dependent", d, waves);
     run<5>("v_mul_f32 two chains", d, waves);
     run<1>("v_mul_f32 eight chains", d, waves);
@@ -79,6 +99,9 @@ int main() {
     run<2>("v_pk_mul_f32 dependent", d, waves);
     run<6>("v_pk_mul_f32 two chains", d, waves);
     run<3>("v_pk_mul_f32 eight chains", d, waves);
+    run<9>("v_mul_f32 eight chains + s_nop 0", d, waves);
+    run<10>("v_pk_mul_f32 dependent + s_nop 0", d, waves);
+    run<11>("8-instr pk/scalar mix (per instr)", d, waves);
     run<7>("v_mul_f64 dependent", d, waves);
     run<8>("v_mul_f64 eight chains", d, waves);
   }
