@@ -102,6 +102,11 @@ typedef enum knh_value_kind {
  * KNH_STAGE_WR_POWF         previous_node.wr_powf(v)       x.powf(v)  wrappers_core/math.rs:508-584  0   v
  * KNH_STAGE_WR_POWI         previous_node.wr_powi(n)       x.powi(n)  wrappers_core/math.rs:587-661  0   n (i32)
  * KNH_STAGE_POW_CONST       x.powf(c) (Constant + MathUGen Pow, math.rs:75-85)      2    c
+ * KNH_STAGE_SAMPLE_DELAY    x >> g.push(SampleDelay::new(Seconds::from_secs_f64(max_delay)))   delay.rs:14-50   1   max_delay (s)
+ *     params: 0 delay_time (seconds; delay_samples = (seconds * sample_rate) as usize).  The ring holds
+ *     (Seconds::to_secs_f64() * sample_rate) as usize samples per voice, in HBM.  A delay_time longer than the ring
+ *     is refused with KNH_ERR_OUT_OF_RANGE (the reference indexes out of bounds there); a zero-length ring fails init.
+ *     At most one per chain.
  *     WrMul: params: 0 = the reference's "wr_mul" (index T::Parameters of the
  *     wrapped node, math.rs:69-98).  No other wrapper adds a parameter.  POW_CONST: params: 0 value.
  *     powi is the multiply-by-squaring loop of compiler-builtins (exact, bit-identical to the oracle);
@@ -129,7 +134,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_WR_POWF = 18,
   KNH_STAGE_WR_POWI = 19,
   KNH_STAGE_POW_CONST = 20,
-  KNH_STAGE_KIND_COUNT = 21
+  KNH_STAGE_SAMPLE_DELAY = 21,
+  KNH_STAGE_KIND_COUNT = 22
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

@@ -59,6 +59,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* WR_POWF     */ {1, 0, 1, 0, 'p', {nullptr}},
     /* WR_POWI     */ {1, 0, 1, 0, 'i', {nullptr}},
     /* POW_CONST   */ {1, 1, 1, 2, 'p', {"value"}},
+    /* SAMPLE_DELAY*/ {4, 1, 1, 1, 'D', {"delay_time"}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -258,6 +259,9 @@ struct Bank final : knh_bank {
   float* d_sine = nullptr;
   double* d_seg_table = nullptr;  // segment Envelope: [voice][seg_max][3]
   uint32_t seg_max = 0;
+  void* d_delay = nullptr;        // SampleDelay rings: [voice][delay_stride] of F
+  uint32_t delay_stride = 0;
+  std::vector<uint32_t> delay_len;  // ring length per voice (samples)
   std::vector<double> env_start;  // Envelope::start_value per voice (t_restart restores it)
   std::vector<uint32_t> env_nseg;
   uint32_t* d_ev_start = nullptr;
@@ -285,7 +289,7 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_ev_start, d_events, d_partials, d_out, d_voices, d_done, d_flags};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_ev_start, d_events, d_partials, d_out, d_voices, d_done, d_flags};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
     void* host_ptrs[] = {h_ev_start, h_events, h_out};
@@ -425,6 +429,24 @@ struct Bank final : knh_bank {
               row[0] = dur; row[1] = 1.0 / dur; row[2] = val;  // EnvelopeSegment::new, envelopes.rs:327-333
             }
           } break;
+          case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:24-31 (new), :45-49 (init)
+            if (v == 0) delay_len.assign(nv, 0u);
+            // Seconds::from_secs_f64 / to_secs_f64 (knaster_primitives/src/time.rs:59-74), then `as usize`
+            const double secs_in = a[0];
+            if (!(secs_in >= 0.0) || secs_in >= 4294967296.0) return fail(KNH_ERR_INVALID_ARGUMENT, "SampleDelay: max delay out of range");
+            const uint32_t whole = static_cast<uint32_t>(std::floor(secs_in));
+            const uint32_t tes = sat_u32((secs_in - std::floor(secs_in)) * 282240000.0);
+            const double secs = static_cast<double>(whole) + static_cast<double>(tes) / 282240000.0;
+            const double nf = secs * static_cast<double>(sr);
+            if (!(nf >= 1.0)) return fail(KNH_ERR_INVALID_ARGUMENT, "SampleDelay: the ring would be empty (the reference divides by zero)");
+            if (nf >= 1073741824.0) return fail(KNH_ERR_INVALID_ARGUMENT, "SampleDelay: max delay too long");
+            const uint32_t len = static_cast<uint32_t>(nf);
+            delay_len[v] = len;
+            slot(S.slot_base + 0, v) = 0;    // write_position
+            slot(S.slot_base + 1, v) = len;  // len - delay_samples, delay_samples = 0
+            slot(S.slot_base + 2, v) = len;
+            slot(S.slot_base + 3, v) = v;
+          } break;
           case KNH_STAGE_WR_POWI:  // WrPowi::new(ugen, value: i32), wrappers_core/math.rs:591-595
             slot(S.slot_base, v) = static_cast<W>(static_cast<uint32_t>(static_cast<int32_t>(a[0])));
             break;
@@ -444,6 +466,17 @@ struct Bank final : knh_bank {
       for (int i = 0; i < 16384; ++i) table[i] = static_cast<float>(std::sin((static_cast<double>(i) / 16384.0) * PI * 2.0));
       KNH_HIP(hipMalloc(&d_sine, 16384 * sizeof(float)));
       KNH_HIP(hipMemcpy(d_sine, table.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (!delay_len.empty()) {
+      uint32_t mx = 0;
+      for (uint32_t l : delay_len) mx = std::max(mx, l);
+      delay_stride = (mx + 3u) & ~3u;
+      const size_t bytes = static_cast<size_t>(nv) * delay_stride * sizeof(F);
+      size_t free_b = 0, total_b = 0;
+      KNH_HIP(hipMemGetInfo(&free_b, &total_b));
+      if (bytes > free_b) return fail(KNH_ERR_DEVICE, "SampleDelay: the delay rings do not fit in device memory");
+      KNH_HIP(hipMalloc(&d_delay, bytes));
+      KNH_HIP(hipMemset(d_delay, 0, bytes));  // vec![F::ZERO; len]
     }
     if (!seg_rows.empty()) {
       KNH_HIP(hipMalloc(&d_seg_table, seg_rows.size() * sizeof(double)));
@@ -656,6 +689,16 @@ struct Bank final : knh_bank {
           set(0, 1);  // t_restart: state = Attacking, t untouched (envelopes.rs:47-49,131-133)
         }
         break;
+      case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:33-36: delay_samples = (seconds * sample_rate) as usize
+        const double ds = f * static_cast<double>(sample_rate);
+        const uint32_t len = delay_len[v];
+        if (!(ds < static_cast<double>(len) + 1.0)) {  // the reference would read outside its buffer
+          warn("SampleDelay: delay_time longer than the ring, change ignored");
+          break;
+        }
+        const uint32_t d = ds > 0.0 ? static_cast<uint32_t>(ds) : 0u;  // NaN and negatives -> 0, as `as usize` does
+        set(1, len - d);
+      } break;
       case KNH_STAGE_MUL_ENVELOPE: {  // envelopes.rs:478-524
         auto set2 = [&](int rel, double d) {
           uint64_t b = to_bits(d);
@@ -892,6 +935,8 @@ struct Bank final : knh_bank {
     a.f2pi = f2pi;
     a.seg_table = d_seg_table;
     a.seg_max = seg_max;
+    a.delay_ring = d_delay;
+    a.delay_stride = delay_stride;
     a.ev_start = have_events ? d_ev_start : nullptr;
     a.events = d_events;
     a.partials = d_partials;
@@ -1043,6 +1088,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
     if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (st[i].kind == KNH_STAGE_SAMPLE_DELAY && sig->find('D') != std::string::npos) { *why = "at most one SampleDelay stage per chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if (st[i].kind == KNH_STAGE_MUL_ENVELOPE && sig->find('V') != std::string::npos) { *why = "at most one Envelope stage per chain"; return KNH_ERR_INVALID_ARGUMENT; }
     sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
     have_x = true;
@@ -1292,6 +1338,7 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: w += word; break;
       case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: w += word * 3; break;
       case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
+      case KNH_STAGE_SAMPLE_DELAY: w += word; break;  // + one sample read and one written per frame (ring in HBM)
       default: break;
     }
   }

@@ -68,6 +68,8 @@ struct Ctx {
   double f2pi;              // SinWt::freq_to_phase_inc (osc.rs:144-145)
   const double* seg_table;  // segment Envelope: [voice][seg_max][3] = (duration, 1/duration, value)
   u32 seg_max;
+  void* delay_ring;         // SampleDelay: [voice][delay_stride] samples of F, each voice's ring contiguous
+  u32 delay_stride;
 };
 
 // ---------------------------------------------------------------------------
@@ -580,6 +582,86 @@ struct MulSegEnv {
   }
 };
 
+// SampleDelay -- delay.rs:14-50.  process: buffer[wp] = x; out = buffer[(wp + len - delay) % len]; wp = (wp + 1) % len.
+// Each voice's ring is a contiguous run of HBM ([voice][delay_stride]); slots: 0 write_position, 1 off = len - delay_samples
+// (0..len), 2 len, 3 the voice's ring row.  A tile whose reads cannot meet its own writes (delay >= T) and that does not
+// cross the end of the ring moves its T samples with 16-byte loads, then 16-byte stores; any other tile runs sample by
+// sample in the reference's order (store, then load).
+struct SampleDelay {
+  static constexpr int kSlots = 4;
+  static constexpr u32 kMutableMask = 0b1u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = true;
+  template <typename F> struct Regs { u32 wp, off, len, row; F* ring; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.wp = (u32)s[0]; r.off = (u32)s[st]; r.len = (u32)s[2 * st]; r.row = (u32)s[3 * st];
+    r.ring = nullptr;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void bind(Regs<F>& r, const Ctx& c) {
+    if (r.ring == nullptr) r.ring = reinterpret_cast<F*>(c.delay_ring) + (long)r.row * c.delay_stride;
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = (W)r.wp; }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx& c, u32, u32&) {
+    bind<F>(r, c);
+    if (r.len == 0u) return x;  // a lane past the last voice (its state words are zero): no memory access
+    r.ring[r.wp] = x;
+    u32 rp = r.wp + r.off;  // < 2 * len
+    if (rp >= r.len) rp -= r.len;
+    // the sample just stored is forwarded from the register (delay 0 or len); anything else comes from memory
+    const F y = rp == r.wp ? x : r.ring[rp];
+    r.wp = r.wp + 1u == r.len ? 0u : r.wp + 1u;
+    return y;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    bind<F>(r, c);
+    constexpr int VW = 16 / (int)sizeof(F);
+    typedef F Vec __attribute__((ext_vector_type(VW), aligned(sizeof(F))));
+    u32 rp = r.wp + r.off;
+    if (rp >= r.len) rp -= r.len;
+    // delay >= T  <=>  off <= len - T;  neither the T stores nor the T loads may cross the end of the ring
+    const bool dead = r.len == 0u;  // a lane past the last voice: takes part in nothing
+    const bool vec_ok = dead || (r.len >= (u32)T && r.off <= r.len - (u32)T && r.wp <= r.len - (u32)T && rp <= r.len - (u32)T);
+    if (__builtin_amdgcn_ballot_w64(!vec_ok) == 0) {
+      if (!dead) {
+        F y[T];
+        const Vec* src = reinterpret_cast<const Vec*>(r.ring + rp);
+#pragma unroll
+        for (int j = 0; j < T / VW; ++j) {
+          const Vec v = src[j];
+#pragma unroll
+          for (int k = 0; k < VW; ++k) y[j * VW + k] = v[k];
+        }
+        Vec* dst = reinterpret_cast<Vec*>(r.ring + r.wp);
+#pragma unroll
+        for (int j = 0; j < T / VW; ++j) {
+          Vec v;
+#pragma unroll
+          for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
+          dst[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) x[j] = y[j];
+        r.wp = r.wp + (u32)T == r.len ? 0u : r.wp + (u32)T;
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    if (rel == 1) r.off = (u32)bits;
+    else if (rel == 0) r.wp = (u32)bits;
+  }
+};
+
 // x (op) value: Constant + MathUGen (util.rs:61-63, math.rs:22-85) and WrMul/WrAdd/WrSub
 // (wrappers_core/math.rs:62-67).  slot 0: value.  OP: 0 mul, 1 add, 2 sub, 3 div
 static __device__ __forceinline__ float dev_pow(float a, float b) { return __ocml_pow_f32(a, b); }
@@ -729,6 +811,8 @@ struct VoiceKernelArgs {
   double f2pi;
   const double* seg_table;          // segment Envelope table [n_voices][seg_max][3], or null
   u32 seg_max;
+  void* delay_ring;                 // SampleDelay rings [n_voices][delay_stride] of F, or null
+  u32 delay_stride;
   const u32* ev_start;              // [n_voices + 1] or null when the block has no events
   const Event* events;
   F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its 64 voices
@@ -774,6 +858,8 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ctx.f2pi = a.f2pi;
   ctx.seg_table = a.seg_table;
   ctx.seg_max = a.seg_max;
+  ctx.delay_ring = a.delay_ring;
+  ctx.delay_stride = a.delay_stride;
 
   const u32 wave_global = blockIdx.x * WAVES + wave;
   const u32 v0 = wave_global * 64u;

@@ -58,6 +58,8 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   ctx.f2pi = a.f2pi;
   ctx.seg_table = a.seg_table;
   ctx.seg_max = a.seg_max;
+  ctx.delay_ring = a.delay_ring;
+  ctx.delay_stride = a.delay_stride;
   const bool live = (u32)lane < nv;
   const u32 voice = live ? v0 + lane : v0 + nv - 1;
   ChainT chain;

@@ -115,6 +115,8 @@ inline UGenSpec SvfFilter(SvfFilterType ty, double cutoff, double q, double gain
 }
 inline UGenSpec OnePoleLpf(double cutoff) { return UGenSpec(KNH_STAGE_ONEPOLE_LPF, {cutoff}); }
 inline UGenSpec OnePoleHpf() { return UGenSpec(KNH_STAGE_ONEPOLE_HPF, {}); }
+// SampleDelay::new(Seconds::from_secs_f64(max_delay_seconds)) -- delay.rs:24-31
+inline UGenSpec SampleDelay(double max_delay_seconds) { return UGenSpec(KNH_STAGE_SAMPLE_DELAY, {max_delay_seconds}); }
 inline UGenSpec EnvAsr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_ASR, {attack, release}); s.is_env = true; return s; }
 inline UGenSpec EnvAr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_AR, {attack, release}); s.is_env = true; return s; }
 // Envelope::new(start_value, segments).time_scale(..).looping(..) -- envelopes.rs:373-400
@@ -232,7 +234,9 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
   static const char* ar[] = {"attack_time", "release_time", "t_restart"};
   static const char* val[] = {"value"};
   static const char* seg[] = {"time_scale", "jump_to_segment", "t_restart", "t_stop"};
+  static const char* dly[] = {"delay_time"};
   switch (kind) {
+    case KNH_STAGE_SAMPLE_DELAY: *n = 1; return dly;
     case KNH_STAGE_MUL_ENVELOPE: *n = 4; return seg;
     case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: *n = 3; return sin;
     case KNH_STAGE_SVF: *n = 5; return svf;

@@ -103,6 +103,9 @@ struct Seconds {
         (samples % sample_rate) * static_cast<uint64_t>(SUBSECOND_TESIMALS_PER_SECOND) / sample_rate);
     return r;
   }
+  double to_secs_f64() const {  // time.rs:71-74
+    return static_cast<double>(seconds) + (static_cast<double>(subsecond_tesimals) / static_cast<double>(SUBSECOND_TESIMALS_PER_SECOND));
+  }
   uint64_t to_samples(uint64_t sample_rate) const {  // time.rs:86-90
     return static_cast<uint64_t>(seconds) * sample_rate +
            (static_cast<uint64_t>(subsecond_tesimals) * sample_rate) /
@@ -874,6 +877,40 @@ struct Envelope : UGen<F> {
         break;
       default: break;
     }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// SampleDelay -- knaster_core_dsp/src/ugens/delay.rs:14-50
+// ---------------------------------------------------------------------------
+template <typename F>
+struct SampleDelay : UGen<F> {
+  std::vector<F> buffer;
+  size_t write_position = 0, delay_samples = 0;
+  Seconds max_delay_length;
+  explicit SampleDelay(Seconds max_delay) : max_delay_length(max_delay) {}
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"delay_time"}; }
+  void init(uint32_t sample_rate, size_t) override {  // :45-49
+    buffer.assign(static_cast<size_t>(max_delay_length.to_secs_f64() * static_cast<double>(sample_rate)), F(0));
+    write_position = 0;
+  }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override {  // :37-44
+    buffer[write_position] = in[0];
+    out[0] = buffer[(write_position + buffer.size() - delay_samples) % buffer.size()];
+    write_position = (write_position + 1) % buffer.size();
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {  // :33-36
+    if (index != 0) { ctx.rt_log("Unknown parameter set for SampleDelay"); return; }
+    const double d = v.float_or_panic() * static_cast<double>(ctx.sample_rate());
+    const size_t n = d > 0.0 ? (d >= 18446744073709551615.0 ? SIZE_MAX : static_cast<size_t>(d)) : 0;  // `as usize` saturates
+    if (n > buffer.size()) {  // the reference's index arithmetic would underflow here; the product ignores the change
+      ctx.rt_log("SampleDelay: delay_time longer than the buffer, ignored");
+      return;
+    }
+    delay_samples = n;
   }
 };
 

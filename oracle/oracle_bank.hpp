@@ -24,7 +24,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: return 1;
     case KNH_STAGE_WR_MUL: case KNH_STAGE_WR_ADD: case KNH_STAGE_WR_SUB: return 1;
     case KNH_STAGE_WR_VSUB: case KNH_STAGE_WR_DIV: case KNH_STAGE_WR_VDIV: case KNH_STAGE_WR_POWF: case KNH_STAGE_WR_POWI:
-    case KNH_STAGE_POW_CONST: return 1;
+    case KNH_STAGE_POW_CONST: case KNH_STAGE_SAMPLE_DELAY: return 1;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -67,6 +67,7 @@ struct VoiceChainBuilder {
           break;
         case KNH_STAGE_ONEPOLE_LPF: core = std::make_unique<OnePoleLpf<F>>(fnew<F>(a[0])); break;
         case KNH_STAGE_ONEPOLE_HPF: core = std::make_unique<OnePoleHpf<F>>(); break;
+        case KNH_STAGE_SAMPLE_DELAY: core = std::make_unique<SampleDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_MUL_ENV_ASR: core = std::make_unique<EnvAsr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
         case KNH_STAGE_MUL_ENV_AR: core = std::make_unique<EnvAr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
         case KNH_STAGE_MUL_ENVELOPE: {

@@ -388,3 +388,55 @@ def test_powf_wrapper_and_pow_node_within_tolerance(knh, oracle):
         if block == 1:
             bank.param_apply_many(v.astype(np.uint32), 4, 0, L.VALUE_FLOAT, 2.0 - 0.01 * v)
     run_pair(knh, oracle, w, 3, ev, voice_tol=2e-6)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_sample_delay_ring_in_hbm(knh, oracle, sample_type):
+    """SampleDelay (delay.rs:14-50): per-voice rings of different lengths, delays of 0, 1, just below / at / above the
+    tile length, half the ring, the whole ring; wrap-around of both pointers; delay changes at block starts and at
+    sample-accurate offsets; a delay longer than the ring is ignored on both sides."""
+    n, bs = 96, 64
+    p = configs.voice_parameters(n)
+    v = np.arange(n, dtype=np.uint32)
+    w = configs.Workload("delay", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_SAMPLE_DELAY, delayed_changes_per_block=2),
+                                   Stage(L.STAGE_MUL_CONST)], n, bs, sample_type, 2)
+    max_delay = 0.002 + 0.0001 * (v % 40)  # 96 .. 283 samples at 48 kHz, through Seconds::from_secs_f64
+    ring = np.array([int((int(np.floor(s)) + int((s - np.floor(s)) * 282240000.0) / 282240000.0) * 48000.0) for s in max_delay])
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.5), 2: max_delay.reshape(n, 1), 3: np.full((n, 1), 1.0 / n)}
+    kinds = [0, 1, 5, 15, 16, 17, 31, 32, 33, -2, -1, -3]  # samples; negative: relative to the ring length (-1 = whole ring)
+
+    def delay_samples(shift):
+        k = np.array([kinds[(i + shift) % len(kinds)] for i in range(n)])
+        d = np.where(k >= 0, k, ring + 1 + k)
+        d = np.where(k == -3, ring // 2, d)
+        return np.minimum(d, ring)
+
+    def ev(block, bank):
+        if block == 0:
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, (delay_samples(0) + 0.25) / 48000.0)
+        if block == 5:
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, (delay_samples(3) + 0.25) / 48000.0)
+        if block == 7:  # sample-accurate change inside the block; every third voice asks for more than its ring holds
+            too_long = (ring + 2.5) / 48000.0
+            want = np.where(v % 3 == 0, too_long, (delay_samples(7) + 0.25) / 48000.0)
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, want, delays=(v % bs).astype(np.uint16))
+    run_pair(knh, oracle, w, 12, ev, L.MIX_LEFT_FOLD)
+
+
+def test_sample_delay_multi_block_launch_equals_single_blocks(knh):
+    n, bs, blocks = 200, 128, 6
+    p = configs.voice_parameters(n)
+    w = configs.Workload("delay_mb", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SVF), Stage(L.STAGE_SAMPLE_DELAY), Stage(L.STAGE_MUL_CONST)],
+                         n, bs, L.F32, 2)
+    svf = np.stack([np.full(n, float(L.SVF_LOW)), p["cutoff"], p["q"], np.zeros(n)], axis=1)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: svf, 2: np.full((n, 1), 0.0101), 3: np.full((n, 1), 1.0 / n)}
+    d = (np.arange(n) * 7 % 480) / 48000.0 + 1e-6
+    a = make_gpu(knh, w)
+    b = make_gpu(knh, w)
+    for bank in (a, b):
+        bank.param_apply_many(np.arange(n, dtype=np.uint32), 2, 0, L.VALUE_FLOAT, d)
+    one = np.stack([a.process_block()[0] for _ in range(blocks)])
+    many, _ = b.process_blocks(blocks)
+    assert_bit_equal(np.asarray(many).reshape(one.shape), one, "multi-block launch with a delay stage")
+    a.close()
+    b.close()
