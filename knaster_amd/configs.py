@@ -67,6 +67,7 @@ class Workload:
     restart: tuple = ()  # (stage, param) trigger fired on every voice before block 0
     release: tuple = ()  # (stage, param, block) trigger fired on every voice before `block`
     description: str = ""
+    delay_times: np.ndarray = None  # D3: per-voice SampleDelay delay_time set before block 0 (stage 3, param 0)
 
 
 def config(name: str, n_voices: int | None = None, block_size: int | None = None, sample_type: int | None = None,
@@ -74,7 +75,8 @@ def config(name: str, n_voices: int | None = None, block_size: int | None = None
     """name in {"C1".."C5"}; sizes default to the BASELINE.json values."""
     name = name.upper()
     defaults = {"C1": (1, 64, L.F32), "C2": (1024, 256, L.F32), "C3": (16384, 512, L.F32),
-                "C4": (65536, 512, L.F64), "C5": (4096, 128, L.F32)}
+                "C4": (65536, 512, L.F64), "C5": (4096, 128, L.F32),
+                "D3": (16384, 512, L.F32)}
     nv, bs, st = defaults[name]
     nv = n_voices or nv
     bs = block_size or bs
@@ -98,6 +100,15 @@ def config(name: str, n_voices: int | None = None, block_size: int | None = None
         w.ctor = {0: col(p["freq"]), 1: col(gain), 2: svf, 3: np.stack([p["attack"], p["release"]], axis=1)}
         w.restart = (3, 3)
         w.release = (3, 2, 32)
+    elif name == "D3":  # not a BASELINE.json config: C3 with a SampleDelay behind the filter (per-voice rings in HBM)
+        w = Workload(name, [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_SVF), Stage(L.STAGE_SAMPLE_DELAY),
+                            Stage(L.STAGE_MUL_ENV_ASR, delayed_changes_per_block=precise)], nv, bs, st,
+                     description="SinWt.wr_mul(1/N) -> SvfFilter(Low) -> SampleDelay(0.25 s) -> * EnvAsr")
+        svf = np.stack([np.full(nv, float(L.SVF_LOW)), p["cutoff"], p["q"], np.zeros(nv)], axis=1)
+        w.ctor = {0: col(p["freq"]), 1: col(gain), 2: svf, 3: col(np.full(nv, 0.25)), 4: np.stack([p["attack"], p["release"]], axis=1)}
+        w.restart = (4, 3)
+        w.release = (4, 2, 32)
+        w.delay_times = 0.01 + 0.2 * (p["q"] - 0.5) / 3.5  # 10 .. 210 ms, different per voice
     elif name == "C5":  # modulator SinWt * index + carrier_freq -> carrier SinWt.ar_params() "freq"; * gain
         pr = precise or 4
         w = Workload(name, [Stage(L.STAGE_SIN_WT, delayed_changes_per_block=pr), Stage(L.STAGE_MUL_CONST),

@@ -42,6 +42,7 @@ static const KernelEntry kEntries[] = {
     KNH_CHAIN("NSAm", SinNum, Svf, MulAsr, MulVal),
     KNH_CHAIN("Wasd", SinWt, AddVal, SubVal, DivVal),
     KNH_CHAIN("WmV", SinWt, MulVal, MulSegEnv),                 // SinWt.wr_mul * segment Envelope
+    KNH_CHAIN("WmSDA", SinWt, MulVal, Svf, SampleDelay, MulAsr), // C3 with a delay line behind the filter (HBM-bound regime)
 };
 
 template <typename F, bool FMA, typename... Gs>
@@ -64,6 +65,7 @@ typedef Group<MulAsr, MulVal> G_Am;
 typedef Group<MulVal> G_m;
 typedef Group<SinWt, MulVal, AddVal> G_Wma;
 typedef Group<SinWtAr, MulVal> G_Rm;
+typedef Group<SampleDelay, MulAsr> G_DA;
 
 static const PipeEntry kPipes[] = {
     KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope (+ mixer wave)
@@ -73,6 +75,7 @@ static const PipeEntry kPipes[] = {
     KNH_PIPE("WmaRm", 2, G_Wma, G_Rm),     // C5: modulator | carrier
     KNH_PIPE("Nm", 2, G_N, G_m),           // C2
     KNH_PIPE("NSAm", 3, G_N, G_S, G_Am),
+    KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA),  // the delay's HBM traffic rides in the envelope wave
 };
 const PipeEntry* find_pipe(const char* signature) {
   for (const PipeEntry& e : kPipes)
@@ -116,6 +119,7 @@ static const WideEntry kWides[] = {
     KNH_WIDE("Wm", SinWt, MulVal),
     KNH_WIDE("Nm", SinNum, MulVal),
     KNH_WIDE("WmSA", SinWt, MulVal, Svf, MulAsr),
+    KNH_WIDE("WmSDA", SinWt, MulVal, Svf, SampleDelay, MulAsr),
     KNH_WIDE("WSAm", SinWt, Svf, MulAsr, MulVal),
     KNH_WIDE("WmE", SinWt, MulVal, MulAr),
     KNH_WIDE("WmaRm", SinWt, MulVal, AddVal, SinWtAr, MulVal),

@@ -440,3 +440,18 @@ def test_sample_delay_multi_block_launch_equals_single_blocks(knh):
     assert_bit_equal(np.asarray(many).reshape(one.shape), one, "multi-block launch with a delay stage")
     a.close()
     b.close()
+
+
+def test_c3_with_delay_line_against_oracle(knh, oracle):
+    """The D3 bench chain (C3 with a SampleDelay behind the filter) on the pipelined kernel, per voice bit for bit."""
+    w = configs.config("D3", n_voices=130, block_size=128)
+    w.ctor[3] = np.full((130, 1), 0.02)  # 960-sample rings keep the oracle run short and make the pointers wrap
+    v = np.arange(130, dtype=np.uint32)
+
+    def ev(block, bank):
+        if block == 0:
+            bank.param_apply_many(v, 4, 3, L.VALUE_TRIGGER)
+            bank.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times * 0.09)
+        if block == 6:
+            bank.param_apply_many(v, 4, 2, L.VALUE_TRIGGER)
+    run_pair(knh, oracle, w, 12, ev, L.MIX_LEFT_FOLD)

@@ -30,6 +30,10 @@ def c3_script(w, block, bank, offset=0):
     v = np.arange(w.n_voices, dtype=np.uint32)
     if block == 0:
         bank.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER, block_offset=offset)
+        if w.delay_times is not None:
+            bank.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times, block_offset=offset)
+    if block == 2 and w.delay_times is not None:  # delays shorter than a tile on some voices: the per-sample path
+        bank.param_apply_many(v[::5], 3, 0, L.VALUE_FLOAT, (v[::5] % 40) / 48000.0 + 1e-6, block_offset=offset)
     if block == 3:
         bank.param_apply_many(v[::3], w.release[0], w.release[1], L.VALUE_TRIGGER, block_offset=offset)
     if block == 4:  # sample-accurate cutoff changes on half the voices (stage 2 is not wrapped -> immediate)
@@ -69,7 +73,8 @@ def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pip
         assert np.max(np.abs(ref)) > 1e-4  # not silence
 
 
-@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C4", 300, 100), ("C5", 260, 128), ("C2", 200, 48)])
+@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C4", 300, 100), ("C5", 260, 128), ("C2", 200, 48),
+                                                      ("D3", 500, 512)])
 def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
     """KNH_PIPELINE 0 = one wavefront per 64 voices, 1 = linear wave pipeline, 2 = five-role pipeline where built."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
@@ -79,7 +84,7 @@ def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_vo
         g = make_gpu(knh, w)
         res = []
         for block in range(6):
-            if name in ("C3", "C4"):
+            if name in ("C3", "C4", "D3"):
                 c3_script(w, block, g)
             if name == "C5":
                 e = configs.c5_events(w, block)
@@ -217,7 +222,8 @@ def test_runtime_fused_kernel_equals_prebuilt_kernel(knh, monkeypatch):
     assert_bit_equal(outs[0], outs[1], "hiprtc-built vs hipcc-built kernel")
 
 
-@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1500, 512), ("C4", 700, 100), ("C5", 520, 128), ("C2", 300, 48)])
+@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1500, 512), ("C4", 700, 100), ("C5", 520, 128), ("C2", 300, 48),
+                                                      ("D3", 900, 256)])
 def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
     """KNH_WIDE=4/8: four or eight 64-voice groups per workgroup (the build used for very large banks)."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
@@ -228,7 +234,7 @@ def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_vo
         g = make_gpu(knh, w)
         res = []
         for block in range(5):
-            if name in ("C3", "C4"):
+            if name in ("C3", "C4", "D3"):
                 c3_script(w, block, g)
             if name == "C5":
                 e = configs.c5_events(w, block)

@@ -22,6 +22,8 @@ def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
     v = np.arange(w.n_voices, dtype=np.uint32)
     if w.restart:
         b.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+    if w.delay_times is not None:
+        b.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times)
     step = [0]
 
     def events(k):
@@ -49,6 +51,9 @@ def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
     ugens = knaster_amd.chain_ugen_count(w.stages)
     work = float(w.n_voices) * w.block_size * ugens * blocks * launches
     rd, wr = b.algorithmic_bytes_per_voice_block()
+    if w.delay_times is not None:  # the ring: one sample read and one written per frame
+        rd += 4 * w.block_size
+        wr += 4 * w.block_size
     print(json.dumps({"config": name, "voices": w.n_voices, "block_size": w.block_size, "sample_type": "f64" if w.sample_type else "f32",
                       "ugens_per_voice": ugens, "allow_fma": allow_fma, "ugen_samples_per_s": work / dt,
                       "kernel_only_ugen_samples_per_s": work / (kms * 1e-3), "us_per_block_kernel": kms * 1e3 / (n * blocks),
@@ -66,3 +71,6 @@ if __name__ == "__main__":
     run("C4", n_voices=8192)
     run("C4")
     run("C5")
+    run("D3")
+    run("D3", n_voices=65536)
+    run("D3", n_voices=262144, launches=4)
