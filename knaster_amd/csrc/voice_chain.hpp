@@ -593,11 +593,18 @@ struct SampleDelay {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = true;
-  template <typename F> struct Regs { u32 wp, off, len, row; F* ring; };
+  static constexpr int kPrefetch = 32;  // largest tile that is read one tile ahead
+  template <typename F> struct Regs {
+    u32 wp, off, len, row;
+    F* ring;
+    u32 pre_pos;       // ring position the tile in `pre` was read from, 0xFFFFFFFF: none
+    F pre[kPrefetch];  // the next tile's samples, requested while this tile is being processed
+  };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
     r.wp = (u32)s[0]; r.off = (u32)s[st]; r.len = (u32)s[2 * st]; r.row = (u32)s[3 * st];
     r.ring = nullptr;
+    r.pre_pos = 0xFFFFFFFFu;
   }
   template <typename F>
   static __device__ __forceinline__ void bind(Regs<F>& r, const Ctx& c) {
@@ -628,14 +635,45 @@ struct SampleDelay {
     const bool dead = r.len == 0u;  // a lane past the last voice: takes part in nothing
     const bool vec_ok = dead || (r.len >= (u32)T && r.off <= r.len - (u32)T && r.wp <= r.len - (u32)T && rp <= r.len - (u32)T);
     if (__builtin_amdgcn_ballot_w64(!vec_ok) == 0) {
+      // Large tiles (the pipelined kernels, one wavefront per SIMD: nothing else hides HBM latency) are read one
+      // tile ahead: this tile comes out of registers filled during the previous one, and the next tile's loads go
+      // out before this tile's stores.  They cannot meet those stores when delay >= 2T (off <= len - 2T).
+      constexpr bool kAhead = T >= 16 && T <= kPrefetch;
+      bool have = false, ahead = false;
+      u32 np = 0;
+      if constexpr (kAhead) {
+        have = !dead && r.pre_pos == rp;
+        np = rp + (u32)T;
+        ahead = !dead && r.len >= 2u * (u32)T && r.off <= r.len - 2u * (u32)T && np <= r.len - (u32)T && r.wp + (u32)T <= r.len - (u32)T;
+      }
+      const bool all_have = kAhead && __builtin_amdgcn_ballot_w64(!(have || dead)) == 0;
       if (!dead) {
         F y[T];
-        const Vec* src = reinterpret_cast<const Vec*>(r.ring + rp);
+        if (all_have) {
+          if constexpr (kAhead) {
 #pragma unroll
-        for (int j = 0; j < T / VW; ++j) {
-          const Vec v = src[j];
+            for (int j = 0; j < T; ++j) y[j] = r.pre[j];
+          }
+        } else {
+          const Vec* src = reinterpret_cast<const Vec*>(r.ring + rp);
 #pragma unroll
-          for (int k = 0; k < VW; ++k) y[j * VW + k] = v[k];
+          for (int j = 0; j < T / VW; ++j) {
+            const Vec v = src[j];
+#pragma unroll
+            for (int k = 0; k < VW; ++k) y[j * VW + k] = v[k];
+          }
+        }
+        if constexpr (kAhead) {
+          if (ahead) {
+            const Vec* nsrc = reinterpret_cast<const Vec*>(r.ring + np);
+#pragma unroll
+            for (int j = 0; j < T / VW; ++j) {
+              const Vec v = nsrc[j];
+#pragma unroll
+              for (int k = 0; k < VW; ++k) r.pre[j * VW + k] = v[k];
+            }
+          }
+          r.pre_pos = ahead ? np : 0xFFFFFFFFu;
         }
         Vec* dst = reinterpret_cast<Vec*>(r.ring + r.wp);
 #pragma unroll
@@ -651,6 +689,7 @@ struct SampleDelay {
       }
       return;
     }
+    r.pre_pos = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
   }

@@ -9,17 +9,20 @@ import numpy as np
 import knaster_amd
 from knaster_amd import _lib as L, configs
 
-w = configs.config("C3")
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+w = configs.config(name)
 b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, 2, L.MIX_TREE)
 for s, a in w.ctor.items():
     b.set_ctor_args(s, a)
 b.init(48000, 512)
 v = np.arange(w.n_voices, dtype=np.uint32)
-b.param_apply_many(v, 3, 3, L.VALUE_TRIGGER)
+b.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+if w.delay_times is not None:
+    b.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times)
 for phase in ["attack (blocks 0-8)", "sustain (8-16)"]:
     b.process_blocks(8)
     print(phase, "busy cycles per tile [osc+gain, svf, env, mixer]:", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
-b.param_apply_many(v, 3, 2, L.VALUE_TRIGGER)
+b.param_apply_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER)
 b.process_blocks(8)
 print("release", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
 b.process_blocks(32)
