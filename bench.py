@@ -30,6 +30,12 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_OPS = 78.6e12        # 157.3 TFLOP/s FP32 vector counts an FMA as 2: 78.6e12 non-fused ops/s
 OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per voice-sample / 4 UGens
+# The filter wavefront of the C3 pipeline kernel executes ~400 instructions per 32-sample tile on its fast path (ISA of the
+# shipped kernel: 339 in the tile body, 320 of them VALU = 10 per sample, + ~60 of loop, event-cursor and LDS bookkeeping);
+# a wavefront alone on its SIMD issues one instruction of that scalar/packed mix per 2.45 ns
+# (tools/micro/valu_issue.hip, profiles/r01_micro_valu_issue.txt: "8-instr pk/scalar mix").
+SVF_WAVE_INSTRUCTIONS_PER_TILE = 400
+LONE_WAVE_ISSUE_NS = 2.45
 REDUCE_EVERY = 64              # blocks per RCCL reduce
 
 
@@ -236,12 +242,24 @@ def main():
                 "kernel": "voice_pipe_kernel<float,false,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>",
                 "kernel_avg_ms": kernel_avg_ms, "launches": launches, "blocks_per_launch": blocks_per_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "note": "fused kernel moves 92 B per voice per block; it is bound by dependent FP32 VALU issue, not HBM (see valu)",
+                "note": "fused kernel moves 92 B per voice per block; it is bound by the instruction issue of its busiest "
+                        "wavefront, not by HBM (see valu and issue)",
             },
             "valu": {
                 "achieved_ops_per_s": kernel_rate * OPS_PER_UGEN_SAMPLE, "peak_ops_per_s": VALU_PEAK_OPS,
                 "frac": kernel_rate * OPS_PER_UGEN_SAMPLE / VALU_PEAK_OPS,
                 "ops_per_ugen_sample": OPS_PER_UGEN_SAMPLE, "kernel_only_ugen_samples_per_s": kernel_rate,
+            },
+            # What actually bounds this kernel at 16 384 voices (one 64-voice group per CU, one wavefront per SIMD): the
+            # filter wavefront's instruction stream.  Instruction count from the ISA of the shipped kernel, issue period of
+            # a wavefront alone on its SIMD from tools/micro/valu_issue.hip (profiles/r01_micro_valu_issue.txt).
+            "issue": {
+                "bound": "instruction issue of the busiest wavefront (SVF), one wavefront per SIMD",
+                "instructions_per_32_sample_tile": SVF_WAVE_INSTRUCTIONS_PER_TILE,
+                "lone_wave_issue_period_ns": LONE_WAVE_ISSUE_NS,
+                "tile_step_ns": kernel_avg_ms * 1e6 / (blocks_per_launch * (bs / 32.0)) if kernel_avg_ms > 0 else None,
+                "frac": (SVF_WAVE_INSTRUCTIONS_PER_TILE * LONE_WAVE_ISSUE_NS) / (kernel_avg_ms * 1e6 / (blocks_per_launch * (bs / 32.0)))
+                if kernel_avg_ms > 0 and not args.allow_fma and bs % 32 == 0 else None,
             },
             "output_finite": sane,
             "host_output": None if host_rate is None else {
