@@ -46,9 +46,11 @@ def needs_build() -> bool:
 
 
 def write_jit_source() -> None:
-    """csrc/jit_source.inc: voice_chain.hpp as C++ raw string literals, embedded in the library so that
-    chains without a pre-built kernel can be fused at run time by hiprtc (jit.hip)."""
+    """csrc/jit_source.inc: voice_chain.hpp + voice_pipe.hpp as C++ raw string literals, embedded in the library so
+    that chains without a pre-built kernel can be fused at run time by hiprtc (jit.hip), in single-wave or pipelined form."""
     text = open(os.path.join(CSRC, "voice_chain.hpp")).read()
+    pipe = open(os.path.join(CSRC, "voice_pipe.hpp")).read()
+    text += "\n" + pipe.replace("#pragma once", "").replace('#include "voice_chain.hpp"', "")
     chunks = [text[i:i + 8000] for i in range(0, len(text), 8000)]
     body = "\n".join('R"KNHJIT(' + c + ')KNHJIT"' for c in chunks) + "\n"
     path = os.path.join(CSRC, "jit_source.inc")

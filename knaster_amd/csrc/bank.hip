@@ -65,6 +65,37 @@ inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
 }
 
+// Rough instructions per sample of each stage (kernel_registry.hpp signature characters), used only to balance the
+// stage groups of a run-time-built pipeline.
+inline int stage_cost(char c) {
+  switch (c) {
+    case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
+    case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10;
+    default: return 1;
+  }
+}
+// Cuts `sig` into 1..3 contiguous groups minimising the heaviest group (each group pays ~4 for its tile I/O);
+// returns the number of cuts and the first stage of every group after the first.
+inline unsigned partition_chain(const std::string& sig, unsigned cuts[2]) {
+  const unsigned n = static_cast<unsigned>(sig.size());
+  std::vector<int> pre(n + 1, 0);
+  for (unsigned i = 0; i < n; ++i) pre[i + 1] = pre[i] + stage_cost(sig[i]);
+  auto cost = [&](unsigned a, unsigned b) { return pre[b] - pre[a] + 4; };
+  int best = cost(0, n);
+  unsigned n_cuts = 0;
+  for (unsigned i = 1; i < n; ++i) {
+    const int c2 = std::max(cost(0, i), cost(i, n));
+    if (c2 < best) { best = c2; n_cuts = 1; cuts[0] = i; }
+  }
+  for (unsigned i = 1; i < n; ++i)
+    for (unsigned j = i + 1; j < n; ++j) {
+      const int c3 = std::max(cost(0, i), std::max(cost(i, j), cost(j, n)));
+      if (c3 < best) { best = c3; n_cuts = 2; cuts[0] = i; cuts[1] = j; }
+    }
+  return n_cuts;
+}
+
 // 0 float, 1 trigger, 2 integer : expected ParameterValue kind per (stage kind, param)
 int expected_value_kind(uint16_t kind, uint32_t param) {
   switch (kind) {
@@ -208,6 +239,7 @@ struct Bank final : knh_bank {
   const knh::WideEntry* wide = nullptr;  // 4/8 voice groups per workgroup, for banks larger than the chip's SIMD count
   int wide_waves = 0;                    // 0 = not used, else 4 or 8
   const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
+  int pipeline_level = 1;                // KNH_PIPELINE
   std::string signature;
   uint32_t nv = 0;
   long stride = 0;
@@ -328,7 +360,20 @@ struct Bank final : knh_bank {
     if (desc.device >= 0) device = desc.device;
     else KNH_HIP(hipGetDevice(&device));
     KNH_HIP(hipSetDevice(device));
-    if (!entry) {  // no pre-built kernel: fuse this chain now
+    // Chains without a pre-built pipelined kernel are fused now (hiprtc).  Up to ~1.5 voice groups per CU the
+    // pipelined form wins by a wide margin, so the chain is cut into at most three stage groups of similar cost
+    // (estimated instructions per sample) and instantiated as voice_pipe_kernel; KNH_JIT_PIPE=0 keeps the
+    // single-wave form.
+    const unsigned n_groups = (nv + 63u) / 64u;
+    const char* jp = std::getenv("KNH_JIT_PIPE");
+    const bool pipe_jit = !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 384 && !(jp && jp[0] == '0');
+    if (pipe_jit) {
+      std::string why;
+      unsigned cuts[2];
+      const unsigned n_cuts = partition_chain(signature, cuts);
+      jit = knh::jit_pipe_kernel(signature.c_str(), cuts, n_cuts, sizeof(F) == 8, desc.allow_fma != 0, &why);
+      if (!jit) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' (pipelined) failed: " + why);
+    } else if (!entry) {  // no pre-built kernel at all
       std::string why;
       jit = knh::jit_voice_kernel(signature.c_str(), sizeof(F) == 8, desc.allow_fma != 0, &why);
       if (!jit) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' failed: " + why);
@@ -1109,6 +1154,7 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
     // (voice_dag.hpp; bit-identical, measured 5-8 % slower than level 1 on MI355X, kept for experiments)
     const char* env = std::getenv("KNH_PIPELINE");
     const int level = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : 1;
+    b->pipeline_level = level;
     if (b->entry && level >= 1) b->pipe = knh::find_pipe(sig.c_str());
     if (b->entry && level >= 2 && d.sample_type == KNH_F32) b->dag = knh::find_dag(sig.c_str());
     // Occupancy regime: the wave pipeline minimises latency when every 64-voice group can have a CU to

@@ -222,6 +222,54 @@ def test_runtime_fused_kernel_equals_prebuilt_kernel(knh, monkeypatch):
     assert_bit_equal(outs[0], outs[1], "hiprtc-built vs hipcc-built kernel")
 
 
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_runtime_built_pipeline_equals_runtime_built_single_wave_kernel(knh, monkeypatch, sample_type):
+    """A chain without a pre-built pipeline gets one at init time: hiprtc instantiates voice_pipe_kernel over stage
+    groups cut by estimated cost (KNH_JIT_PIPE=0 keeps the single-wave form).  Same arithmetic, same bits; also
+    against the hipcc-built pipeline of a chain that has one."""
+    from knaster_amd.bank import Stage
+
+    n, bs = 700, 160
+    p = configs.voice_parameters(n)
+    w = configs.Workload("jitpipe", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_ONEPOLE_LPF), Stage(L.STAGE_SVF),
+                                     Stage(L.STAGE_SAMPLE_DELAY), Stage(L.STAGE_MUL_ENV_AR, delayed_changes_per_block=2),
+                                     Stage(L.STAGE_MUL_CONST)], n, bs, sample_type, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.7), 2: p["cutoff"].reshape(n, 1),
+              3: np.stack([np.full(n, float(L.SVF_PEAK)), p["cutoff"] * 0.5, p["q"], np.zeros(n)], axis=1),
+              4: np.full((n, 1), 0.011), 5: np.stack([p["attack"] * 0.1, p["release"] * 0.05], axis=1), 6: np.full((n, 1), 1.0 / n)}
+    v = np.arange(n, dtype=np.uint32)
+    outs = []
+    for jit_pipe in ("0", "1"):
+        monkeypatch.setenv("KNH_JIT_PIPE", jit_pipe)
+        g = make_gpu(knh, w)
+        g.param_apply_many(v, 4, 0, L.VALUE_FLOAT, (v % 500) / 48000.0 + 1e-6)
+        res = []
+        for block in range(5):
+            if block in (0, 3):
+                g.param_apply_many(v, 5, 2, L.VALUE_TRIGGER, delays=(v % bs).astype(np.uint16))
+            res.append(g.process_block_voices())
+        res.append((g.process_blocks(3)[0], None, 0))
+        outs.append(res)
+        g.close()
+    for (o0, v0, f0), (o1, v1, f1) in zip(*outs):
+        assert_bit_equal(o0, o1, "mix")
+        if v0 is not None:
+            assert_bit_equal(v0, v1, "per voice")
+            assert f0 == f1
+    assert np.max(np.abs(outs[0][2][1])) > 1e-6
+    # a chain that has a hipcc-built pipeline: forcing run-time fusion must give the same bits
+    w3 = configs.config("C3", n_voices=300, block_size=128, sample_type=sample_type)
+    c3 = []
+    for jit in ("0", "1"):
+        monkeypatch.setenv("KNH_JIT", jit)
+        monkeypatch.setenv("KNH_JIT_PIPE", "1")
+        g = make_gpu(knh, w3)
+        fire_all(g, w3.n_voices, *w3.restart)
+        c3.append(g.process_blocks(4)[0])
+        g.close()
+    assert_bit_equal(c3[0], c3[1], "hiprtc-built vs hipcc-built pipeline")
+
+
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1500, 512), ("C4", 700, 100), ("C5", 520, 128), ("C2", 300, 48),
                                                       ("D3", 900, 256)])
 def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
