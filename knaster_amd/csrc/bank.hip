@@ -366,7 +366,9 @@ struct Bank final : knh_bank {
     // single-wave form.
     const unsigned n_groups = (nv + 63u) / 64u;
     const char* jp = std::getenv("KNH_JIT_PIPE");
-    const bool pipe_jit = !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 384 && !(jp && jp[0] == '0');
+    // (a single voice group with a pre-built kernel stays on it: nothing to gain, and no compile at init)
+    const bool pipe_jit = !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 384 && !(jp && jp[0] == '0') &&
+                          !(entry && n_groups == 1);
     if (pipe_jit) {
       std::string why;
       unsigned cuts[2];
