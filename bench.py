@@ -256,10 +256,13 @@ def main():
             "issue": {
                 "bound": "instruction issue of the busiest wavefront (SVF), one wavefront per SIMD",
                 "instructions_per_32_sample_tile": SVF_WAVE_INSTRUCTIONS_PER_TILE,
-                "lone_wave_issue_period_ns": LONE_WAVE_ISSUE_NS,
                 "tile_step_ns": kernel_avg_ms * 1e6 / (blocks_per_launch * (bs / 32.0)) if kernel_avg_ms > 0 else None,
-                "frac": (SVF_WAVE_INSTRUCTIONS_PER_TILE * LONE_WAVE_ISSUE_NS) / (kernel_avg_ms * 1e6 / (blocks_per_launch * (bs / 32.0)))
+                "ns_per_instruction": kernel_avg_ms * 1e6 / (blocks_per_launch * (bs / 32.0)) / SVF_WAVE_INSTRUCTIONS_PER_TILE
                 if kernel_avg_ms > 0 and not args.allow_fma and bs % 32 == 0 else None,
+                "lone_wave_issue_period_ns_microbenchmark": LONE_WAVE_ISSUE_NS,
+                "note": "the whole tile step divided by the filter wavefront's instruction count, against the issue period of "
+                        "a wavefront alone on its SIMD measured in a separate short kernel (clock not pinned): at or below "
+                        "that period means this wavefront issues back to back for the entire step",
             },
             "output_finite": sane,
             "host_output": None if host_rate is None else {

@@ -446,6 +446,38 @@ struct MulEnvT {
         if (moving) r.t = t;
         return;
       }
+      // Some lane changes state in this tile.  The two common cases stay tile-wise, at one select per sample:
+      if (anyR) {
+        // a release runs out (envelopes.rs:72-78 / :224-230): t keeps falling in the speculative sequence, so the
+        // samples after the last positive t are exactly the Stopped ones (env 0), and their count gives the frame
+        // of mark_done.  `!(t <= 0)` keeps a NaN t on the cubic branch, as the reference's `nt <= 0` test does.
+        u32 alive = 0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+          const bool pos = !(tt[j] <= (F)0);
+          const F e = pos ? (tt[j] * (tt[j] * tt[j])) * scale : (F)0;
+          alive += pos ? 1u : 0u;
+          x[j] = x[j] * e;
+        }
+        if (isR && hit) { r.state = 0u; r.t = (F)0; done_frame = frame0 + alive - 1u - r.seg; }
+        else if (moving) r.t = t;
+        return;
+      }
+      if (!AR) {
+        // an EnvAsr attack arrives (envelopes.rs:58-64): from the first t >= 1 on the envelope is 1 (Sustaining)
+        // and t stays at that first value.  Sample 0 outputs its t whatever it is (a restart can come in above 1).
+        F first = t;  // the sequence rises, so the first t >= 1 is the smallest one; the tile's last step is a candidate too
+        x[0] = x[0] * tt[0];
+#pragma unroll
+        for (int j = T - 1; j >= 1; --j) {
+          const bool ge = tt[j] >= (F)1;
+          first = ge ? tt[j] : first;
+          x[j] = x[j] * (ge ? (F)1 : tt[j]);
+        }
+        if (isA && hit) { r.state = 2u; r.t = first; }
+        else if (moving) r.t = t;
+        return;
+      }
     }
 #pragma unroll
     for (int j = 0; j < T; ++j) x[j] = x[j] * env_next<F>(r, frame0 + j, done_frame);
