@@ -54,6 +54,12 @@ __global__ void k(float* out, int iters) {
             "v_pk_fma_f32 %3, %2, %6, %3\n\t"
             : "+v"(a[0]), "+v"(a[1]), "+v"(p[0]), "+v"(p[1]), "+v"(a[2]), "+v"(a[3]) : "v"(pb));
       }
+    } else if (MODE == 12) {  // scalar fma, independent
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[u & 7]) : "v"(b));
+    } else if (MODE == 13) {  // v_add_f32 (VOP2) independent
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[u & 7]) : "v"(b));
     } else if (MODE == 7) {  // f64 mul dependent
       double d = a[0];
 #pragma unroll
@@ -96,6 +102,8 @@ int main() {
     run<5>("v_mul_f32 two chains", d, waves);
     run<1>("v_mul_f32 eight chains", d, waves);
     run<4>("v_fma_f32 dependent", d, waves);
+    run<12>("v_fma_f32 eight chains", d, waves);
+    run<13>("v_add_f32 eight chains", d, waves);
     run<2>("v_pk_mul_f32 dependent", d, waves);
     run<6>("v_pk_mul_f32 two chains", d, waves);
     run<3>("v_pk_mul_f32 eight chains", d, waves);
