@@ -781,7 +781,9 @@ struct Bank final : knh_bank {
     smooth_epoch = (smooth_epoch + 1) & 0x7FFFFFFFu;
     if (!queued.empty()) {
       // group by node, keeping arrival order inside each node's queue
-      std::stable_sort(queued.begin(), queued.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      // (callers that walk the voices in order, as the batched entry points are normally used, arrive sorted)
+      auto by_node = [](const auto& a, const auto& b) { return a.first < b.first; };
+      if (!std::is_sorted(queued.begin(), queued.end(), by_node)) std::stable_sort(queued.begin(), queued.end(), by_node);
       size_t i = 0;
       std::vector<std::pair<uint32_t, const QueuedChange*>> due_list;
       while (i < queued.size()) {
@@ -891,7 +893,8 @@ struct Bank final : knh_bank {
       for (uint32_t v = 0; v < nv; ++v) {
         Event* b = h_events + h_ev_start[v];
         Event* e = h_events + h_ev_start[v + 1];
-        if (e - b > 1) std::stable_sort(b, e, [](const Event& x, const Event& y) { return x.frame < y.frame; });
+        auto by_frame = [](const Event& x, const Event& y) { return x.frame < y.frame; };
+        if (e - b > 1 && !std::is_sorted(b, e, by_frame)) std::stable_sort(b, e, by_frame);
       }
     }
     KNH_HIP(hipMemcpyAsync(d_ev_start, h_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
