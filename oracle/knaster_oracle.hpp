@@ -103,6 +103,23 @@ struct Seconds {
         (samples % sample_rate) * static_cast<uint64_t>(SUBSECOND_TESIMALS_PER_SECOND) / sample_rate);
     return r;
   }
+  static Seconds from_subsample_tesimals_u64(uint64_t t) {  // time.rs:48-53
+    Seconds r;
+    r.seconds = static_cast<uint32_t>(t / SUBSECOND_TESIMALS_PER_SECOND);
+    r.subsecond_tesimals = static_cast<uint32_t>(t - static_cast<uint64_t>(r.seconds) * SUBSECOND_TESIMALS_PER_SECOND);
+    return r;
+  }
+  uint64_t to_subsample_tesimals_u64() const {  // time.rs:55-57
+    return static_cast<uint64_t>(seconds) * SUBSECOND_TESIMALS_PER_SECOND + subsecond_tesimals;
+  }
+  // From<core::time::Duration> (time.rs:135-143); Duration::from_secs_f64 truncates to whole nanoseconds
+  static Seconds from_duration(uint64_t secs, uint32_t subsec_nanos) {
+    const double conversion_factor = static_cast<double>(SUBSECOND_TESIMALS_PER_SECOND) / 1000000000.0;
+    Seconds r;
+    r.seconds = static_cast<uint32_t>(secs);
+    r.subsecond_tesimals = sat_u32(static_cast<double>(subsec_nanos) * conversion_factor);
+    return r;
+  }
   double to_secs_f64() const {  // time.rs:71-74
     return static_cast<double>(seconds) + (static_cast<double>(subsecond_tesimals) / static_cast<double>(SUBSECOND_TESIMALS_PER_SECOND));
   }

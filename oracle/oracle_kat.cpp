@@ -283,6 +283,21 @@ static void seconds_sample_conversion() {
   CHECK((s == Seconds{2, 0}));
 }
 // knaster_graph/src/graph.rs:2483-2513: EnvAsr(0,0) restarted+released is done within 10 blocks of 16
+// knaster_primitives/src/time.rs:460-472, 497-503
+static void seconds_tesimals_duration_arithmetic() {
+  Seconds original{8347, SUBSECOND_TESIMALS_PER_SECOND - 5};
+  CHECK(original == Seconds::from_subsample_tesimals_u64(original.to_subsample_tesimals_u64()));
+  // duration_to_subsample_time: the two conversions need not agree in the last tesimal for arbitrary inputs, the
+  // reference asserts they do for these four (Duration::from_secs_f64 = whole seconds + nanoseconds, truncated)
+  for (double s : {73.73, 10.832, 10000.25, 84923.399}) {
+    const double whole = std::floor(s);
+    const uint32_t nanos = static_cast<uint32_t>((s - whole) * 1e9);
+    CHECK(Seconds::from_secs_f64(s) == Seconds::from_duration(static_cast<uint64_t>(whole), nanos));
+  }
+  Seconds a{0, SUBSECOND_TESIMALS_PER_SECOND - 1}, b{1, 1};
+  CHECK(a.add(b) == (Seconds{2, 0}));
+}
+
 static void free_node_when_done() {
   Graph<float> g(0, 2, 16, 48000);
   NodeKey asr = g.push(std::make_unique<EnvAsr<float>>(0.0f, 0.0f));
@@ -371,6 +386,7 @@ int main() {
   RUN(bench_asserts);
   RUN(implement_a_gen_sine);
   RUN(seconds_sample_conversion);
+  RUN(seconds_tesimals_duration_arithmetic);
   RUN(free_node_when_done);
   RUN(readme_example_shape);
   RUN(buffer_reuse_linear_chain);

@@ -13,7 +13,7 @@ def test_reference_known_answer_tests_pass(oracle):
     expected = ["wrapper_arithmetic", "sample_accurate_parameters_test", "sample_accurate_parameters_with_wrappers_test",
                 "gen_arithmetics", "gen_arithmetics_multichannel", "graph_empty_graph_zero_output", "graph_inputs_to_outputs",
                 "graph_inputs_to_nodes_to_outputs", "multichannel_nodes", "disconnect", "bench_asserts", "implement_a_gen_sine",
-                "seconds_sample_conversion", "free_node_when_done"]
+                "seconds_sample_conversion", "seconds_tesimals_duration_arithmetic", "free_node_when_done"]
     for name in expected:
         assert f"ok   {name}" in res.stdout, name
 
