@@ -296,21 +296,25 @@ struct Bank final : knh_bank {
   std::vector<uint32_t> delay_len;  // ring length per voice (samples)
   std::vector<double> env_start;  // Envelope::start_value per voice (t_restart restores it)
   std::vector<uint32_t> env_nseg;
-  uint32_t* d_ev_start = nullptr;
-  Event* d_events = nullptr;
-  size_t d_events_cap = 0;
   F* d_partials = nullptr;
   F* d_out = nullptr;
   F* d_voices = nullptr;
   uint32_t* d_done = nullptr;
   uint32_t* d_flags = nullptr;
   // pinned host staging
-  uint32_t* h_ev_start = nullptr;
+  // Event lists are read by the kernel straight from pinned host memory (each is read once, a few hundred KB per
+  // launch): no copy in the stream, the kernel's first waves pull them over PCIe while the others start.  Two
+  // buffers alternate; one is rewritten only after the kernel that read it has finished (list_done).
+  uint32_t* h_ev_start2[2] = {nullptr, nullptr};
+  Event* h_events2[2] = {nullptr, nullptr};
+  size_t h_events_cap2[2] = {0, 0};
+  hipEvent_t list_done[2] = {nullptr, nullptr};
+  bool list_busy[2] = {false, false};
+  unsigned list_parity = 0;
+  int list_in_use = -1;            // buffer the kernel being launched reads
+  uint32_t* h_ev_start = nullptr;  // the buffer of the launch being assembled
   Event* h_events = nullptr;
-  size_t h_events_cap = 0;
   F* h_out = nullptr;  // [channels][block] then 2 x u32 flags
-  hipEvent_t staging_free = nullptr;
-  bool staging_in_flight = false;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_pool;
@@ -321,13 +325,14 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_ev_start, d_events, d_partials, d_out, d_voices, d_done, d_flags};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_partials, d_out, d_voices, d_done, d_flags};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
-    void* host_ptrs[] = {h_ev_start, h_events, h_out};
+    void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out};
     for (void* p : host_ptrs)
       if (p) (void)hipHostFree(p);
-    if (staging_free) (void)hipEventDestroy(staging_free);
+    for (hipEvent_t e : list_done)
+      if (e) (void)hipEventDestroy(e);
     for (auto& p : timing_pool) {
       (void)hipEventDestroy(p.first);
       (void)hipEventDestroy(p.second);
@@ -530,7 +535,6 @@ struct Bank final : knh_bank {
       KNH_HIP(hipMemcpy(d_seg_table, seg_rows.data(), seg_rows.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     const size_t n_waves = (nv + 63) / 64;
-    KNH_HIP(hipMalloc(&d_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
     KNH_HIP(hipMalloc(&d_partials, n_waves * bs * sizeof(F)));
     KNH_HIP(hipMalloc(&d_out, desc.out_channels * bs * sizeof(F)));
     KNH_HIP(hipMemset(d_out, 0, desc.out_channels * bs * sizeof(F)));
@@ -538,9 +542,11 @@ struct Bank final : knh_bank {
     KNH_HIP(hipMemset(d_done, 0xFF, static_cast<size_t>(nv) * sizeof(uint32_t)));
     KNH_HIP(hipMalloc(&d_flags, 16 * sizeof(uint32_t)));
     KNH_HIP(hipMemset(d_flags, 0, 16 * sizeof(uint32_t)));
-    KNH_HIP(hipHostMalloc(&h_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
+    for (int b = 0; b < 2; ++b) {
+      KNH_HIP(hipHostMalloc(&h_ev_start2[b], (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
+      KNH_HIP(hipEventCreateWithFlags(&list_done[b], hipEventDisableTiming));
+    }
     KNH_HIP(hipHostMalloc(&h_out, desc.out_channels * bs * sizeof(F) + 2 * sizeof(uint32_t)));
-    KNH_HIP(hipEventCreateWithFlags(&staging_free, hipEventDisableTiming));
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD) KNH_HIP(ensure_voices());
     bool any_wrapped = false;
     for (auto& S : stages) any_wrapped = any_wrapped || S.dcpb > 0;
@@ -860,24 +866,22 @@ struct Bank final : knh_bank {
     *have_events = false;
     const size_t total = pending.size();
     if (total == 0) return KNH_OK;
-    if (staging_in_flight) {  // the previous upload must have left the pinned staging buffers
-      KNH_HIP(hipEventSynchronize(staging_free));
-      staging_in_flight = false;
+    const unsigned lb = list_parity;
+    list_parity ^= 1u;
+    if (list_busy[lb]) {  // the kernel that read this buffer two launches ago must be done with it
+      KNH_HIP(hipEventSynchronize(list_done[lb]));
+      list_busy[lb] = false;
     }
-    if (total > h_events_cap) {
+    if (total > h_events_cap2[lb]) {
       size_t cap = std::max<size_t>(total, 1024) * 2;
-      if (h_events) KNH_HIP(hipHostFree(h_events));
-      h_events = nullptr;
-      KNH_HIP(hipHostMalloc(&h_events, cap * sizeof(Event)));
-      h_events_cap = cap;
+      if (h_events2[lb]) KNH_HIP(hipHostFree(h_events2[lb]));
+      h_events2[lb] = nullptr;
+      KNH_HIP(hipHostMalloc(&h_events2[lb], cap * sizeof(Event)));
+      h_events_cap2[lb] = cap;
     }
-    if (total > d_events_cap) {
-      KNH_HIP(hipStreamSynchronize(s));
-      KNH_HIP(hipFree(d_events));
-      d_events = nullptr;
-      KNH_HIP(hipMalloc(&d_events, h_events_cap * sizeof(Event)));
-      d_events_cap = h_events_cap;
-    }
+    h_ev_start = h_ev_start2[lb];
+    h_events = h_events2[lb];
+    list_in_use = static_cast<int>(lb);
     // counting sort by voice (stable: keeps application order), then each voice's few events by frame (stable)
     std::fill(h_ev_start, h_ev_start + nv + 1, 0u);
     for (const HostEvent& e : pending) h_ev_start[e.voice + 1]++;
@@ -897,10 +901,7 @@ struct Bank final : knh_bank {
         if (e - b > 1 && !std::is_sorted(b, e, by_frame)) std::stable_sort(b, e, by_frame);
       }
     }
-    KNH_HIP(hipMemcpyAsync(d_ev_start, h_ev_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    KNH_HIP(hipMemcpyAsync(d_events, h_events, total * sizeof(Event), hipMemcpyHostToDevice, s));
-    KNH_HIP(hipEventRecord(staging_free, s));
-    staging_in_flight = true;
+    (void)s;
     pending.clear();
     pending_needs_sort = false;
     *have_events = true;
@@ -987,8 +988,8 @@ struct Bank final : knh_bank {
     a.seg_max = seg_max;
     a.delay_ring = d_delay;
     a.delay_stride = delay_stride;
-    a.ev_start = have_events ? d_ev_start : nullptr;
-    a.events = d_events;
+    a.ev_start = have_events ? h_ev_start : nullptr;  // pinned host memory, device-visible
+    a.events = h_events;
     a.partials = d_partials;
     a.voices_out = want_voices ? d_voices : nullptr;
     a.done_frames = d_done;
@@ -1011,6 +1012,11 @@ struct Bank final : knh_bank {
     }
     KNH_HIP(launch_voice(a, n_waves, s));
     if (tp) KNH_HIP(hipEventRecord(tp->second, s));
+    if (have_events && list_in_use >= 0) {
+      KNH_HIP(hipEventRecord(list_done[list_in_use], s));
+      list_busy[list_in_use] = true;
+      list_in_use = -1;
+    }
 
     F* dst = out_device ? static_cast<F*>(out_device) : d_out;
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
@@ -1027,7 +1033,6 @@ struct Bank final : knh_bank {
     if (voices_host)
       KNH_HIP(hipMemcpyAsync(voices_host, d_voices, static_cast<size_t>(nv) * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
     KNH_HIP(hipStreamSynchronize(s));
-    staging_in_flight = false;
     if (out_host) {
       if (n_blocks > 1) {
         std::memcpy(out_host, h_out, out_bytes);
@@ -1088,7 +1093,6 @@ struct Bank final : knh_bank {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
     KNH_HIP(hipSetDevice(device));
     KNH_HIP(hipDeviceSynchronize());
-    staging_in_flight = false;
     return KNH_OK;
   }
   int timing_collect() {
