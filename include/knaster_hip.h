@@ -107,6 +107,10 @@ typedef enum knh_value_kind {
  *     (Seconds::to_secs_f64() * sample_rate) as usize samples per voice, in HBM.  A delay_time longer than the ring
  *     is refused with KNH_ERR_OUT_OF_RANGE (the reference indexes out of bounds there); a zero-length ring fails init.
  *     At most one per chain.
+ * KNH_STAGE_PHASOR          g.push(Phasor::new(freq))           osc.rs:172-214       1    freq
+ *     a source like SinWt: a 0..1 ramp, f64 phase and step whatever F is.  params: 0 freq
+ * KNH_STAGE_SAFETY_LIMITER  x >> g.push(SafetyLimiter::new())   dynamics.rs:9-31     1    (none)
+ *     clamp to [-1, 1], NaN -> 0; no parameters, no state
  *     WrMul: params: 0 = the reference's "wr_mul" (index T::Parameters of the
  *     wrapped node, math.rs:69-98).  No other wrapper adds a parameter.  POW_CONST: params: 0 value.
  *     powi is the multiply-by-squaring loop of compiler-builtins (exact, bit-identical to the oracle);
@@ -135,7 +139,9 @@ typedef enum knh_stage_kind {
   KNH_STAGE_WR_POWI = 19,
   KNH_STAGE_POW_CONST = 20,
   KNH_STAGE_SAMPLE_DELAY = 21,
-  KNH_STAGE_KIND_COUNT = 22
+  KNH_STAGE_PHASOR = 22,
+  KNH_STAGE_SAFETY_LIMITER = 23,
+  KNH_STAGE_KIND_COUNT = 24
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

@@ -60,6 +60,8 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* WR_POWI     */ {1, 0, 1, 0, 'i', {nullptr}},
     /* POW_CONST   */ {1, 1, 1, 2, 'p', {"value"}},
     /* SAMPLE_DELAY*/ {4, 1, 1, 1, 'D', {"delay_time"}},
+    /* PHASOR      */ {4, 1, 1, 1, 'P', {"freq"}},
+    /* SAFETY_LIM  */ {0, 0, 0, 1, 'X', {nullptr}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -71,7 +73,7 @@ inline int stage_cost(char c) {
   switch (c) {
     case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
     case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
-    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4;
     default: return 1;
   }
 }
@@ -481,6 +483,15 @@ struct Bank final : knh_bank {
               row[0] = dur; row[1] = 1.0 / dur; row[2] = val;  // EnvelopeSegment::new, envelopes.rs:327-333
             }
           } break;
+          case KNH_STAGE_PHASOR: {  // osc.rs:181-188 (new), :197-200 (init: step = freq * (1 / sample_rate))
+            const double step = a[0] * (1.0 / static_cast<double>(sr));
+            const uint64_t sb = to_bits(step);
+            slot(S.slot_base + 0, v) = 0;
+            slot(S.slot_base + 1, v) = 0;
+            slot(S.slot_base + 2, v) = static_cast<W>(static_cast<uint32_t>(sb));
+            slot(S.slot_base + 3, v) = static_cast<W>(static_cast<uint32_t>(sb >> 32));
+          } break;
+          case KNH_STAGE_SAFETY_LIMITER: break;
           case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:24-31 (new), :45-49 (init)
             if (v == 0) delay_len.assign(nv, 0u);
             // Seconds::from_secs_f64 / to_secs_f64 (knaster_primitives/src/time.rs:59-74), then `as usize`
@@ -742,6 +753,11 @@ struct Bank final : knh_bank {
           set(0, 1);  // t_restart: state = Attacking, t untouched (envelopes.rs:47-49,131-133)
         }
         break;
+      case KNH_STAGE_PHASOR: {  // osc.rs:189-196
+        const uint64_t sb = to_bits(f * (1.0 / static_cast<double>(sample_rate)));
+        set(2, static_cast<uint32_t>(sb));
+        set(3, static_cast<uint32_t>(sb >> 32));
+      } break;
       case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:33-36: delay_samples = (seconds * sample_rate) as usize
         const double ds = f * static_cast<double>(sample_rate);
         const uint32_t len = delay_len[v];
@@ -1134,7 +1150,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
   bool have_x = false;
   for (uint32_t i = 0; i < n; ++i) {
     if (st[i].kind >= KNH_STAGE_KIND_COUNT) { *why = "unknown stage kind"; return KNH_ERR_INVALID_ARGUMENT; }
-    const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC;
+    const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC || st[i].kind == KNH_STAGE_PHASOR;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ)) { *why = "SMOOTH_PARAMS and AR_FREQ cannot be combined"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1396,7 +1412,8 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: w += word; break;
       case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: w += word * 3; break;
       case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
-      case KNH_STAGE_SAMPLE_DELAY: w += word; break;  // + one sample read and one written per frame (ring in HBM)
+      case KNH_STAGE_SAMPLE_DELAY: w += word; break;
+      case KNH_STAGE_PHASOR: w += word * 2; break;  // + one sample read and one written per frame (ring in HBM)
       default: break;
     }
   }

@@ -122,6 +122,79 @@ struct SinWtT {
 typedef SinWtT<false> SinWt;
 typedef SinWtT<true> SinWtAr;
 
+// Phasor -- osc.rs:172-214: out = phase; phase += step; while phase >= 1 { phase -= 1 }.  Phase and step are f64 for
+// any F.  slots: 0,1 phase (low, high word)  2,3 step
+struct Phasor {
+  static constexpr int kSlots = 4;
+  static constexpr u32 kMutableMask = 0b0011u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  template <typename F> struct Regs { double phase, step; };
+  template <typename W> static __device__ __forceinline__ double ld2(const W* s, long st, int k) {
+    const u64 lo = (u32)s[(long)k * st], hi = (u32)s[(long)(k + 1) * st];
+    return __builtin_bit_cast(double, lo | (hi << 32));
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) { r.phase = ld2(s, st, 0); r.step = ld2(s, st, 2); }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    const u64 b = __builtin_bit_cast(u64, r.phase);
+    s[0] = (W)(u32)b;
+    s[st] = (W)(u32)(b >> 32);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
+    const F out = (F)r.phase;
+    r.phase += r.step;
+    while (r.phase >= 1.0) r.phase -= 1.0;
+    return out;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    const u32 w = (u32)bits;
+    auto lo = [](double d, u32 v) { return __builtin_bit_cast(double, (__builtin_bit_cast(u64, d) & 0xFFFFFFFF00000000ull) | (u64)v); };
+    auto hi = [](double d, u32 v) { return __builtin_bit_cast(double, (__builtin_bit_cast(u64, d) & 0x00000000FFFFFFFFull) | ((u64)v << 32)); };
+    switch (rel) {
+      case 0: r.phase = lo(r.phase, w); break;
+      case 1: r.phase = hi(r.phase, w); break;
+      case 2: r.step = lo(r.step, w); break;
+      default: r.step = hi(r.step, w); break;
+    }
+  }
+};
+
+// SafetyLimiter -- dynamics.rs:9-31: clamp to [-1, 1] (a NaN passes the clamp), then NaN -> 0.  No state.
+struct SafetyLimiter {
+  static constexpr int kSlots = 0;
+  static constexpr u32 kMutableMask = 0u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  template <typename F> struct Regs {};
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>&, const W*, long) {}
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>&, F x, const Ctx&, u32, u32&) {
+    F s = x;
+    if (s < (F)-1) s = (F)-1;  // f32::clamp: comparisons, so -0.0 and NaN come through unchanged
+    if (s > (F)1) s = (F)1;
+    return s != s ? (F)0 : s;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F> static __device__ __forceinline__ void on_event(Regs<F>&, u32, u32, u64, u32) {}
+};
+
 // SinNumeric -- osc.rs:222-271.  slots: 0 phase, 1 phase_offset, 2 phase_increment
 struct SinNum {
   static constexpr int kSlots = 3;
@@ -823,10 +896,11 @@ struct Chain<F, FMA, BASE> {
   static constexpr bool kUsesSine = false;
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
   template <typename W> __device__ __forceinline__ void store(W*, long) const {}
-  __device__ __forceinline__ F tick(F x, const Ctx&, u32, u32&) { return x; }
-  template <int T> __device__ __forceinline__ void tick_tile(F (&)[T], const Ctx&, u32, u32&) {}
+  __device__ __forceinline__ F tick(F x, const Ctx&, u32) { return x; }
+  template <int T> __device__ __forceinline__ void tick_tile(F (&)[T], const Ctx&, u32) {}
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
+  __device__ __forceinline__ u32 collect_done(u32 acc) const { return acc; }
   __device__ __forceinline__ void begin_block(u32, const Ctx&) {}
 };
 template <typename F, bool FMA, int BASE, typename S0, typename... Rest>
@@ -835,6 +909,10 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   static constexpr int kSlots = RestT::kSlots;
   static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
   typename S0::template Regs<F> r;
+  // The frame this stage last passed to mark_done (UGenFlags::mark_done, ugen.rs:199-202), 0xFFFFFFFF: never.  The
+  // reference hands one UGenFlags to every task of a block in node order (graph_gen.rs:196-200), so the mark a voice
+  // ends up with is that of the last node in order that set one: collect_done.
+  u32 mark = 0xFFFFFFFFu;
   RestT rest;
   template <typename W> __device__ __forceinline__ void load(const W* s, long stride) {
     S0::template load<F, W>(r, s + (long)BASE * stride, stride);
@@ -844,13 +922,17 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
     S0::template store<F, W>(r, s + (long)BASE * stride, stride);
     rest.store(s, stride);
   }
-  __device__ __forceinline__ F tick(F x, const Ctx& c, u32 frame, u32& done_frame) {
-    x = S0::template tick<F, FMA>(r, x, c, frame, done_frame);
-    return rest.tick(x, c, frame, done_frame);
+  __device__ __forceinline__ F tick(F x, const Ctx& c, u32 frame) {
+    x = S0::template tick<F, FMA>(r, x, c, frame, mark);
+    return rest.tick(x, c, frame);
   }
-  template <int T> __device__ __forceinline__ void tick_tile(F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
-    S0::template tick_tile<F, FMA, T>(r, x, c, frame0, done_frame);
-    rest.template tick_tile<T>(x, c, frame0, done_frame);
+  template <int T> __device__ __forceinline__ void tick_tile(F (&x)[T], const Ctx& c, u32 frame0) {
+    S0::template tick_tile<F, FMA, T>(r, x, c, frame0, mark);
+    rest.template tick_tile<T>(x, c, frame0);
+  }
+  __device__ __forceinline__ u32 collect_done(u32 acc) const {
+    if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
+    return rest.collect_done(acc);
   }
   __device__ __forceinline__ void on_event(u32 op, u32 slot, u64 bits, u32 frame) {
     if (slot >= (u32)BASE && slot < (u32)(BASE + S0::kSlots)) S0::template on_event<F>(r, op, slot - BASE, bits, frame);
@@ -946,7 +1028,6 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
   u32 next_frame = 0xFFFFFFFFu;
   if (ev_i < ev_end) next_frame = a.events[ev_i].frame;
-  u32 done_frame = 0xFFFFFFFFu;
   u32 base = 0;  // absolute frame of the current block's frame 0
 
   auto apply_events_upto = [&](u32 n_abs) {
@@ -979,14 +1060,14 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
           F x[kTile];
 #pragma unroll
           for (int j = 0; j < kTile; ++j) x[j] = (F)0;
-          chain.template tick_tile<kTile>(x, ctx, n, done_frame);
+          chain.template tick_tile<kTile>(x, ctx, n);
 #pragma unroll
           for (int j = 0; j < kTile; ++j) my[j0 + j][lane] = x[j];
         } else {
           const u32 m = len - j0 < (u32)kTile ? len - j0 : (u32)kTile;
           for (u32 j = 0; j < m; ++j) {
             apply_events_upto(base + n + j);
-            my[j0 + j][lane] = chain.tick((F)0, ctx, n + j, done_frame);
+            my[j0 + j][lane] = chain.tick((F)0, ctx, n + j);
           }
         }
       }
@@ -1022,6 +1103,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
     apply_events_upto(base + a.frame_end);
   }
 
+  const u32 done_frame = chain.collect_done(0xFFFFFFFFu);
   if (live) {
     chain.store(a.state + voice, a.stride);
     a.done_frames[voice] = done_frame;

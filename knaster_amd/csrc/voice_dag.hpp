@@ -242,7 +242,6 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
     ChainT chain;
     chain.load(a.state + voice, a.stride);
     EventCursor<F> ev(a, voice, live);
-    u32 done_unused = 0xFFFFFFFFu;
     auto on = [&](u32 op, u32 slot, u64 bits, u32 rel) { chain.on_event(op, slot, bits, rel); };
     role_loop(0,
               [&](int g, int, int ti, u32 base, u32 n, u32 m) {
@@ -253,12 +252,12 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
                   F x[T];
 #pragma unroll
                   for (int j = 0; j < T; ++j) x[j] = (F)0;
-                  chain.template tick_tile<T>(x, ctx, n, done_unused);
+                  chain.template tick_tile<T>(x, ctx, n);
                   edge_write<F, T>(xt, lane, x);
                 } else {  // sample by sample, straight through LDS (no register tile: keeps it out of scratch)
                   for (u32 j = 0; j < m; ++j) {
                     ev.upto(base + n + j, base, 0, SRC_SLOTS, on);
-                    xt[j * 64 + lane] = chain.tick((F)0, ctx, n + j, done_unused);
+                    xt[j * 64 + lane] = chain.tick((F)0, ctx, n + j);
                   }
                 }
               },
@@ -334,7 +333,6 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
     PostT post;
     post.load(a.state + voice, a.stride);
     EventCursor<F> ev(a, voice, live);
-    u32 done_unused = 0xFFFFFFFFu;
     auto on = [&](u32 op, u32 slot, u64 bits, u32 rel) {
       if (slot < (u32)ENV_BASE) SvfOut::on_event<F>(mo, op, slot - SVF_BASE, bits);
       else post.on_event(op, slot, bits, rel);
@@ -371,14 +369,14 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
                   edge_read<F, T>(et, lane, e);
 #pragma unroll
                   for (int j = 0; j < T; ++j) x[j] = SvfOut::combine<F, FMA>(mo, x[j], v1[j], v2[j]) * e[j];
-                  post.template tick_tile<T>(x, ctx, n, done_unused);
+                  post.template tick_tile<T>(x, ctx, n);
 #pragma unroll
                   for (int j = 0; j < T; ++j) out[j * TS] = x[j];
                 } else {
                   for (u32 j = 0; j < m; ++j) {
                     events_upto(base + n + j, base);
                     const F y = SvfOut::combine<F, FMA>(mo, xt[j * 64 + lane], v1t[j * 64 + lane], v2t[j * 64 + lane]) * et[j * 64 + lane];
-                    out[j * TS] = post.tick(y, ctx, n + j, done_unused);
+                    out[j * TS] = post.tick(y, ctx, n + j);
                   }
                 }
               },

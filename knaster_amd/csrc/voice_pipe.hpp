@@ -47,7 +47,7 @@ template <typename F> struct PipeShared {
 // One stage group = one wavefront.  I: group index, NG: number of chain groups (mixer excluded),
 // LAST_ENV: index of the group holding the chain's last envelope stage (-1: none).
 template <typename F, bool FMA, int NG, int I, int BASE, int LAST_ENV, typename G>
-__device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
+__device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
   typedef typename GroupChain<F, FMA, BASE, G>::type ChainT;
   typedef typename WordOf<F>::type W;
   constexpr int T = PipeTile<F>::value;
@@ -69,7 +69,6 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
   u32 next_frame = 0xFFFFFFFFu;
   if (ev_i < ev_end) next_frame = a.events[ev_i].frame;
-  u32 done_frame = 0xFFFFFFFFu;
   u32 base = 0;  // absolute frame of the current block's frame 0
   auto apply_events_upto = [&](u32 n_abs) {
     while (next_frame <= n_abs) {
@@ -127,11 +126,11 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
       busy_in += t1 - t0;
 #endif
       if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev_inside)) {
-        chain.template tick_tile<T>(x, ctx, n, done_frame);
+        chain.template tick_tile<T>(x, ctx, n);
       } else {
         for (u32 j = 0; j < m; ++j) {
           apply_events_upto(base + n + j);
-          x[j] = chain.tick(x[j], ctx, n + j, done_frame);
+          x[j] = chain.tick(x[j], ctx, n + j);
         }
       }
       {  // every group, the last one included, hands its tile on as 64 rows of T samples (16-byte LDS stores)
@@ -173,17 +172,13 @@ __device__ __forceinline__ void pipe_run_group(const PipeShared<F>& sh, const Vo
   }
 #endif
   if (live) chain.store(a.state + voice, a.stride);
-  if (GroupInfo<G>::has_env) {
-    const bool any_done = live && done_frame != 0xFFFFFFFFu;
-    if (I == LAST_ENV && live) a.done_frames[voice] = done_frame;
-    const u64 bd = __builtin_amdgcn_ballot_w64(any_done);
-    if (lane == 0 && bd) atomicOr(&a.flags[0], 1u);
-    if (I == LAST_ENV) {
-      const bool running = live && !chain.last_env_stopped(false);
-      const u64 br = __builtin_amdgcn_ballot_w64(running);
-      if (lane == 0 && br) atomicAdd(&a.flags[1], (u32)__builtin_popcountll(br));
-    }
+  const u32 done_frame = chain.collect_done(0xFFFFFFFFu);  // this group's envelopes; the kernel combines the groups in order
+  if (GroupInfo<G>::has_env && I == LAST_ENV) {
+    const bool running = live && !chain.last_env_stopped(false);
+    const u64 br = __builtin_amdgcn_ballot_w64(running);
+    if (lane == 0 && br) atomicAdd(&a.flags[1], (u32)__builtin_popcountll(br));
   }
+  return done_frame;
 }
 
 // The mixer wavefront: lane j folds frame j of the tile the last chain group finished in the previous step over
@@ -250,13 +245,11 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
 }
 
 template <typename F, bool FMA, int NG, int I, int BASE, int LAST_ENV, typename G, typename... Rest>
-__device__ __forceinline__ void pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
-  if (wave == I) {
-    pipe_run_group<F, FMA, NG, I, BASE, LAST_ENV, G>(sh, a, lane, v0, nv);
-    return;
-  }
+__device__ __forceinline__ u32 pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
+  if (wave == I) return pipe_run_group<F, FMA, NG, I, BASE, LAST_ENV, G>(sh, a, lane, v0, nv);
   if constexpr (sizeof...(Rest) > 0)
-    pipe_dispatch<F, FMA, NG, I + 1, BASE + GroupInfo<G>::slots, LAST_ENV, Rest...>(wave, sh, a, lane, v0, nv);
+    return pipe_dispatch<F, FMA, NG, I + 1, BASE + GroupInfo<G>::slots, LAST_ENV, Rest...>(wave, sh, a, lane, v0, nv);
+  return 0xFFFFFFFFu;
 }
 
 template <int I, typename... Gs> struct LastEnv;
@@ -295,8 +288,26 @@ __global__ void __launch_bounds__((sizeof...(Gs) + 1) * 64) voice_pipe_kernel(Vo
   const u32 wave_global = blockIdx.x;  // one 64-voice wavefront-group per workgroup
   const u32 v0 = wave_global * 64u;
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
+  u32 done_frame = 0xFFFFFFFFu;
   if (wave == NG) pipe_run_mixer<F, NG>(sh, a, lane, wave_global, v0, nv);
-  else pipe_dispatch<F, FMA, NG, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, v0, nv);
+  else done_frame = pipe_dispatch<F, FMA, NG, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, v0, nv);
+  // mark_done of a voice = that of the last node in task order that set one: combine the groups in chain order
+  constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);
+  if constexpr (kAnyEnv) {
+    u32* marks = reinterpret_cast<u32*>(edge);  // the tiles are dead: every wavefront is past its last barrier-separated read
+    __syncthreads();
+    if (wave < NG) marks[wave * 64 + lane] = done_frame;
+    __syncthreads();
+    if (wave == 0) {
+      u32 d = 0xFFFFFFFFu;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) d = marks[g * 64 + lane] != 0xFFFFFFFFu ? marks[g * 64 + lane] : d;
+      const bool live = (u32)lane < nv;
+      if (live) a.done_frames[v0 + lane] = d;
+      const u64 bd = __builtin_amdgcn_ballot_w64(live && d != 0xFFFFFFFFu);
+      if (lane == 0 && bd) atomicOr(&a.flags[0], 1u);
+    }
+  }
 }
 
 }  // namespace knh_dev

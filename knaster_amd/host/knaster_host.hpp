@@ -110,6 +110,8 @@ struct UGenSpec {
 };
 inline UGenSpec SinWt(double freq) { return UGenSpec(KNH_STAGE_SIN_WT, {freq}); }
 inline UGenSpec SinNumeric(double freq) { return UGenSpec(KNH_STAGE_SIN_NUMERIC, {freq}); }
+inline UGenSpec Phasor(double freq) { return UGenSpec(KNH_STAGE_PHASOR, {freq}); }        // osc.rs:172-214
+inline UGenSpec SafetyLimiter() { return UGenSpec(KNH_STAGE_SAFETY_LIMITER, {}); }        // dynamics.rs:9-31
 inline UGenSpec SvfFilter(SvfFilterType ty, double cutoff, double q, double gain_db) {
   return UGenSpec(KNH_STAGE_SVF, {static_cast<double>(ty), cutoff, q, gain_db});
 }
@@ -235,7 +237,10 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
   static const char* val[] = {"value"};
   static const char* seg[] = {"time_scale", "jump_to_segment", "t_restart", "t_stop"};
   static const char* dly[] = {"delay_time"};
+  static const char* frq[] = {"freq"};
   switch (kind) {
+    case KNH_STAGE_PHASOR: *n = 1; return frq;
+    case KNH_STAGE_SAFETY_LIMITER: *n = 0; return frq;
     case KNH_STAGE_SAMPLE_DELAY: *n = 1; return dly;
     case KNH_STAGE_MUL_ENVELOPE: *n = 4; return seg;
     case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: *n = 3; return sin;
@@ -317,7 +322,7 @@ class Graph {
     }
     const UGenSpec& s = n.spec;
     if (s.is_env || s.is_constant) throw GraphError("an envelope/constant must be an operand of * + - /");
-    const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC;
+    const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR;
     uint16_t flags = 0;
     if (source) {
       if (n.link_source >= 0) {

@@ -898,6 +898,46 @@ struct Envelope : UGen<F> {
 };
 
 // ---------------------------------------------------------------------------
+// Phasor -- knaster_core_dsp/src/ugens/osc.rs:172-214;  SafetyLimiter -- ugens/dynamics.rs:9-31
+// ---------------------------------------------------------------------------
+template <typename F>
+struct Phasor : UGen<F> {
+  double phase = 0.0, step, freq_to_phase_step_mult = 0.0;
+  explicit Phasor(double freq) : step(freq) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"freq"}; }
+  void set_freq(double freq) { step = freq_to_phase_step_mult == 0.0 ? freq : freq * freq_to_phase_step_mult; }
+  void init(uint32_t sample_rate, size_t) override {
+    freq_to_phase_step_mult = 1.0 / static_cast<double>(sample_rate);
+    set_freq(step);
+  }
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override {
+    out[0] = fnew<F>(phase);
+    phase += step;
+    while (phase >= 1.0) phase -= 1.0;
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    if (index == 0) set_freq(v.float_or_panic());
+    else ctx.rt_log("Unknown parameter set for Phasor");
+  }
+};
+template <typename F>
+struct SafetyLimiter : UGen<F> {
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 0; }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override {
+    F s = in[0];
+    if (s < F(-1)) s = F(-1);  // f32::clamp(min, max): NaN in, NaN out
+    if (s > F(1)) s = F(1);
+    out[0] = std::isnan(s) ? F(0) : s;
+  }
+  void param_apply(AudioCtx&, size_t, ParameterValue) override {}
+};
+
+// ---------------------------------------------------------------------------
 // SampleDelay -- knaster_core_dsp/src/ugens/delay.rs:14-50
 // ---------------------------------------------------------------------------
 template <typename F>

@@ -24,7 +24,8 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: return 1;
     case KNH_STAGE_WR_MUL: case KNH_STAGE_WR_ADD: case KNH_STAGE_WR_SUB: return 1;
     case KNH_STAGE_WR_VSUB: case KNH_STAGE_WR_DIV: case KNH_STAGE_WR_VDIV: case KNH_STAGE_WR_POWF: case KNH_STAGE_WR_POWI:
-    case KNH_STAGE_POW_CONST: case KNH_STAGE_SAMPLE_DELAY: return 1;
+    case KNH_STAGE_POW_CONST: case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_PHASOR: return 1;
+    case KNH_STAGE_SAFETY_LIMITER: return 0;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -67,6 +68,8 @@ struct VoiceChainBuilder {
           break;
         case KNH_STAGE_ONEPOLE_LPF: core = std::make_unique<OnePoleLpf<F>>(fnew<F>(a[0])); break;
         case KNH_STAGE_ONEPOLE_HPF: core = std::make_unique<OnePoleHpf<F>>(); break;
+        case KNH_STAGE_PHASOR: core = std::make_unique<Phasor<F>>(a[0]); break;
+        case KNH_STAGE_SAFETY_LIMITER: core = std::make_unique<SafetyLimiter<F>>(); break;
         case KNH_STAGE_SAMPLE_DELAY: core = std::make_unique<SampleDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_MUL_ENV_ASR: core = std::make_unique<EnvAsr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
         case KNH_STAGE_MUL_ENV_AR: core = std::make_unique<EnvAr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
@@ -131,7 +134,7 @@ struct VoiceChainBuilder {
       if (two_node && !wr_targets.empty() && stages[s2 - 1].delayed_changes_per_block > 0)
         math = std::make_unique<WrPreciseTiming<F>>(stages[s2 - 1].delayed_changes_per_block, std::move(math));
 
-      const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC;
+      const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC || st.kind == KNH_STAGE_PHASOR;
       const bool ar = st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ);
       NodeKey core_key = g.push(std::move(core));
       targets[s].node = core_key;

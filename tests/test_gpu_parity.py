@@ -455,3 +455,24 @@ def test_c3_with_delay_line_against_oracle(knh, oracle):
         if block == 6:
             bank.param_apply_many(v, 4, 2, L.VALUE_TRIGGER)
     run_pair(knh, oracle, w, 12, ev, L.MIX_LEFT_FOLD)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_phasor_and_safety_limiter(knh, oracle, sample_type):
+    """Phasor (osc.rs:172-214: f64 ramp, `while phase >= 1` wrap, negative and > sample-rate frequencies) into
+    SafetyLimiter (dynamics.rs:9-31: clamp to +-1, NaN -> 0; a division by zero upstream supplies the NaN and infinities)."""
+    n = 90
+    v = np.arange(n, dtype=np.uint32)
+    w = configs.Workload("phasor", [Stage(L.STAGE_PHASOR, delayed_changes_per_block=1), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_WR_SUB),
+                                    Stage(L.STAGE_DIV_CONST), Stage(L.STAGE_SAFETY_LIMITER), Stage(L.STAGE_MUL_CONST)], n, 96, sample_type, 2)
+    freq = 20.0 + 37.0 * v
+    w.ctor = {0: freq.reshape(n, 1), 1: np.full((n, 1), 3.0), 2: np.full((n, 1), 1.5),
+              3: np.where(v % 9 == 0, 0.0, 0.5).reshape(n, 1),  # x / 0: +-inf and, where x == 0, NaN
+              5: np.full((n, 1), 1.0 / n)}
+
+    def ev(block, bank):
+        if block == 2:  # more than one wrap per sample, and a ramp that runs backwards
+            bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, np.where(v % 2 == 0, 48000.0 * 2.75, -333.0), delays=(v % 96).astype(np.uint16))
+        if block == 4:
+            bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, freq * 0.5)
+    run_pair(knh, oracle, w, 6, ev, L.MIX_TREE)

@@ -24,6 +24,7 @@ PROCESSORS = [
     (L.STAGE_MUL_ENV_AR, []),
     (L.STAGE_SAMPLE_DELAY, [(0, 0.0, 0.004)]),
     (L.STAGE_MUL_ENVELOPE, [(0, 0.5, 2.0)]),
+    (L.STAGE_SAFETY_LIMITER, []),
 ]
 WRAPPERS = [L.STAGE_WR_MUL, L.STAGE_WR_ADD, L.STAGE_WR_SUB, L.STAGE_WR_VSUB, L.STAGE_WR_DIV, L.STAGE_WR_POWI]
 
@@ -36,7 +37,7 @@ def ctor_for(kind, n, rng, p):
         return np.stack([ty, p["cutoff"], p["q"], rng.uniform(-6.0, 6.0, n)], axis=1)
     if kind == L.STAGE_ONEPOLE_LPF:
         return p["cutoff"].reshape(n, 1)
-    if kind == L.STAGE_ONEPOLE_HPF:
+    if kind in (L.STAGE_ONEPOLE_HPF, L.STAGE_SAFETY_LIMITER):
         return None
     if kind in (L.STAGE_MUL_ENV_ASR, L.STAGE_MUL_ENV_AR):
         return np.stack([p["attack"] * 0.2, p["release"] * 0.02], axis=1)
@@ -64,7 +65,8 @@ def random_chain(seed):
     bs = int(rng.choice([32, 64, 100, 128]))
     st = L.F64 if seed % 4 == 3 else L.F32
     p = configs.voice_parameters(n)
-    stages, ctor, changes, triggers = [Stage(L.STAGE_SIN_WT)], {0: ctor_for(L.STAGE_SIN_WT, n, rng, p)}, [], []
+    src = L.STAGE_PHASOR if seed % 5 == 4 else L.STAGE_SIN_WT  # both constructors take a frequency
+    stages, ctor, changes, triggers = [Stage(src)], {0: ctor_for(L.STAGE_SIN_WT, n, rng, p)}, [], []
     have_delay = have_segenv = False
     for _ in range(int(rng.integers(2, 6))):
         if rng.random() < 0.3:
