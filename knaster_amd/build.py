@@ -65,6 +65,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     write_jit_source()
     extra = ["-DKNH_DAG_STAMPS"] if os.environ.get("KNH_BUILD_STAMPS") == "1" else []  # diagnostic build only
+    extra += os.environ.get("KNH_EXTRA_FLAGS", "").split()
     cmd = [_hipcc(), *FLAGS, *extra, "-o", LIB + ".tmp", *SOURCES]
     if verbose:
         print("[knaster_amd.build]", " ".join(cmd), flush=True)
