@@ -109,6 +109,11 @@ typedef enum knh_value_kind {
  *     At most one per chain.
  * KNH_STAGE_PHASOR          g.push(Phasor::new(freq))           osc.rs:172-214       1    freq
  *     a source like SinWt: a 0..1 ramp, f64 phase and step whatever F is.  params: 0 freq
+ * KNH_STAGE_POLYBLEP        g.push(PolyBlep::new(waveform, freq))   polyblep.rs:123-508   1    waveform (0..13), freq
+ *     a source: band-limited saw, sine, cosine, triangle, square, rectangle, ramp, modified triangle / square, half- and
+ *     full-wave rectified sine, triangular pulse, fixed and variable trapezoid (the reference's Waveform order; any other
+ *     value is Sawtooth).  params: 0 freq, 1 pulse_width, 2 waveform(integer).  Bit-exact except where the reference
+ *     calls sin/cos (waveforms 1, 2, 9, 10, and every waveform at or above sample_rate / 4): device libm there.
  * KNH_STAGE_SAFETY_LIMITER  x >> g.push(SafetyLimiter::new())   dynamics.rs:9-31     1    (none)
  *     clamp to [-1, 1], NaN -> 0; no parameters, no state
  *     WrMul: params: 0 = the reference's "wr_mul" (index T::Parameters of the
@@ -141,7 +146,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_SAMPLE_DELAY = 21,
   KNH_STAGE_PHASOR = 22,
   KNH_STAGE_SAFETY_LIMITER = 23,
-  KNH_STAGE_KIND_COUNT = 24
+  KNH_STAGE_POLYBLEP = 24,
+  KNH_STAGE_KIND_COUNT = 25
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

@@ -76,7 +76,7 @@ def config(name: str, n_voices: int | None = None, block_size: int | None = None
     name = name.upper()
     defaults = {"C1": (1, 64, L.F32), "C2": (1024, 256, L.F32), "C3": (16384, 512, L.F32),
                 "C4": (65536, 512, L.F64), "C5": (4096, 128, L.F32),
-                "D3": (16384, 512, L.F32)}
+                "D3": (16384, 512, L.F32), "B3": (16384, 512, L.F32)}
     nv, bs, st = defaults[name]
     nv = n_voices or nv
     bs = block_size or bs
@@ -98,6 +98,16 @@ def config(name: str, n_voices: int | None = None, block_size: int | None = None
                      description="SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr")
         svf = np.stack([np.full(nv, float(L.SVF_LOW)), p["cutoff"], p["q"], np.zeros(nv)], axis=1)
         w.ctor = {0: col(p["freq"]), 1: col(gain), 2: svf, 3: np.stack([p["attack"], p["release"]], axis=1)}
+        w.restart = (3, 3)
+        w.release = (3, 2, 32)
+    elif name == "B3":  # not a BASELINE.json config: the C3 voice with a band-limited PolyBlep oscillator; one waveform per
+        # 64-voice group (a wavefront executes every waveform its lanes hold, so a bank is laid out by waveform)
+        w = Workload(name, [Stage(L.STAGE_POLYBLEP), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_SVF),
+                            Stage(L.STAGE_MUL_ENV_ASR, delayed_changes_per_block=precise)], nv, bs, st,
+                     description="PolyBlep((voice / 64) % 14).wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr")
+        svf = np.stack([np.full(nv, float(L.SVF_LOW)), p["cutoff"], p["q"], np.zeros(nv)], axis=1)
+        w.ctor = {0: np.stack([(np.arange(nv) // 64) % 14, p["freq"]], axis=1).astype(np.float64), 1: col(gain), 2: svf,
+                  3: np.stack([p["attack"], p["release"]], axis=1)}
         w.restart = (3, 3)
         w.release = (3, 2, 32)
     elif name == "D3":  # not a BASELINE.json config: C3 with a SampleDelay behind the filter (per-voice rings in HBM)

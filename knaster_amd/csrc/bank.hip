@@ -62,6 +62,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* SAMPLE_DELAY*/ {4, 1, 1, 1, 'D', {"delay_time"}},
     /* PHASOR      */ {4, 1, 1, 1, 'P', {"freq"}},
     /* SAFETY_LIM  */ {0, 0, 0, 1, 'X', {nullptr}},
+    /* POLYBLEP    */ {5, 3, 2, 1, 'B', {"freq", "pulse_width", "waveform"}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -73,7 +74,7 @@ inline int stage_cost(char c) {
   switch (c) {
     case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
     case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
-    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45;
     default: return 1;
   }
 }
@@ -106,6 +107,7 @@ int expected_value_kind(uint16_t kind, uint32_t param) {
     case KNH_STAGE_MUL_ENV_ASR: return param >= 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
     case KNH_STAGE_MUL_ENV_AR: return param == 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
     case KNH_STAGE_MUL_ENVELOPE: return param == 0 ? KNH_VALUE_FLOAT : param == 1 ? KNH_VALUE_INTEGER : KNH_VALUE_TRIGGER;
+    case KNH_STAGE_POLYBLEP: return param == 2 ? KNH_VALUE_INTEGER : KNH_VALUE_FLOAT;
     default: return KNH_VALUE_FLOAT;
   }
 }
@@ -492,6 +494,17 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 3, v) = static_cast<W>(static_cast<uint32_t>(sb >> 32));
           } break;
           case KNH_STAGE_SAFETY_LIMITER: break;
+          case KNH_STAGE_POLYBLEP: {  // polyblep.rs:136-153: new(waveform, freq), init -> set_freq: dt = freq / sample_rate
+            const F srf = static_cast<F>(sr);  // F::from(sample_rate)
+            const F freq = static_cast<F>(a[1]);
+            const F dt = freq != F(0) ? freq / srf : F(0);
+            const uint64_t wf = a[0] >= 0.0 && a[0] < 14.0 ? static_cast<uint64_t>(a[0]) : 0u;
+            slot(S.slot_base + 0, v) = fw(F(0));
+            slot(S.slot_base + 1, v) = fw(dt);
+            slot(S.slot_base + 2, v) = fw(F(0.5));
+            slot(S.slot_base + 3, v) = static_cast<W>(wf);
+            slot(S.slot_base + 4, v) = (dt * srf >= srf / F(4)) ? 1u : 0u;  // get_freq_in_hz() >= sample_rate / 4, :210
+          } break;
           case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:24-31 (new), :45-49 (init)
             if (v == 0) delay_len.assign(nv, 0u);
             // Seconds::from_secs_f64 / to_secs_f64 (knaster_primitives/src/time.rs:59-74), then `as usize`
@@ -753,6 +766,18 @@ struct Bank final : knh_bank {
           set(0, 1);  // t_restart: state = Attacking, t untouched (envelopes.rs:47-49,131-133)
         }
         break;
+      case KNH_STAGE_POLYBLEP: {  // polyblep.rs:158-182
+        const F srf = static_cast<F>(sample_rate);
+        if (param == 0) {
+          const F dt = static_cast<F>(f) / srf;
+          set(1, to_bits(dt));
+          set(4, (dt * srf >= srf / F(4)) ? 1u : 0u);
+        } else if (param == 1) {
+          set(2, to_bits(static_cast<F>(f)));
+        } else {  // Waveform::from(PInteger): out of range -> default (Sawtooth)
+          set(3, iv >= 0 && iv < 14 ? static_cast<uint64_t>(iv) : 0u);
+        }
+      } break;
       case KNH_STAGE_PHASOR: {  // osc.rs:189-196
         const uint64_t sb = to_bits(f * (1.0 / static_cast<double>(sample_rate)));
         set(2, static_cast<uint32_t>(sb));
@@ -1150,7 +1175,8 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
   bool have_x = false;
   for (uint32_t i = 0; i < n; ++i) {
     if (st[i].kind >= KNH_STAGE_KIND_COUNT) { *why = "unknown stage kind"; return KNH_ERR_INVALID_ARGUMENT; }
-    const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC || st[i].kind == KNH_STAGE_PHASOR;
+    const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC || st[i].kind == KNH_STAGE_PHASOR ||
+                        st[i].kind == KNH_STAGE_POLYBLEP;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ)) { *why = "SMOOTH_PARAMS and AR_FREQ cannot be combined"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1413,7 +1439,8 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: w += word * 3; break;
       case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
       case KNH_STAGE_SAMPLE_DELAY: w += word; break;
-      case KNH_STAGE_PHASOR: w += word * 2; break;  // + one sample read and one written per frame (ring in HBM)
+      case KNH_STAGE_PHASOR: w += word * 2; break;
+      case KNH_STAGE_POLYBLEP: w += word; break;  // + one sample read and one written per frame (ring in HBM)
       default: break;
     }
   }

@@ -43,6 +43,7 @@ static const KernelEntry kEntries[] = {
     KNH_CHAIN("Wasd", SinWt, AddVal, SubVal, DivVal),
     KNH_CHAIN("WmV", SinWt, MulVal, MulSegEnv),                 // SinWt.wr_mul * segment Envelope
     KNH_CHAIN("WmSDA", SinWt, MulVal, Svf, SampleDelay, MulAsr), // C3 with a delay line behind the filter (HBM-bound regime)
+    KNH_CHAIN("BmSA", PolyBlepOsc, MulVal, Svf, MulAsr),         // the C3 voice with a band-limited oscillator
 };
 
 template <typename F, bool FMA, typename... Gs>
@@ -66,6 +67,7 @@ typedef Group<MulVal> G_m;
 typedef Group<SinWt, MulVal, AddVal> G_Wma;
 typedef Group<SinWtAr, MulVal> G_Rm;
 typedef Group<SampleDelay, MulAsr> G_DA;
+typedef Group<PolyBlepOsc, MulVal> G_Bm;
 
 static const PipeEntry kPipes[] = {
     KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope (+ mixer wave)
@@ -76,6 +78,7 @@ static const PipeEntry kPipes[] = {
     KNH_PIPE("Nm", 2, G_N, G_m),           // C2
     KNH_PIPE("NSAm", 3, G_N, G_S, G_Am),
     KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA),  // the delay's HBM traffic rides in the envelope wave
+    KNH_PIPE("BmSA", 3, G_Bm, G_S, G_A),
 };
 const PipeEntry* find_pipe(const char* signature) {
   for (const PipeEntry& e : kPipes)
@@ -120,6 +123,7 @@ static const WideEntry kWides[] = {
     KNH_WIDE("Nm", SinNum, MulVal),
     KNH_WIDE("WmSA", SinWt, MulVal, Svf, MulAsr),
     KNH_WIDE("WmSDA", SinWt, MulVal, Svf, SampleDelay, MulAsr),
+    KNH_WIDE("BmSA", PolyBlepOsc, MulVal, Svf, MulAsr),
     KNH_WIDE("WSAm", SinWt, Svf, MulAsr, MulVal),
     KNH_WIDE("WmE", SinWt, MulVal, MulAr),
     KNH_WIDE("WmaRm", SinWt, MulVal, AddVal, SinWtAr, MulVal),

@@ -17,6 +17,8 @@
 // Accurate (not v_sin_f32) sine from the ROCm device library, linked by hipcc and hiprtc alike.
 extern "C" __device__ float __ocml_sin_f32(float);
 extern "C" __device__ double __ocml_sin_f64(double);
+extern "C" __device__ float __ocml_cos_f32(float);
+extern "C" __device__ double __ocml_cos_f64(double);
 extern "C" __device__ float __ocml_pow_f32(float, float);
 extern "C" __device__ double __ocml_pow_f64(double, double);
 
@@ -193,6 +195,177 @@ struct SafetyLimiter {
     for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
   }
   template <typename F> static __device__ __forceinline__ void on_event(Regs<F>&, u32, u32, u64, u32) {}
+};
+
+// PolyBlep -- polyblep.rs:123-508: fourteen waveforms with polynomial band-limiting of their steps (blep) and corners
+// (blamp).  Every waveform is + - * / and comparisons in the reference's order, except the four that call sin
+// (Sine, Cosine, Half/FullWaveRectifiedSine, and every waveform above sample_rate / 4): device libm, tolerance only.
+// slots: 0 t (phase 0..1)  1 dt = freq / sample_rate  2 pulse_width  3 waveform (u32)  4 dt * sample_rate >= sample_rate / 4
+struct PolyBlepOsc {
+  static constexpr int kSlots = 5;
+  static constexpr u32 kMutableMask = 0b00001u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  template <typename F> struct Regs { F t, dt, pw; u32 wf, fast; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.t = word_to_f<F>(s[0]); r.dt = word_to_f<F>(s[st]); r.pw = word_to_f<F>(s[2 * st]);
+    r.wf = (u32)s[3 * st]; r.fast = (u32)s[4 * st];
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = f_to_word(r.t); }
+  static __device__ __forceinline__ float trunc_f(float v) { return __builtin_truncf(v); }
+  static __device__ __forceinline__ double trunc_f(double v) { return __builtin_trunc(v); }
+  static __device__ __forceinline__ float sin_f(float v) { return __ocml_sin_f32(v); }
+  static __device__ __forceinline__ double sin_f(double v) { return __ocml_sin_f64(v); }
+  static __device__ __forceinline__ float cos_f(float v) { return __ocml_cos_f32(v); }
+  static __device__ __forceinline__ double cos_f(double v) { return __ocml_cos_f64(v); }
+  template <typename F> static __device__ __forceinline__ F wrap(F v) { return v - trunc_f(v); }  // t -= bitwise_or_zero(t)
+  template <typename F> static __device__ __forceinline__ F sq(F v) { return v * v; }
+  template <typename F> static __device__ __forceinline__ F blep(F t, F dt) {  // :49-57
+    if (t < dt) return -sq<F>(t / dt - (F)1);
+    if (t > (F)1 - dt) return sq<F>((t - (F)1) / dt + (F)1);
+    return (F)0;
+  }
+  template <typename F> static __device__ __forceinline__ F blamp(F t, F dt) {  // :60-70
+    if (t < dt) { t = t / dt - (F)1; return ((F)-1 / (F)3) * sq<F>(t) * t; }
+    if (t > (F)1 - dt) { t = (t - (F)1) / dt + (F)1; return ((F)1 / (F)3) * sq<F>(t) * t; }
+    return (F)0;
+  }
+  template <typename F> static __device__ __forceinline__ F clamp1(F v) { return v < (F)-1 ? (F)-1 : (v > (F)1 ? (F)1 : v); }
+  template <typename F> static __device__ __forceinline__ F fold_tri(F y) {  // the 4t triangle fold shared by tri / trap / trap2
+    if (y >= (F)3) return y - (F)4;
+    if (y > (F)1) return (F)2 - y;
+    return y;
+  }
+  // One instance per kernel, called: inlined into every sample of an unrolled tile it would be ~400 instructions x 32.
+  template <typename F> static __device__ __attribute__((noinline)) F sample(F t, F dt, F pw_in, u32 wf, u32 fast) {
+    Regs<F> r;
+    r.t = t; r.dt = dt; r.pw = pw_in; r.wf = wf; r.fast = fast;
+    constexpr F TAU = (F)6.28318530717958647692528676655900577, PI = (F)3.14159265358979323846264338327950288;
+    if (fast) wf = 1u;  // next_sample, :210-212
+    switch (wf) {
+      case 1u: return sin_f(t * TAU);
+      case 2u: return cos_f(t * TAU);
+      case 3u: {  // tri, :264-285
+        const F t1 = wrap<F>(t + (F)0.25), t2 = wrap<F>(t + (F)0.75);
+        F y = fold_tri<F>(t * (F)4);
+        return y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+      }
+      case 4u: {  // sqr, :428-441
+        const F t2 = wrap<F>(t + (F)0.5);
+        const F y = t < (F)0.5 ? (F)1 : (F)-1;
+        return y + (blep<F>(t, dt) - blep<F>(t2, dt));
+      }
+      case 5u: {  // rect, :471-484
+        const F t2 = wrap<F>(t + (F)1 - r.pw);
+        F y = (F)-2 * r.pw;
+        if (t < r.pw) y = y + (F)2;
+        return y + (blep<F>(t, dt) - blep<F>(t2, dt));
+      }
+      case 6u: {  // ramp, :496-504
+        const F u = wrap<F>(t);
+        const F y = (F)1 - (F)2 * u;
+        return y + blep<F>(u, dt);
+      }
+      case 7u: {  // tri2, :287-311
+        F pw = r.pw < (F)0.9999 ? r.pw : (F)0.9999;  // f32::min / max: a NaN pulse width turns into the bound
+        if (!(r.pw == r.pw)) pw = (F)0.9999;
+        pw = pw > (F)0.0001 ? pw : (F)0.0001;
+        const F t1 = wrap<F>(t + (F)0.5 * pw), t2 = wrap<F>(t + (F)1 - (F)0.5 * pw);
+        F y = t * (F)2;
+        if (y >= (F)2 - pw) y = (y - (F)2) / pw;
+        else if (y >= pw) y = (F)1 - (y - pw) / ((F)1 - pw);
+        else y = y / pw;
+        return y + dt / (pw - pw * pw) * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+      }
+      case 8u: {  // sqr2, :443-469
+        F t1 = wrap<F>(t + (F)0.875 + (F)0.25 * (r.pw - (F)0.5));
+        F t2 = wrap<F>(t + (F)0.375 + (F)0.25 * (r.pw - (F)0.5));
+        F y = t1 < (F)0.5 ? (F)1 : (F)-1;
+        y = y + (blep<F>(t1, dt) - blep<F>(t2, dt));
+        t1 = wrap<F>(t1 + (F)0.5 * ((F)1 - r.pw));
+        t2 = wrap<F>(t2 + (F)0.5 * ((F)1 - r.pw));
+        y = y + (t1 < (F)0.5 ? (F)1 : (F)-1);
+        y = y + (blep<F>(t1, dt) - blep<F>(t2, dt));
+        return (F)0.5 * y;
+      }
+      case 9u: {  // half, :231-247
+        const F t2 = wrap<F>(t + (F)0.5);
+        F y = t < (F)0.5 ? (F)2 * sin_f(t * TAU) - (F)2 / PI : (F)-2 / PI;
+        return y + TAU * dt * (blamp<F>(t, dt) + blamp<F>(t2, dt));
+      }
+      case 10u: {  // full, :249-257
+        const F u = wrap<F>(t + (F)0.25);
+        const F y = (F)2 * sin_f(u * PI) - (F)4 / PI;
+        return y + TAU * dt * blamp<F>(u, dt);
+      }
+      case 11u: {  // trip, :313-351
+        const F pw = r.pw;
+        const F t1 = wrap<F>(t + (F)0.75 + (F)0.5 * pw);
+        F y;
+        if (t1 >= pw) {
+          y = -pw;
+        } else {
+          y = (F)4 * t1;
+          y = y >= (F)2 * pw ? (F)4 - y / pw - pw : y / pw - pw;
+        }
+        if (pw > (F)0) {
+          const F t2 = wrap<F>(t1 + (F)1 - (F)0.5 * pw), t3 = wrap<F>(t1 + (F)1 - pw);
+          y = y + (F)2 * dt / pw * (blamp<F>(t1, dt) - (F)2 * blamp<F>(t2, dt) + blamp<F>(t3, dt));
+        }
+        return y;
+      }
+      case 12u: {  // trap, :353-386
+        F y = fold_tri<F>((F)4 * t);
+        y = clamp1<F>((F)2 * y);
+        F t1 = wrap<F>(t + (F)0.125), t2 = wrap<F>(t1 + (F)0.5);
+        y = y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+        t1 = wrap<F>(t + (F)0.375);
+        t2 = wrap<F>(t1 + (F)0.5);
+        return y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+      }
+      case 13u: {  // trap2, :388-426
+        F pw = r.pw < (F)0.9999 ? r.pw : (F)0.9999;
+        if (!(r.pw == r.pw)) pw = (F)0.9999;
+        const F scale = (F)1 / ((F)1 - pw);
+        F y = fold_tri<F>((F)4 * t);
+        y = clamp1<F>(scale * y);
+        F t1 = wrap<F>(t + (F)0.25 - (F)0.25 * pw), t2 = wrap<F>(t1 + (F)0.5);
+        y = y + scale * (F)2 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+        t1 = wrap<F>(t + (F)0.25 + (F)0.25 * pw);
+        t2 = wrap<F>(t1 + (F)0.5);
+        return y + scale * (F)2 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+      }
+      default: {  // saw (0, and every out-of-range value), :486-494
+        const F u = wrap<F>(t + (F)0.5);
+        const F y = (F)2 * u - (F)1;
+        return y - blep<F>(u, dt);
+      }
+    }
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
+    const F y = sample<F>(r.t, r.dt, r.pw, r.wf, r.fast);
+    r.t = r.t + r.dt;  // inc, :219-222
+    r.t = r.t - trunc_f(r.t);
+    return y;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    const F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    switch (rel) {
+      case 0: r.t = v; break; case 1: r.dt = v; break; case 2: r.pw = v; break;
+      case 3: r.wf = (u32)bits; break; default: r.fast = (u32)bits; break;
+    }
+  }
 };
 
 // SinNumeric -- osc.rs:222-271.  slots: 0 phase, 1 phase_offset, 2 phase_increment

@@ -110,6 +110,8 @@ struct UGenSpec {
 };
 inline UGenSpec SinWt(double freq) { return UGenSpec(KNH_STAGE_SIN_WT, {freq}); }
 inline UGenSpec SinNumeric(double freq) { return UGenSpec(KNH_STAGE_SIN_NUMERIC, {freq}); }
+// PolyBlep::new(waveform, freq) -- polyblep.rs:136-145; Waveform in the reference's order (Sawtooth = 0 ... TrapezoidVariable = 13)
+inline UGenSpec PolyBlep(int waveform, double freq) { return UGenSpec(KNH_STAGE_POLYBLEP, {static_cast<double>(waveform), freq}); }
 inline UGenSpec Phasor(double freq) { return UGenSpec(KNH_STAGE_PHASOR, {freq}); }        // osc.rs:172-214
 inline UGenSpec SafetyLimiter() { return UGenSpec(KNH_STAGE_SAFETY_LIMITER, {}); }        // dynamics.rs:9-31
 inline UGenSpec SvfFilter(SvfFilterType ty, double cutoff, double q, double gain_db) {
@@ -240,6 +242,7 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
   static const char* frq[] = {"freq"};
   switch (kind) {
     case KNH_STAGE_PHASOR: *n = 1; return frq;
+    case KNH_STAGE_POLYBLEP: { static const char* pb[] = {"freq", "pulse_width", "waveform"}; *n = 3; return pb; }
     case KNH_STAGE_SAFETY_LIMITER: *n = 0; return frq;
     case KNH_STAGE_SAMPLE_DELAY: *n = 1; return dly;
     case KNH_STAGE_MUL_ENVELOPE: *n = 4; return seg;
@@ -322,7 +325,7 @@ class Graph {
     }
     const UGenSpec& s = n.spec;
     if (s.is_env || s.is_constant) throw GraphError("an envelope/constant must be an operand of * + - /");
-    const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR;
+    const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR || s.kind == KNH_STAGE_POLYBLEP;
     uint16_t flags = 0;
     if (source) {
       if (n.link_source >= 0) {

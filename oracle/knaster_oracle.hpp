@@ -898,6 +898,196 @@ struct Envelope : UGen<F> {
 };
 
 // ---------------------------------------------------------------------------
+// PolyBlep -- knaster_core_dsp/src/ugens/polyblep.rs:41-508
+// ---------------------------------------------------------------------------
+enum class Waveform : uint8_t {
+  Sawtooth = 0, Sine, Cosine, Triangle, Square, Rectangle, Ramp, ModifiedTriangle, ModifiedSquare,
+  HalfWaveRectifiedSine, FullWaveRectifiedSine, TriangularPulse, TrapezoidFixed, TrapezoidVariable
+};
+inline Waveform waveform_from_pinteger(uint64_t v) { return v < 14 ? static_cast<Waveform>(v) : Waveform::Sawtooth; }  // macro: unwrap_or(default)
+template <typename F>
+struct PolyBlep : UGen<F> {
+  Waveform waveform;
+  F sample_rate = F(0), freq_in_hz, dt = F(0), pulse_width = F(0.5), t = F(0);
+  PolyBlep(Waveform wf, F freq) : waveform(wf), freq_in_hz(freq) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 3; }
+  std::vector<std::string> param_descriptions() const override { return {"freq", "pulse_width", "waveform"}; }
+  static F tau() { return static_cast<F>(6.28318530717958647692528676655900577); }
+  static F pi() { return static_cast<F>(3.14159265358979323846264338327950288); }
+  static F square_number(F v) { return v * v; }
+  static F bitwise_or_zero(F v) { return std::trunc(v); }
+  static F blep(F t, F dt) {
+    if (t < dt) return -square_number(t / dt - F(1));
+    if (t > F(1) - dt) return square_number((t - F(1)) / dt + F(1));
+    return F(0);
+  }
+  static F blamp(F t, F dt) {
+    if (t < dt) {
+      t = t / dt - F(1);
+      return -F(1) / F(3) * square_number(t) * t;
+    }
+    if (t > F(1) - dt) {
+      t = (t - F(1)) / dt + F(1);
+      return F(1) / F(3) * square_number(t) * t;
+    }
+    return F(0);
+  }
+  static F fmin_rs(F a, F b) { return std::isnan(a) ? b : (std::isnan(b) ? a : (a < b ? a : b)); }  // f32::min
+  static F fmax_rs(F a, F b) { return std::isnan(a) ? b : (std::isnan(b) ? a : (a > b ? a : b)); }
+  static F clamp_rs(F v, F lo, F hi) { return v < lo ? lo : (v > hi ? hi : v); }                    // f32::clamp
+  void set_freq(F f) { freq_in_hz = f; dt = f / sample_rate; }
+  F get_freq_in_hz() const { return dt * sample_rate; }
+  void init(uint32_t sr, size_t) override {
+    sample_rate = static_cast<F>(sr);
+    if (dt == F(0) && freq_in_hz != F(0)) set_freq(freq_in_hz);
+  }
+  F wrap(F v) const { return v - bitwise_or_zero(v); }
+  F sin_w() const { return std::sin(t * tau()); }
+  F cos_w() const { return std::cos(t * tau()); }
+  F half() const {
+    F t2 = wrap(t + F(0.5));
+    F y = t < F(0.5) ? F(2) * std::sin(t * tau()) - F(2) / pi() : -F(2) / pi();
+    y += tau() * dt * (blamp(t, dt) + blamp(t2, dt));
+    return y;
+  }
+  F full() const {
+    F u = wrap(t + F(0.25));
+    F y = F(2) * std::sin(u * pi()) - F(4) / pi();
+    y += tau() * dt * blamp(u, dt);
+    return y;
+  }
+  static F fold(F y) {
+    if (y >= F(3)) y -= F(4);
+    else if (y > F(1)) y = F(2) - y;
+    return y;
+  }
+  F tri() const {
+    F t1 = wrap(t + F(0.25)), t2 = wrap(t + F(0.75));
+    F y = fold(t * F(4));
+    y += F(4) * dt * (blamp(t1, dt) - blamp(t2, dt));
+    return y;
+  }
+  F tri2() const {
+    F pw = fmax_rs(fmin_rs(pulse_width, F(0.9999)), F(0.0001));
+    F t1 = wrap(t + F(0.5) * pw), t2 = wrap(t + F(1) - F(0.5) * pw);
+    F y = t * F(2);
+    if (y >= F(2) - pw) y = (y - F(2)) / pw;
+    else if (y >= pw) y = F(1) - (y - pw) / (F(1) - pw);
+    else y /= pw;
+    y += dt / (pw - pw * pw) * (blamp(t1, dt) - blamp(t2, dt));
+    return y;
+  }
+  F trip() const {
+    F t1 = wrap(t + F(0.75) + F(0.5) * pulse_width);
+    F y;
+    if (t1 >= pulse_width) {
+      y = -pulse_width;
+    } else {
+      y = F(4) * t1;
+      y = y >= F(2) * pulse_width ? F(4) - y / pulse_width - pulse_width : y / pulse_width - pulse_width;
+    }
+    if (pulse_width > F(0)) {
+      F t2 = wrap(t1 + F(1) - F(0.5) * pulse_width), t3 = wrap(t1 + F(1) - pulse_width);
+      y += F(2) * dt / pulse_width * (blamp(t1, dt) - F(2) * blamp(t2, dt) + blamp(t3, dt));
+    }
+    return y;
+  }
+  F trap() const {
+    F y = fold(F(4) * t);
+    y = clamp_rs(F(2) * y, -F(1), F(1));
+    F t1 = wrap(t + F(0.125)), t2 = wrap(t1 + F(0.5));
+    y += F(4) * dt * (blamp(t1, dt) - blamp(t2, dt));
+    t1 = wrap(t + F(0.375));
+    t2 = wrap(t1 + F(0.5));
+    y += F(4) * dt * (blamp(t1, dt) - blamp(t2, dt));
+    return y;
+  }
+  F trap2() const {
+    F pw = fmin_rs(pulse_width, F(0.9999));
+    F scale = F(1) / (F(1) - pw);
+    F y = fold(F(4) * t);
+    y = clamp_rs(scale * y, -F(1), F(1));
+    F t1 = wrap(t + F(0.25) - F(0.25) * pw), t2 = wrap(t1 + F(0.5));
+    y += scale * F(2) * dt * (blamp(t1, dt) - blamp(t2, dt));
+    t1 = wrap(t + F(0.25) + F(0.25) * pw);
+    t2 = wrap(t1 + F(0.5));
+    y += scale * F(2) * dt * (blamp(t1, dt) - blamp(t2, dt));
+    return y;
+  }
+  F sqr() const {
+    F t2 = wrap(t + F(0.5));
+    F y = t < F(0.5) ? F(1) : -F(1);
+    y += blep(t, dt) - blep(t2, dt);
+    return y;
+  }
+  F sqr2() const {
+    F t1 = wrap(t + F(0.875) + F(0.25) * (pulse_width - F(0.5)));
+    F t2 = wrap(t + F(0.375) + F(0.25) * (pulse_width - F(0.5)));
+    F y = t1 < F(0.5) ? F(1) : -F(1);
+    y += blep(t1, dt) - blep(t2, dt);
+    t1 = wrap(t1 + F(0.5) * (F(1) - pulse_width));
+    t2 = wrap(t2 + F(0.5) * (F(1) - pulse_width));
+    y += t1 < F(0.5) ? F(1) : -F(1);
+    y += blep(t1, dt) - blep(t2, dt);
+    return F(0.5) * y;
+  }
+  F rect() const {
+    F t2 = wrap(t + F(1) - pulse_width);
+    F y = -F(2) * pulse_width;
+    if (t < pulse_width) y += F(2);
+    y += blep(t, dt) - blep(t2, dt);
+    return y;
+  }
+  F saw() const {
+    F u = wrap(t + F(0.5));
+    F y = F(2) * u - F(1);
+    y -= blep(u, dt);
+    return y;
+  }
+  F ramp() const {
+    F u = wrap(t);
+    F y = F(1) - F(2) * u;
+    y += blep(u, dt);
+    return y;
+  }
+  F next_sample() const {
+    if (get_freq_in_hz() >= sample_rate / F(4)) return sin_w();
+    switch (waveform) {
+      case Waveform::Sine: return sin_w();
+      case Waveform::Cosine: return cos_w();
+      case Waveform::Triangle: return tri();
+      case Waveform::Square: return sqr();
+      case Waveform::Rectangle: return rect();
+      case Waveform::Sawtooth: return saw();
+      case Waveform::Ramp: return ramp();
+      case Waveform::ModifiedTriangle: return tri2();
+      case Waveform::ModifiedSquare: return sqr2();
+      case Waveform::HalfWaveRectifiedSine: return half();
+      case Waveform::FullWaveRectifiedSine: return full();
+      case Waveform::TriangularPulse: return trip();
+      case Waveform::TrapezoidFixed: return trap();
+      case Waveform::TrapezoidVariable: return trap2();
+    }
+    return F(0);
+  }
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override {
+    out[0] = next_sample();
+    t += dt;
+    t -= bitwise_or_zero(t);
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    switch (index) {
+      case 0: set_freq(fnew<F>(v.float_or_panic())); break;
+      case 1: pulse_width = fnew<F>(v.float_or_panic()); break;
+      case 2: waveform = waveform_from_pinteger(static_cast<uint64_t>(v.integer_or_panic())); break;
+      default: ctx.rt_log("Unknown parameter set for PolyBlep");
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
 // Phasor -- knaster_core_dsp/src/ugens/osc.rs:172-214;  SafetyLimiter -- ugens/dynamics.rs:9-31
 // ---------------------------------------------------------------------------
 template <typename F>

@@ -26,6 +26,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_WR_VSUB: case KNH_STAGE_WR_DIV: case KNH_STAGE_WR_VDIV: case KNH_STAGE_WR_POWF: case KNH_STAGE_WR_POWI:
     case KNH_STAGE_POW_CONST: case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_PHASOR: return 1;
     case KNH_STAGE_SAFETY_LIMITER: return 0;
+    case KNH_STAGE_POLYBLEP: return 2;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -69,6 +70,9 @@ struct VoiceChainBuilder {
         case KNH_STAGE_ONEPOLE_LPF: core = std::make_unique<OnePoleLpf<F>>(fnew<F>(a[0])); break;
         case KNH_STAGE_ONEPOLE_HPF: core = std::make_unique<OnePoleHpf<F>>(); break;
         case KNH_STAGE_PHASOR: core = std::make_unique<Phasor<F>>(a[0]); break;
+        case KNH_STAGE_POLYBLEP:
+          core = std::make_unique<PolyBlep<F>>(waveform_from_pinteger(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u), fnew<F>(a[1]));
+          break;
         case KNH_STAGE_SAFETY_LIMITER: core = std::make_unique<SafetyLimiter<F>>(); break;
         case KNH_STAGE_SAMPLE_DELAY: core = std::make_unique<SampleDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_MUL_ENV_ASR: core = std::make_unique<EnvAsr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;
@@ -134,7 +138,8 @@ struct VoiceChainBuilder {
       if (two_node && !wr_targets.empty() && stages[s2 - 1].delayed_changes_per_block > 0)
         math = std::make_unique<WrPreciseTiming<F>>(stages[s2 - 1].delayed_changes_per_block, std::move(math));
 
-      const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC || st.kind == KNH_STAGE_PHASOR;
+      const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC || st.kind == KNH_STAGE_PHASOR ||
+                             st.kind == KNH_STAGE_POLYBLEP;
       const bool ar = st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ);
       NodeKey core_key = g.push(std::move(core));
       targets[s].node = core_key;

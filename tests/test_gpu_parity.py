@@ -476,3 +476,44 @@ def test_phasor_and_safety_limiter(knh, oracle, sample_type):
         if block == 4:
             bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, freq * 0.5)
     run_pair(knh, oracle, w, 6, ev, L.MIX_TREE)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_polyblep_all_waveforms(knh, oracle, sample_type):
+    """PolyBlep (polyblep.rs:123-508): fourteen waveforms, pulse widths incl. the clamped extremes, frequency, pulse-width
+    and waveform changes.  Waveforms built from + - * / and comparisons are bit-exact; the four that call sin (and any
+    voice at or above sample_rate / 4, which the reference renders as a sine) are compared with a tolerance."""
+    n, bs = 14 * 8, 128
+    v = np.arange(n, dtype=np.uint32)
+    wf = (v % 14).astype(np.float64)
+    freq = 55.0 * 2.0 ** ((v // 14) * 0.9)  # 55 Hz .. 4.3 kHz
+    w = configs.Workload("polyblep", [Stage(L.STAGE_POLYBLEP, delayed_changes_per_block=1), Stage(L.STAGE_MUL_CONST)], n, bs, sample_type, 2)
+    w.ctor = {0: np.stack([wf, freq], axis=1), 1: np.full((n, 1), 1.0 / n)}
+    g, o = make_gpu(knh, w), make_oracle(oracle, w)
+    cur_wf, cur_freq = wf.copy(), freq.copy()
+    for block in range(8):
+        if block == 1:  # pulse widths across and beyond the clamps of tri2 / trap2, and 0 for trip's guard
+            pw = np.choose(v % 6, [0.5, 0.1, 0.9, 0.99995, 0.00001, 0.0])
+            for b in (g, o):
+                b.param_apply_many(v, 0, 1, L.VALUE_FLOAT, pw)
+        if block == 3:  # every third voice above sample_rate / 4 (rendered as a sine), at a sample-accurate offset
+            sel = v[::3]
+            cur_freq[::3] = 12000.0 + 100.0 * (sel % 7)
+            for b in (g, o):
+                b.param_apply_many(sel, 0, 0, L.VALUE_FLOAT, cur_freq[::3], delays=(sel % bs).astype(np.uint16))
+        if block == 5:  # rotate the waveforms; 14 and 99 are out of range -> Sawtooth
+            new_wf = (v + 5) % 16
+            new_wf = np.where(new_wf == 15, 99, new_wf)
+            cur_wf = np.where(new_wf < 14, new_wf, 0).astype(np.float64)
+            for b in (g, o):
+                b.param_apply_many(v, 0, 2, L.VALUE_INTEGER, ivalues=new_wf.astype(np.int64))
+        _, gv, _ = g.process_block_voices()
+        _, ov, _, _ = o.process_block()
+        exact = ~np.isin(cur_wf, [1, 2, 9, 10]) & (cur_freq < 12000.0)
+        if block in (3, 5):  # the block in which a change lands: the voice is exact or not depending on the frame
+            exact &= False
+        assert_bit_equal(gv[exact], ov[exact], f"block {block}: waveforms without sin")
+        assert np.max(np.abs(gv.astype(np.float64) - ov)) <= 4e-6 / n, f"block {block}"
+        assert np.abs(ov).max() > 0.1 / n
+    g.close()
+    o.close()

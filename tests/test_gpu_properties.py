@@ -74,7 +74,7 @@ def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pip
 
 
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C4", 300, 100), ("C5", 260, 128), ("C2", 200, 48),
-                                                      ("D3", 500, 512)])
+                                                      ("D3", 500, 512), ("B3", 300, 256)])
 def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
     """KNH_PIPELINE 0 = one wavefront per 64 voices, 1 = linear wave pipeline, 2 = five-role pipeline where built."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
@@ -84,7 +84,7 @@ def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_vo
         g = make_gpu(knh, w)
         res = []
         for block in range(6):
-            if name in ("C3", "C4", "D3"):
+            if name in ("C3", "C4", "D3", "B3"):
                 c3_script(w, block, g)
             if name == "C5":
                 e = configs.c5_events(w, block)
@@ -271,7 +271,7 @@ def test_runtime_built_pipeline_equals_runtime_built_single_wave_kernel(knh, mon
 
 
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1500, 512), ("C4", 700, 100), ("C5", 520, 128), ("C2", 300, 48),
-                                                      ("D3", 900, 256)])
+                                                      ("D3", 900, 256), ("B3", 700, 128)])
 def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
     """KNH_WIDE=4/8: four or eight 64-voice groups per workgroup (the build used for very large banks)."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
@@ -282,7 +282,7 @@ def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_vo
         g = make_gpu(knh, w)
         res = []
         for block in range(5):
-            if name in ("C3", "C4", "D3"):
+            if name in ("C3", "C4", "D3", "B3"):
                 c3_script(w, block, g)
             if name == "C5":
                 e = configs.c5_events(w, block)

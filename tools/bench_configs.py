@@ -71,6 +71,7 @@ if __name__ == "__main__":
     run("C4", n_voices=8192)
     run("C4")
     run("C5")
+    run("B3")
     run("D3")
     run("D3", n_voices=65536)
     run("D3", n_voices=262144, launches=4)
