@@ -239,123 +239,149 @@ struct PolyBlepOsc {
     if (y > (F)1) return (F)2 - y;
     return y;
   }
-  // One instance per kernel, called: inlined into every sample of an unrolled tile it would be ~400 instructions x 32.
-  template <typename F> static __device__ __attribute__((noinline)) F sample(F t, F dt, F pw_in, u32 wf, u32 fast) {
-    Regs<F> r;
-    r.t = t; r.dt = dt; r.pw = pw_in; r.wf = wf; r.fast = fast;
+  // One waveform, one sample (the reference's method of the same name; line numbers in polyblep.rs).
+  template <typename F, int WF> static __device__ __forceinline__ F wave(F t, F dt, F pw_in) {
     constexpr F TAU = (F)6.28318530717958647692528676655900577, PI = (F)3.14159265358979323846264338327950288;
-    if (fast) wf = 1u;  // next_sample, :210-212
-    switch (wf) {
-      case 1u: return sin_f(t * TAU);
-      case 2u: return cos_f(t * TAU);
-      case 3u: {  // tri, :264-285
-        const F t1 = wrap<F>(t + (F)0.25), t2 = wrap<F>(t + (F)0.75);
-        F y = fold_tri<F>(t * (F)4);
-        return y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+    if constexpr (WF == 1) {
+      return sin_f(t * TAU);
+    } else if constexpr (WF == 2) {
+      return cos_f(t * TAU);
+    } else if constexpr (WF == 3) {  // tri, :264-285
+      const F t1 = wrap<F>(t + (F)0.25), t2 = wrap<F>(t + (F)0.75);
+      F y = fold_tri<F>(t * (F)4);
+      return y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+    } else if constexpr (WF == 4) {  // sqr, :428-441
+      const F t2 = wrap<F>(t + (F)0.5);
+      const F y = t < (F)0.5 ? (F)1 : (F)-1;
+      return y + (blep<F>(t, dt) - blep<F>(t2, dt));
+    } else if constexpr (WF == 5) {  // rect, :471-484
+      const F t2 = wrap<F>(t + (F)1 - pw_in);
+      F y = (F)-2 * pw_in;
+      if (t < pw_in) y = y + (F)2;
+      return y + (blep<F>(t, dt) - blep<F>(t2, dt));
+    } else if constexpr (WF == 6) {  // ramp, :496-504
+      const F u = wrap<F>(t);
+      const F y = (F)1 - (F)2 * u;
+      return y + blep<F>(u, dt);
+    } else if constexpr (WF == 7) {  // tri2, :287-311
+      F pw = pw_in < (F)0.9999 ? pw_in : (F)0.9999;  // f32::min / max: a NaN pulse width turns into the bound
+      if (!(pw_in == pw_in)) pw = (F)0.9999;
+      pw = pw > (F)0.0001 ? pw : (F)0.0001;
+      const F t1 = wrap<F>(t + (F)0.5 * pw), t2 = wrap<F>(t + (F)1 - (F)0.5 * pw);
+      F y = t * (F)2;
+      if (y >= (F)2 - pw) y = (y - (F)2) / pw;
+      else if (y >= pw) y = (F)1 - (y - pw) / ((F)1 - pw);
+      else y = y / pw;
+      return y + dt / (pw - pw * pw) * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+    } else if constexpr (WF == 8) {  // sqr2, :443-469
+      F t1 = wrap<F>(t + (F)0.875 + (F)0.25 * (pw_in - (F)0.5));
+      F t2 = wrap<F>(t + (F)0.375 + (F)0.25 * (pw_in - (F)0.5));
+      F y = t1 < (F)0.5 ? (F)1 : (F)-1;
+      y = y + (blep<F>(t1, dt) - blep<F>(t2, dt));
+      t1 = wrap<F>(t1 + (F)0.5 * ((F)1 - pw_in));
+      t2 = wrap<F>(t2 + (F)0.5 * ((F)1 - pw_in));
+      y = y + (t1 < (F)0.5 ? (F)1 : (F)-1);
+      y = y + (blep<F>(t1, dt) - blep<F>(t2, dt));
+      return (F)0.5 * y;
+    } else if constexpr (WF == 9) {  // half, :231-247
+      const F t2 = wrap<F>(t + (F)0.5);
+      F y = t < (F)0.5 ? (F)2 * sin_f(t * TAU) - (F)2 / PI : (F)-2 / PI;
+      return y + TAU * dt * (blamp<F>(t, dt) + blamp<F>(t2, dt));
+    } else if constexpr (WF == 10) {  // full, :249-257
+      const F u = wrap<F>(t + (F)0.25);
+      const F y = (F)2 * sin_f(u * PI) - (F)4 / PI;
+      return y + TAU * dt * blamp<F>(u, dt);
+    } else if constexpr (WF == 11) {  // trip, :313-351
+      const F pw = pw_in;
+      const F t1 = wrap<F>(t + (F)0.75 + (F)0.5 * pw);
+      F y;
+      if (t1 >= pw) {
+        y = -pw;
+      } else {
+        y = (F)4 * t1;
+        y = y >= (F)2 * pw ? (F)4 - y / pw - pw : y / pw - pw;
       }
-      case 4u: {  // sqr, :428-441
-        const F t2 = wrap<F>(t + (F)0.5);
-        const F y = t < (F)0.5 ? (F)1 : (F)-1;
-        return y + (blep<F>(t, dt) - blep<F>(t2, dt));
+      if (pw > (F)0) {
+        const F t2 = wrap<F>(t1 + (F)1 - (F)0.5 * pw), t3 = wrap<F>(t1 + (F)1 - pw);
+        y = y + (F)2 * dt / pw * (blamp<F>(t1, dt) - (F)2 * blamp<F>(t2, dt) + blamp<F>(t3, dt));
       }
-      case 5u: {  // rect, :471-484
-        const F t2 = wrap<F>(t + (F)1 - r.pw);
-        F y = (F)-2 * r.pw;
-        if (t < r.pw) y = y + (F)2;
-        return y + (blep<F>(t, dt) - blep<F>(t2, dt));
-      }
-      case 6u: {  // ramp, :496-504
-        const F u = wrap<F>(t);
-        const F y = (F)1 - (F)2 * u;
-        return y + blep<F>(u, dt);
-      }
-      case 7u: {  // tri2, :287-311
-        F pw = r.pw < (F)0.9999 ? r.pw : (F)0.9999;  // f32::min / max: a NaN pulse width turns into the bound
-        if (!(r.pw == r.pw)) pw = (F)0.9999;
-        pw = pw > (F)0.0001 ? pw : (F)0.0001;
-        const F t1 = wrap<F>(t + (F)0.5 * pw), t2 = wrap<F>(t + (F)1 - (F)0.5 * pw);
-        F y = t * (F)2;
-        if (y >= (F)2 - pw) y = (y - (F)2) / pw;
-        else if (y >= pw) y = (F)1 - (y - pw) / ((F)1 - pw);
-        else y = y / pw;
-        return y + dt / (pw - pw * pw) * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
-      }
-      case 8u: {  // sqr2, :443-469
-        F t1 = wrap<F>(t + (F)0.875 + (F)0.25 * (r.pw - (F)0.5));
-        F t2 = wrap<F>(t + (F)0.375 + (F)0.25 * (r.pw - (F)0.5));
-        F y = t1 < (F)0.5 ? (F)1 : (F)-1;
-        y = y + (blep<F>(t1, dt) - blep<F>(t2, dt));
-        t1 = wrap<F>(t1 + (F)0.5 * ((F)1 - r.pw));
-        t2 = wrap<F>(t2 + (F)0.5 * ((F)1 - r.pw));
-        y = y + (t1 < (F)0.5 ? (F)1 : (F)-1);
-        y = y + (blep<F>(t1, dt) - blep<F>(t2, dt));
-        return (F)0.5 * y;
-      }
-      case 9u: {  // half, :231-247
-        const F t2 = wrap<F>(t + (F)0.5);
-        F y = t < (F)0.5 ? (F)2 * sin_f(t * TAU) - (F)2 / PI : (F)-2 / PI;
-        return y + TAU * dt * (blamp<F>(t, dt) + blamp<F>(t2, dt));
-      }
-      case 10u: {  // full, :249-257
-        const F u = wrap<F>(t + (F)0.25);
-        const F y = (F)2 * sin_f(u * PI) - (F)4 / PI;
-        return y + TAU * dt * blamp<F>(u, dt);
-      }
-      case 11u: {  // trip, :313-351
-        const F pw = r.pw;
-        const F t1 = wrap<F>(t + (F)0.75 + (F)0.5 * pw);
-        F y;
-        if (t1 >= pw) {
-          y = -pw;
-        } else {
-          y = (F)4 * t1;
-          y = y >= (F)2 * pw ? (F)4 - y / pw - pw : y / pw - pw;
-        }
-        if (pw > (F)0) {
-          const F t2 = wrap<F>(t1 + (F)1 - (F)0.5 * pw), t3 = wrap<F>(t1 + (F)1 - pw);
-          y = y + (F)2 * dt / pw * (blamp<F>(t1, dt) - (F)2 * blamp<F>(t2, dt) + blamp<F>(t3, dt));
-        }
-        return y;
-      }
-      case 12u: {  // trap, :353-386
-        F y = fold_tri<F>((F)4 * t);
-        y = clamp1<F>((F)2 * y);
-        F t1 = wrap<F>(t + (F)0.125), t2 = wrap<F>(t1 + (F)0.5);
-        y = y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
-        t1 = wrap<F>(t + (F)0.375);
-        t2 = wrap<F>(t1 + (F)0.5);
-        return y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
-      }
-      case 13u: {  // trap2, :388-426
-        F pw = r.pw < (F)0.9999 ? r.pw : (F)0.9999;
-        if (!(r.pw == r.pw)) pw = (F)0.9999;
-        const F scale = (F)1 / ((F)1 - pw);
-        F y = fold_tri<F>((F)4 * t);
-        y = clamp1<F>(scale * y);
-        F t1 = wrap<F>(t + (F)0.25 - (F)0.25 * pw), t2 = wrap<F>(t1 + (F)0.5);
-        y = y + scale * (F)2 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
-        t1 = wrap<F>(t + (F)0.25 + (F)0.25 * pw);
-        t2 = wrap<F>(t1 + (F)0.5);
-        return y + scale * (F)2 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
-      }
-      default: {  // saw (0, and every out-of-range value), :486-494
-        const F u = wrap<F>(t + (F)0.5);
-        const F y = (F)2 * u - (F)1;
-        return y - blep<F>(u, dt);
-      }
+      return y;
+    } else if constexpr (WF == 12) {  // trap, :353-386
+      F y = fold_tri<F>((F)4 * t);
+      y = clamp1<F>((F)2 * y);
+      F t1 = wrap<F>(t + (F)0.125), t2 = wrap<F>(t1 + (F)0.5);
+      y = y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+      t1 = wrap<F>(t + (F)0.375);
+      t2 = wrap<F>(t1 + (F)0.5);
+      return y + (F)4 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+    } else if constexpr (WF == 13) {  // trap2, :388-426
+      F pw = pw_in < (F)0.9999 ? pw_in : (F)0.9999;
+      if (!(pw_in == pw_in)) pw = (F)0.9999;
+      const F scale = (F)1 / ((F)1 - pw);
+      F y = fold_tri<F>((F)4 * t);
+      y = clamp1<F>(scale * y);
+      F t1 = wrap<F>(t + (F)0.25 - (F)0.25 * pw), t2 = wrap<F>(t1 + (F)0.5);
+      y = y + scale * (F)2 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+      t1 = wrap<F>(t + (F)0.25 + (F)0.25 * pw);
+      t2 = wrap<F>(t1 + (F)0.5);
+      return y + scale * (F)2 * dt * (blamp<F>(t1, dt) - blamp<F>(t2, dt));
+    } else {  // saw (0, and every out-of-range value), :486-494
+      const F u = wrap<F>(t + (F)0.5);
+      const F y = (F)2 * u - (F)1;
+      return y - blep<F>(u, dt);
     }
+  }
+  // N consecutive samples of one waveform: get_and_inc, :224-228, N times
+  template <typename F, int N> struct Run { F y[N]; F t; };
+  template <typename F, int N, int WF> static __device__ __forceinline__ void run(Run<F, N>& q, F t, F dt, F pw) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      q.y[k] = wave<F, WF>(t, dt, pw);
+      t = t + dt;  // inc, :219-222
+      t = t - trunc_f(t);
+    }
+    q.t = t;
+  }
+  // One instance of each N per kernel, called, with the waveform dispatched once per call: inlined into every sample
+  // of an unrolled tile the fourteen waveforms would be ~400 instructions x 32, and called once per sample the entry
+  // (a full s_waitcnt, the dispatch tree, two far jumps) costs more than most waveforms.
+  template <typename F, int N> static __device__ __attribute__((noinline)) Run<F, N> samples(F t, F dt, F pw, u32 wf, u32 fast) {
+    Run<F, N> q;
+    if (fast) wf = 1u;  // next_sample, :210-212: a sine at or above sample_rate / 4
+    switch (wf) {
+      case 1u: run<F, N, 1>(q, t, dt, pw); break;
+      case 2u: run<F, N, 2>(q, t, dt, pw); break;
+      case 3u: run<F, N, 3>(q, t, dt, pw); break;
+      case 4u: run<F, N, 4>(q, t, dt, pw); break;
+      case 5u: run<F, N, 5>(q, t, dt, pw); break;
+      case 6u: run<F, N, 6>(q, t, dt, pw); break;
+      case 7u: run<F, N, 7>(q, t, dt, pw); break;
+      case 8u: run<F, N, 8>(q, t, dt, pw); break;
+      case 9u: run<F, N, 9>(q, t, dt, pw); break;
+      case 10u: run<F, N, 10>(q, t, dt, pw); break;
+      case 11u: run<F, N, 11>(q, t, dt, pw); break;
+      case 12u: run<F, N, 12>(q, t, dt, pw); break;
+      case 13u: run<F, N, 13>(q, t, dt, pw); break;
+      default: run<F, N, 0>(q, t, dt, pw); break;
+    }
+    return q;
   }
   template <typename F, bool FMA>
   static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
-    const F y = sample<F>(r.t, r.dt, r.pw, r.wf, r.fast);
-    r.t = r.t + r.dt;  // inc, :219-222
-    r.t = r.t - trunc_f(r.t);
-    return y;
+    const Run<F, 1> q = samples<F, 1>(r.t, r.dt, r.pw, r.wf, r.fast);
+    r.t = q.t;
+    return q.y[0];
   }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    static_assert(T % 8 == 0, "tiles are multiples of eight samples");
 #pragma unroll
-    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+    for (int j = 0; j < T; j += 8) {
+      const Run<F, 8> q = samples<F, 8>(r.t, r.dt, r.pw, r.wf, r.fast);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[j + k] = q.y[k];
+      r.t = q.t;
+    }
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
