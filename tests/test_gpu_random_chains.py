@@ -65,8 +65,12 @@ def random_chain(seed):
     bs = int(rng.choice([32, 64, 100, 128]))
     st = L.F64 if seed % 4 == 3 else L.F32
     p = configs.voice_parameters(n)
-    src = L.STAGE_PHASOR if seed % 5 == 4 else L.STAGE_SIN_WT  # both constructors take a frequency
-    stages, ctor, changes, triggers = [Stage(src)], {0: ctor_for(L.STAGE_SIN_WT, n, rng, p)}, [], []
+    src = L.STAGE_PHASOR if seed % 5 == 4 else (L.STAGE_POLYBLEP if seed % 5 == 3 else L.STAGE_SIN_WT)
+    src_args = ctor_for(L.STAGE_SIN_WT, n, rng, p)  # a frequency per voice
+    if src == L.STAGE_POLYBLEP:  # waveforms without sin: those are bit-exact
+        wf = rng.choice([0, 3, 4, 5, 6, 7, 8, 11, 12, 13], n).astype(np.float64)
+        src_args = np.stack([wf, src_args[:, 0]], axis=1)
+    stages, ctor, changes, triggers = [Stage(src)], {0: src_args}, [], []
     have_delay = have_segenv = False
     for _ in range(int(rng.integers(2, 6))):
         if rng.random() < 0.3:
