@@ -63,6 +63,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* PHASOR      */ {4, 1, 1, 1, 'P', {"freq"}},
     /* SAFETY_LIM  */ {0, 0, 0, 1, 'X', {nullptr}},
     /* POLYBLEP    */ {5, 3, 2, 1, 'B', {"freq", "pulse_width", "waveform"}},
+    /* ALLPASS_DLY */ {7, 1, 1, 1, 'Y', {"delay_time"}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -74,7 +75,7 @@ inline int stage_cost(char c) {
   switch (c) {
     case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
     case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
-    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45; case 'Y': return 14;
     default: return 1;
   }
 }
@@ -505,6 +506,24 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 3, v) = static_cast<W>(wf);
             slot(S.slot_base + 4, v) = (dt * srf >= srf / F(4)) ? 1u : 0u;  // get_freq_in_hz() >= sample_rate / 4, :210
           } break;
+          case KNH_STAGE_ALLPASS_DELAY: {  // delay.rs:107-123: buffer = max_delay_seconds.to_samples(sample_rate) zeros
+            if (v == 0) delay_len.assign(nv, 0u);
+            const double secs_in = a[0];
+            if (!(secs_in >= 0.0) || secs_in >= 4294967296.0) return fail(KNH_ERR_INVALID_ARGUMENT, "AllpassDelay: max delay out of range");
+            const uint64_t whole = static_cast<uint64_t>(std::floor(secs_in));
+            const uint64_t tes = sat_u32((secs_in - std::floor(secs_in)) * 282240000.0);
+            const uint64_t nsamp = whole * sr + tes * static_cast<uint64_t>(sr) / 282240000ull;  // Seconds::to_samples, time.rs:86-90
+            if (nsamp == 0) return fail(KNH_ERR_INVALID_ARGUMENT, "AllpassDelay: the ring would be empty (the reference takes a remainder by zero)");
+            if (nsamp >= (1ull << 30)) return fail(KNH_ERR_INVALID_ARGUMENT, "AllpassDelay: max delay too long");
+            delay_len[v] = static_cast<uint32_t>(nsamp);
+            slot(S.slot_base + 0, v) = 0;  // write_frame
+            slot(S.slot_base + 1, v) = 0;  // read_frame
+            slot(S.slot_base + 2, v) = static_cast<W>(nsamp);
+            slot(S.slot_base + 3, v) = v;
+            slot(S.slot_base + 4, v) = fw(F(1));  // AllpassInterpolator::new: coeff, prev_input, prev_output all ONE (:61-67)
+            slot(S.slot_base + 5, v) = fw(F(1));
+            slot(S.slot_base + 6, v) = fw(F(1));
+          } break;
           case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:24-31 (new), :45-49 (init)
             if (v == 0) delay_len.assign(nv, 0u);
             // Seconds::from_secs_f64 / to_secs_f64 (knaster_primitives/src/time.rs:59-74), then `as usize`
@@ -782,6 +801,21 @@ struct Bank final : knh_bank {
         const uint64_t sb = to_bits(f * (1.0 / static_cast<double>(sample_rate)));
         set(2, static_cast<uint32_t>(sb));
         set(3, static_cast<uint32_t>(sb >> 32));
+      } break;
+      case KNH_STAGE_ALLPASS_DELAY: {  // delay_time, :136-143 -> set_delay_in_frames, :160-174
+        const double delay_frames = f * static_cast<double>(sample_rate);
+        const uint32_t len = delay_len[v];
+        if (!(delay_frames < static_cast<double>(len))) break;  // `(delay_frames as usize) < buffer.len()` fails: ignored
+        F num = static_cast<F>(delay_frames);  // F::new; a negative or NaN value casts to 0 frames above, and goes on as it is
+        const F fl = std::floor(num);
+        uint32_t whole = fl > F(0) ? static_cast<uint32_t>(fl) : 0u;  // to_usize().unwrap() on a negative value panics in the reference
+        F delta = num - fl;
+        if (num > F(0.5) && delta < F(0.5)) {
+          delta += F(1);
+          whole -= 1u;
+        }
+        out.push_back(HostEvent{v, frame, knh_dev::EV_ALLPASS_DELAY, static_cast<uint32_t>(S.slot_base), whole});
+        set(4, to_bits((F(1) - delta) / (F(1) + delta)));  // AllpassInterpolator::set_delta, :74-76
       } break;
       case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:33-36: delay_samples = (seconds * sample_rate) as usize
         const double ds = f * static_cast<double>(sample_rate);
@@ -1184,7 +1218,11 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
     if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }
-    if (st[i].kind == KNH_STAGE_SAMPLE_DELAY && sig->find('D') != std::string::npos) { *why = "at most one SampleDelay stage per chain"; return KNH_ERR_INVALID_ARGUMENT; }
+    if ((st[i].kind == KNH_STAGE_SAMPLE_DELAY || st[i].kind == KNH_STAGE_ALLPASS_DELAY) &&
+        (sig->find('D') != std::string::npos || sig->find('Y') != std::string::npos)) {
+      *why = "at most one delay stage per chain";
+      return KNH_ERR_INVALID_ARGUMENT;
+    }
     if (st[i].kind == KNH_STAGE_MUL_ENVELOPE && sig->find('V') != std::string::npos) { *why = "at most one Envelope stage per chain"; return KNH_ERR_INVALID_ARGUMENT; }
     sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
     have_x = true;
@@ -1218,7 +1256,7 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
       if (!b->pipe && groups <= 256) ww = 0;
       // a delay line wants the pipeline's 32-sample tiles (whole 128-byte lines per visit, reads one tile ahead):
       // measured 1.37e12 against 0.88e12 UGen-samples/s at 262 144 voices
-      if (b->pipe && sig.find('D') != std::string::npos) ww = 0;
+      if (b->pipe && (sig.find('D') != std::string::npos || sig.find('Y') != std::string::npos)) ww = 0;
       const char* wenv = std::getenv("KNH_WIDE");
       if (wenv) ww = std::atoi(wenv);
       if (ww == 4 || ww == 8) b->wide_waves = ww;
@@ -1440,7 +1478,8 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
       case KNH_STAGE_SAMPLE_DELAY: w += word; break;
       case KNH_STAGE_PHASOR: w += word * 2; break;
-      case KNH_STAGE_POLYBLEP: w += word; break;  // + one sample read and one written per frame (ring in HBM)
+      case KNH_STAGE_POLYBLEP: w += word; break;
+      case KNH_STAGE_ALLPASS_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)
       default: break;
     }
   }

@@ -55,7 +55,7 @@ __device__ __forceinline__ u32 sat_u32(double v) {
 }
 
 // Event opcodes (host -> device state patches, applied at an in-block frame).
-enum { EV_SET = 0, EV_ENV_ASR_RELEASE = 1, EV_NOP = 2, EV_SEGENV_STOP = 3, EV_SPLIT = 0x80 /* flag: change came out of a WrPreciseTiming queue */ };
+enum { EV_SET = 0, EV_ENV_ASR_RELEASE = 1, EV_NOP = 2, EV_SEGENV_STOP = 3, EV_ALLPASS_DELAY = 4, EV_SPLIT = 0x80 /* flag: change came out of a WrPreciseTiming queue */ };
 
 struct Event {   // 16 bytes
   u32 frame;     // absolute frame within the launch: block_index * block_size + frame_in_block
@@ -1002,6 +1002,100 @@ struct SampleDelay {
     if ((op & 0x7Fu) != EV_SET) return;
     if (rel == 1) r.off = (u32)bits;
     else if (rel == 0) r.wp = (u32)bits;
+  }
+};
+
+// AllpassDelay -- delay.rs:93-206: out = allpass(buffer[read]); read += 1; buffer[write] = x; write += 1 (both modulo the
+// ring), with a first-order allpass interpolator (delay.rs:53-90: out = coeff * (in - prev_out) + prev_in) for the
+// fractional part of the delay.  Ring layout as SampleDelay.  slots: 0 write_frame  1 read_frame  2 ring length
+// 3 ring row  4 coeff  5 prev_input  6 prev_output.  delay_time arrives as a coeff patch plus EV_ALLPASS_DELAY carrying
+// the whole number of frames: read_frame is derived from the live write_frame (set_delay_in_frames, :160-174).
+struct AllpassDelay {
+  static constexpr int kSlots = 7;
+  static constexpr u32 kMutableMask = 0b1100011u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = true;
+  template <typename F> struct Regs { u32 wp, rp, len, row; F coeff, pin, pout; F* ring; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.wp = (u32)s[0]; r.rp = (u32)s[st]; r.len = (u32)s[2 * st]; r.row = (u32)s[3 * st];
+    r.coeff = word_to_f<F>(s[4 * st]); r.pin = word_to_f<F>(s[5 * st]); r.pout = word_to_f<F>(s[6 * st]);
+    r.ring = nullptr;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void bind(Regs<F>& r, const Ctx& c) {
+    if (r.ring == nullptr) r.ring = reinterpret_cast<F*>(c.delay_ring) + (long)r.row * c.delay_stride;
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    s[0] = (W)r.wp; s[st] = (W)r.rp; s[5 * st] = f_to_word(r.pin); s[6 * st] = f_to_word(r.pout);
+  }
+  template <typename F> static __device__ __forceinline__ F allpass(Regs<F>& r, F in) {  // :78-83
+    const F out = r.coeff * (in - r.pout) + r.pin;
+    r.pout = out;
+    r.pin = in;
+    return out;
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx& c, u32, u32&) {
+    bind<F>(r, c);
+    if (r.len == 0u) return x;  // a lane past the last voice
+    const F y = allpass<F>(r, r.ring[r.rp]);
+    r.rp = r.rp + 1u == r.len ? 0u : r.rp + 1u;
+    r.ring[r.wp] = x;
+    r.wp = r.wp + 1u == r.len ? 0u : r.wp + 1u;
+    return y;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    bind<F>(r, c);
+    constexpr int VW = 16 / (int)sizeof(F);
+    typedef F Vec __attribute__((ext_vector_type(VW), aligned(sizeof(F))));
+    const bool dead = r.len == 0u;
+    // a read meets a store of the same tile only when the write pointer is 1 .. T-1 frames ahead of the read pointer
+    const u32 ahead = r.wp >= r.rp ? r.wp - r.rp : r.wp + r.len - r.rp;
+    const bool vec_ok = dead || (r.len >= (u32)T && (ahead == 0u || ahead >= (u32)T) && r.wp <= r.len - (u32)T && r.rp <= r.len - (u32)T);
+    if (__builtin_amdgcn_ballot_w64(!vec_ok) == 0) {
+      if (!dead) {
+        F y[T];
+        const Vec* src = reinterpret_cast<const Vec*>(r.ring + r.rp);
+#pragma unroll
+        for (int j = 0; j < T / VW; ++j) {
+          const Vec v = src[j];
+#pragma unroll
+          for (int k = 0; k < VW; ++k) y[j * VW + k] = v[k];
+        }
+        Vec* dst = reinterpret_cast<Vec*>(r.ring + r.wp);
+#pragma unroll
+        for (int j = 0; j < T / VW; ++j) {
+          Vec v;
+#pragma unroll
+          for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
+          dst[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) x[j] = allpass<F>(r, y[j]);
+        r.rp = r.rp + (u32)T == r.len ? 0u : r.rp + (u32)T;
+        r.wp = r.wp + (u32)T == r.len ? 0u : r.wp + (u32)T;
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    op &= 0x7Fu;
+    if (op == EV_ALLPASS_DELAY) {  // set_delay_in_frames, :168-172
+      const u32 nf = (u32)bits;
+      r.rp = r.wp >= nf ? r.wp - nf : r.len - nf + r.wp;
+      return;
+    }
+    if (op != EV_SET) return;
+    if (rel == 4) r.coeff = word_to_f<F>((typename WordOf<F>::type)bits);
+    else if (rel == 0) r.wp = (u32)bits;
+    else if (rel == 1) r.rp = (u32)bits;
   }
 };
 

@@ -1128,6 +1128,70 @@ struct SafetyLimiter : UGen<F> {
 };
 
 // ---------------------------------------------------------------------------
+// AllpassInterpolator / AllpassDelay -- knaster_core_dsp/src/ugens/delay.rs:53-206
+// ---------------------------------------------------------------------------
+template <typename F>
+struct AllpassInterpolator {
+  F coeff = F(1), prev_input = F(1), prev_output = F(1);  // new(): all ONE
+  void clear() { prev_input = F(1); prev_output = F(1); }
+  void set_delta(F delta) { coeff = (F(1) - delta) / (F(1) + delta); }
+  F process_sample(F input) {
+    const F output = coeff * (input - prev_output) + prev_input;
+    prev_output = output;
+    prev_input = input;
+    return output;
+  }
+};
+template <typename F>
+struct AllpassDelay : UGen<F> {
+  std::vector<F> buffer;
+  size_t write_frame = 0, read_frame = 0, num_frames = 1, clear_nr_of_samples_left = 0;
+  AllpassInterpolator<F> allpass;
+  Seconds max_delay_seconds;
+  explicit AllpassDelay(Seconds max_delay) : max_delay_seconds(max_delay) {}
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"delay_time"}; }
+  void init(uint32_t sample_rate, size_t) override { buffer.assign(static_cast<size_t>(max_delay_seconds.to_samples(sample_rate)), F(0)); }
+  F read() {  // :145-157
+    if (clear_nr_of_samples_left > 0) {
+      clear_nr_of_samples_left -= 1;
+      read_frame = (read_frame + 1) % buffer.size();
+      return F(0);
+    }
+    const F v = allpass.process_sample(buffer[read_frame]);
+    read_frame = (read_frame + 1) % buffer.size();
+    return v;
+  }
+  void write_and_advance(F input) {  // :202-205
+    buffer[write_frame] = input;
+    write_frame = (write_frame + 1) % buffer.size();
+  }
+  void set_delay_in_frames(F nf) {  // :160-174
+    const F nf_floor = std::floor(nf);
+    num_frames = static_cast<size_t>(nf_floor);
+    F delta = nf - nf_floor;
+    if (nf > F(0.5) && delta < F(0.5)) {
+      delta += F(1);
+      num_frames -= 1;
+    }
+    read_frame = write_frame >= num_frames ? write_frame - num_frames : buffer.size() - num_frames + write_frame;
+    allpass.set_delta(delta);
+  }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override {  // :125-134
+    out[0] = read();
+    write_and_advance(in[0]);
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {  // :136-143
+    if (index != 0) { ctx.rt_log("Unknown parameter set for AllpassDelay"); return; }
+    const double delay_frames = v.float_or_panic() * static_cast<double>(ctx.sample_rate());
+    const size_t as_usize = delay_frames > 0.0 ? (delay_frames >= 18446744073709551615.0 ? SIZE_MAX : static_cast<size_t>(delay_frames)) : 0;
+    if (as_usize < buffer.size()) set_delay_in_frames(fnew<F>(delay_frames));
+  }
+};
+
+// ---------------------------------------------------------------------------
 // SampleDelay -- knaster_core_dsp/src/ugens/delay.rs:14-50
 // ---------------------------------------------------------------------------
 template <typename F>

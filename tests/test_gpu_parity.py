@@ -517,3 +517,34 @@ def test_polyblep_all_waveforms(knh, oracle, sample_type):
         assert np.abs(ov).max() > 0.1 / n
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_allpass_delay(knh, oracle, sample_type):
+    """AllpassDelay (delay.rs:93-206): fractional delays through the allpass interpolator, the untouched start (read and
+    write pointers together: a whole ring of delay), delays shorter than a tile, pointer wrap-around, changes at block
+    starts and mid-block, a delay_time of the ring length or more ignored."""
+    n, bs = 96, 64
+    p = configs.voice_parameters(n)
+    v = np.arange(n, dtype=np.uint32)
+    w = configs.Workload("allpass", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_ALLPASS_DELAY, delayed_changes_per_block=2),
+                                     Stage(L.STAGE_MUL_CONST)], n, bs, sample_type, 2)
+    max_delay = 0.003 + 0.0001 * (v % 30)
+    ring = np.array([int(s * 282240000.0) * 48000 // 282240000 for s in max_delay])  # Seconds::to_samples for s < 1
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.5), 2: max_delay.reshape(n, 1), 3: np.full((n, 1), 1.0 / n)}
+    frames = [0.7, 1.2, 5.49, 15.5, 31.9, 32.0, 33.25, 64.75, -1.0, -2.0]  # negative: relative to the ring (-1: just inside, -2: half)
+
+    def delay_seconds(shift):
+        k = np.array([frames[(i + shift) % len(frames)] for i in range(n)])
+        d = np.where(k >= 0, k, np.where(k == -1.0, ring - 1.25, ring * 0.5 + 0.3))
+        return d / 48000.0
+
+    def ev(block, bank):
+        if block == 2:
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, delay_seconds(0))
+        if block == 6:
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, delay_seconds(4), delays=(v % bs).astype(np.uint16))
+        if block == 9:  # too long for the ring on every other voice: ignored there
+            want = np.where(v % 2 == 0, (ring + 3.0) / 48000.0, delay_seconds(7))
+            bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, want)
+    run_pair(knh, oracle, w, 14, ev, L.MIX_LEFT_FOLD)
