@@ -80,7 +80,8 @@ pub const KNH_STAGE_PHASOR: u16 = 22;
 pub const KNH_STAGE_SAFETY_LIMITER: u16 = 23;
 pub const KNH_STAGE_POLYBLEP: u16 = 24;
 pub const KNH_STAGE_ALLPASS_DELAY: u16 = 25;
-pub const KNH_STAGE_KIND_COUNT: u16 = 26;
+pub const KNH_STAGE_ALLPASS_FB_DELAY: u16 = 26;
+pub const KNH_STAGE_KIND_COUNT: u16 = 27;
 
 // knh_svf_type = SvfFilterType, knaster_core_dsp/src/ugens/svf.rs:19-39
 pub const KNH_SVF_LOW: u32 = 0;

@@ -111,6 +111,9 @@ typedef enum knh_value_kind {
  *     params: 0 delay_time (seconds).  The ring holds Seconds::to_samples(sample_rate) samples per voice (HBM); the
  *     fractional part of the delay goes through the reference's first-order allpass interpolator.  A delay_time of
  *     the ring length or more is ignored, as in the reference.  At most one delay stage (of either kind) per chain.
+ * KNH_STAGE_ALLPASS_FB_DELAY  x >> g.push(AllpassFeedbackDelay::new(Seconds::from_secs_f64(max_delay)))  delay.rs:210-306  1  max_delay (s)
+ *     the Schroeder allpass around an AllpassDelay.  params: 0 delay_time (seconds; longer than the ring: ignored -- the
+ *     reference does not check and would index out of bounds), 1 feedback
  * KNH_STAGE_PHASOR          g.push(Phasor::new(freq))           osc.rs:172-214       1    freq
  *     a source like SinWt: a 0..1 ramp, f64 phase and step whatever F is.  params: 0 freq
  * KNH_STAGE_POLYBLEP        g.push(PolyBlep::new(waveform, freq))   polyblep.rs:123-508   1    waveform (0..13), freq
@@ -152,7 +155,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_SAFETY_LIMITER = 23,
   KNH_STAGE_POLYBLEP = 24,
   KNH_STAGE_ALLPASS_DELAY = 25,
-  KNH_STAGE_KIND_COUNT = 26
+  KNH_STAGE_ALLPASS_FB_DELAY = 26,
+  KNH_STAGE_KIND_COUNT = 27
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

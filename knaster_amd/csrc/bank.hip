@@ -64,6 +64,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* SAFETY_LIM  */ {0, 0, 0, 1, 'X', {nullptr}},
     /* POLYBLEP    */ {5, 3, 2, 1, 'B', {"freq", "pulse_width", "waveform"}},
     /* ALLPASS_DLY */ {7, 1, 1, 1, 'Y', {"delay_time"}},
+    /* ALLPASS_FB  */ {8, 2, 1, 1, 'Z', {"delay_time", "feedback"}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -75,7 +76,7 @@ inline int stage_cost(char c) {
   switch (c) {
     case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
     case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
-    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45; case 'Y': return 14;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45; case 'Y': return 14; case 'Z': return 18;
     default: return 1;
   }
 }
@@ -506,6 +507,7 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 3, v) = static_cast<W>(wf);
             slot(S.slot_base + 4, v) = (dt * srf >= srf / F(4)) ? 1u : 0u;  // get_freq_in_hz() >= sample_rate / 4, :210
           } break;
+          case KNH_STAGE_ALLPASS_FB_DELAY:  // delay.rs:221-229: an AllpassDelay and feedback = 0
           case KNH_STAGE_ALLPASS_DELAY: {  // delay.rs:107-123: buffer = max_delay_seconds.to_samples(sample_rate) zeros
             if (v == 0) delay_len.assign(nv, 0u);
             const double secs_in = a[0];
@@ -523,6 +525,7 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 4, v) = fw(F(1));  // AllpassInterpolator::new: coeff, prev_input, prev_output all ONE (:61-67)
             slot(S.slot_base + 5, v) = fw(F(1));
             slot(S.slot_base + 6, v) = fw(F(1));
+            if (S.kind == KNH_STAGE_ALLPASS_FB_DELAY) slot(S.slot_base + 7, v) = fw(F(0));
           } break;
           case KNH_STAGE_SAMPLE_DELAY: {  // delay.rs:24-31 (new), :45-49 (init)
             if (v == 0) delay_len.assign(nv, 0u);
@@ -802,10 +805,19 @@ struct Bank final : knh_bank {
         set(2, static_cast<uint32_t>(sb));
         set(3, static_cast<uint32_t>(sb >> 32));
       } break;
+      case KNH_STAGE_ALLPASS_FB_DELAY:
+        if (param == 1) {  // feedback, :237-240
+          set(7, to_bits(static_cast<F>(f)));
+          break;
+        }
+        [[fallthrough]];  // delay_time, :231-236: set_delay_in_frames without the length check of AllpassDelay's
       case KNH_STAGE_ALLPASS_DELAY: {  // delay_time, :136-143 -> set_delay_in_frames, :160-174
         const double delay_frames = f * static_cast<double>(sample_rate);
         const uint32_t len = delay_len[v];
-        if (!(delay_frames < static_cast<double>(len))) break;  // `(delay_frames as usize) < buffer.len()` fails: ignored
+        if (!(delay_frames < static_cast<double>(len))) {  // `(delay_frames as usize) < buffer.len()` fails: ignored
+          if (S.kind == KNH_STAGE_ALLPASS_FB_DELAY) warn("AllpassFeedbackDelay: delay_time longer than the ring, change ignored");
+          break;
+        }
         F num = static_cast<F>(delay_frames);  // F::new; a negative or NaN value casts to 0 frames above, and goes on as it is
         const F fl = std::floor(num);
         uint32_t whole = fl > F(0) ? static_cast<uint32_t>(fl) : 0u;  // to_usize().unwrap() on a negative value panics in the reference
@@ -1218,8 +1230,8 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
     if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }
-    if ((st[i].kind == KNH_STAGE_SAMPLE_DELAY || st[i].kind == KNH_STAGE_ALLPASS_DELAY) &&
-        (sig->find('D') != std::string::npos || sig->find('Y') != std::string::npos)) {
+    if ((st[i].kind == KNH_STAGE_SAMPLE_DELAY || st[i].kind == KNH_STAGE_ALLPASS_DELAY || st[i].kind == KNH_STAGE_ALLPASS_FB_DELAY) &&
+        sig->find_first_of("DYZ") != std::string::npos) {
       *why = "at most one delay stage per chain";
       return KNH_ERR_INVALID_ARGUMENT;
     }
@@ -1256,7 +1268,7 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
       if (!b->pipe && groups <= 256) ww = 0;
       // a delay line wants the pipeline's 32-sample tiles (whole 128-byte lines per visit, reads one tile ahead):
       // measured 1.37e12 against 0.88e12 UGen-samples/s at 262 144 voices
-      if (b->pipe && (sig.find('D') != std::string::npos || sig.find('Y') != std::string::npos)) ww = 0;
+      if (b->pipe && sig.find_first_of("DYZ") != std::string::npos) ww = 0;
       const char* wenv = std::getenv("KNH_WIDE");
       if (wenv) ww = std::atoi(wenv);
       if (ww == 4 || ww == 8) b->wide_waves = ww;
@@ -1479,7 +1491,7 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_SAMPLE_DELAY: w += word; break;
       case KNH_STAGE_PHASOR: w += word * 2; break;
       case KNH_STAGE_POLYBLEP: w += word; break;
-      case KNH_STAGE_ALLPASS_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)
+      case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)
       default: break;
     }
   }

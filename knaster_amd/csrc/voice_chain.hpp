@@ -1008,19 +1008,24 @@ struct SampleDelay {
 // AllpassDelay -- delay.rs:93-206: out = allpass(buffer[read]); read += 1; buffer[write] = x; write += 1 (both modulo the
 // ring), with a first-order allpass interpolator (delay.rs:53-90: out = coeff * (in - prev_out) + prev_in) for the
 // fractional part of the delay.  Ring layout as SampleDelay.  slots: 0 write_frame  1 read_frame  2 ring length
-// 3 ring row  4 coeff  5 prev_input  6 prev_output.  delay_time arrives as a coeff patch plus EV_ALLPASS_DELAY carrying
-// the whole number of frames: read_frame is derived from the live write_frame (set_delay_in_frames, :160-174).
-struct AllpassDelay {
-  static constexpr int kSlots = 7;
+// 3 ring row  4 coeff  5 prev_input  6 prev_output  (7 feedback).  delay_time arrives as a coeff patch plus
+// EV_ALLPASS_DELAY carrying the whole number of frames: read_frame is derived from the live write_frame
+// (set_delay_in_frames, :160-174).
+// FB = true: AllpassFeedbackDelay, the Schroeder allpass around it (delay.rs:210-306): d = read(); w = d * feedback + x;
+// write(w); out = d - feedback * w.
+template <bool FB>
+struct AllpassDelayT {
+  static constexpr int kSlots = FB ? 8 : 7;
   static constexpr u32 kMutableMask = 0b1100011u;
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = true;
-  template <typename F> struct Regs { u32 wp, rp, len, row; F coeff, pin, pout; F* ring; };
+  template <typename F> struct Regs { u32 wp, rp, len, row; F coeff, pin, pout, fb; F* ring; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
     r.wp = (u32)s[0]; r.rp = (u32)s[st]; r.len = (u32)s[2 * st]; r.row = (u32)s[3 * st];
     r.coeff = word_to_f<F>(s[4 * st]); r.pin = word_to_f<F>(s[5 * st]); r.pout = word_to_f<F>(s[6 * st]);
+    r.fb = FB ? word_to_f<F>(s[7 * st]) : (F)0;
     r.ring = nullptr;
   }
   template <typename F>
@@ -1043,9 +1048,10 @@ struct AllpassDelay {
     if (r.len == 0u) return x;  // a lane past the last voice
     const F y = allpass<F>(r, r.ring[r.rp]);
     r.rp = r.rp + 1u == r.len ? 0u : r.rp + 1u;
-    r.ring[r.wp] = x;
+    const F w = FB ? y * r.fb + x : x;  // process_sample, :263-269
+    r.ring[r.wp] = w;
     r.wp = r.wp + 1u == r.len ? 0u : r.wp + 1u;
-    return y;
+    return FB ? y - r.fb * w : y;
   }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
@@ -1066,16 +1072,21 @@ struct AllpassDelay {
 #pragma unroll
           for (int k = 0; k < VW; ++k) y[j * VW + k] = v[k];
         }
+        F wr[T];  // what goes into the ring: the input, or the input plus the fed-back delayed signal
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+          const F d = allpass<F>(r, y[j]);
+          wr[j] = FB ? d * r.fb + x[j] : x[j];
+          x[j] = FB ? d - r.fb * wr[j] : d;
+        }
         Vec* dst = reinterpret_cast<Vec*>(r.ring + r.wp);
 #pragma unroll
         for (int j = 0; j < T / VW; ++j) {
           Vec v;
 #pragma unroll
-          for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
+          for (int k = 0; k < VW; ++k) v[k] = wr[j * VW + k];
           dst[j] = v;
         }
-#pragma unroll
-        for (int j = 0; j < T; ++j) x[j] = allpass<F>(r, y[j]);
         r.rp = r.rp + (u32)T == r.len ? 0u : r.rp + (u32)T;
         r.wp = r.wp + (u32)T == r.len ? 0u : r.wp + (u32)T;
       }
@@ -1094,10 +1105,13 @@ struct AllpassDelay {
     }
     if (op != EV_SET) return;
     if (rel == 4) r.coeff = word_to_f<F>((typename WordOf<F>::type)bits);
+    else if (rel == 7) r.fb = word_to_f<F>((typename WordOf<F>::type)bits);
     else if (rel == 0) r.wp = (u32)bits;
     else if (rel == 1) r.rp = (u32)bits;
   }
 };
+typedef AllpassDelayT<false> AllpassDelay;
+typedef AllpassDelayT<true> AllpassFbDelay;
 
 // x (op) value: Constant + MathUGen (util.rs:61-63, math.rs:22-85) and WrMul/WrAdd/WrSub
 // (wrappers_core/math.rs:62-67).  slot 0: value.  OP: 0 mul, 1 add, 2 sub, 3 div

@@ -121,6 +121,7 @@ inline UGenSpec OnePoleLpf(double cutoff) { return UGenSpec(KNH_STAGE_ONEPOLE_LP
 inline UGenSpec OnePoleHpf() { return UGenSpec(KNH_STAGE_ONEPOLE_HPF, {}); }
 // SampleDelay::new(Seconds::from_secs_f64(max_delay_seconds)) -- delay.rs:24-31
 inline UGenSpec AllpassDelay(double max_delay_seconds) { return UGenSpec(KNH_STAGE_ALLPASS_DELAY, {max_delay_seconds}); }  // delay.rs:107-117
+inline UGenSpec AllpassFeedbackDelay(double max_delay_seconds) { return UGenSpec(KNH_STAGE_ALLPASS_FB_DELAY, {max_delay_seconds}); }  // delay.rs:221-229
 inline UGenSpec SampleDelay(double max_delay_seconds) { return UGenSpec(KNH_STAGE_SAMPLE_DELAY, {max_delay_seconds}); }
 inline UGenSpec EnvAsr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_ASR, {attack, release}); s.is_env = true; return s; }
 inline UGenSpec EnvAr(double attack, double release) { UGenSpec s(KNH_STAGE_MUL_ENV_AR, {attack, release}); s.is_env = true; return s; }
@@ -246,6 +247,7 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
     case KNH_STAGE_POLYBLEP: { static const char* pb[] = {"freq", "pulse_width", "waveform"}; *n = 3; return pb; }
     case KNH_STAGE_SAFETY_LIMITER: *n = 0; return frq;
     case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_ALLPASS_DELAY: *n = 1; return dly;
+    case KNH_STAGE_ALLPASS_FB_DELAY: { static const char* fbd[] = {"delay_time", "feedback"}; *n = 2; return fbd; }
     case KNH_STAGE_MUL_ENVELOPE: *n = 4; return seg;
     case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: *n = 3; return sin;
     case KNH_STAGE_SVF: *n = 5; return svf;

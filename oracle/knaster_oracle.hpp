@@ -1191,6 +1191,36 @@ struct AllpassDelay : UGen<F> {
   }
 };
 
+// AllpassFeedbackDelay -- delay.rs:210-306
+template <typename F>
+struct AllpassFeedbackDelay : UGen<F> {
+  F feedback = F(0);
+  AllpassDelay<F> allpass_delay;
+  explicit AllpassFeedbackDelay(Seconds max_delay) : allpass_delay(max_delay) {}
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 2; }
+  std::vector<std::string> param_descriptions() const override { return {"delay_time", "feedback"}; }
+  void init(uint32_t sample_rate, size_t bs) override { allpass_delay.init(sample_rate, bs); }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override {  // process_sample, :263-269
+    const F delayed_sig = allpass_delay.read();
+    const F delay_write = delayed_sig * feedback + in[0];
+    allpass_delay.write_and_advance(delay_write);
+    out[0] = delayed_sig - feedback * delay_write;
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    if (index == 0) {  // :231-236; the product ignores a delay that does not fit the ring (the reference indexes out of bounds)
+      const double delay_frames = v.float_or_panic() * static_cast<double>(ctx.sample_rate());
+      if (delay_frames < static_cast<double>(allpass_delay.buffer.size())) allpass_delay.set_delay_in_frames(fnew<F>(delay_frames));
+      else ctx.rt_log("AllpassFeedbackDelay: delay_time longer than the buffer, ignored");
+    } else if (index == 1) {
+      feedback = fnew<F>(v.float_or_panic());
+    } else {
+      ctx.rt_log("Unknown parameter set for AllpassFeedbackDelay");
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------
 // SampleDelay -- knaster_core_dsp/src/ugens/delay.rs:14-50
 // ---------------------------------------------------------------------------

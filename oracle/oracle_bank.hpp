@@ -24,7 +24,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: return 1;
     case KNH_STAGE_WR_MUL: case KNH_STAGE_WR_ADD: case KNH_STAGE_WR_SUB: return 1;
     case KNH_STAGE_WR_VSUB: case KNH_STAGE_WR_DIV: case KNH_STAGE_WR_VDIV: case KNH_STAGE_WR_POWF: case KNH_STAGE_WR_POWI:
-    case KNH_STAGE_POW_CONST: case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_PHASOR: case KNH_STAGE_ALLPASS_DELAY: return 1;
+    case KNH_STAGE_POW_CONST: case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_PHASOR: case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: return 1;
     case KNH_STAGE_SAFETY_LIMITER: return 0;
     case KNH_STAGE_POLYBLEP: return 2;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
@@ -74,6 +74,7 @@ struct VoiceChainBuilder {
           core = std::make_unique<PolyBlep<F>>(waveform_from_pinteger(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u), fnew<F>(a[1]));
           break;
         case KNH_STAGE_SAFETY_LIMITER: core = std::make_unique<SafetyLimiter<F>>(); break;
+        case KNH_STAGE_ALLPASS_FB_DELAY: core = std::make_unique<AllpassFeedbackDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_ALLPASS_DELAY: core = std::make_unique<AllpassDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_SAMPLE_DELAY: core = std::make_unique<SampleDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_MUL_ENV_ASR: core = std::make_unique<EnvAsr<F>>(fnew<F>(a[0]), fnew<F>(a[1])); break;

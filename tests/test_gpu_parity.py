@@ -519,15 +519,17 @@ def test_polyblep_all_waveforms(knh, oracle, sample_type):
     o.close()
 
 
+@pytest.mark.parametrize("kind", [L.STAGE_ALLPASS_DELAY, L.STAGE_ALLPASS_FB_DELAY])
 @pytest.mark.parametrize("sample_type", [L.F32, L.F64])
-def test_allpass_delay(knh, oracle, sample_type):
-    """AllpassDelay (delay.rs:93-206): fractional delays through the allpass interpolator, the untouched start (read and
+def test_allpass_delay(knh, oracle, sample_type, kind):
+    """AllpassDelay (delay.rs:93-206) and AllpassFeedbackDelay (the Schroeder allpass around it, :210-306; feedback set at
+    block 1 and changed later): fractional delays through the allpass interpolator, the untouched start (read and
     write pointers together: a whole ring of delay), delays shorter than a tile, pointer wrap-around, changes at block
     starts and mid-block, a delay_time of the ring length or more ignored."""
     n, bs = 96, 64
     p = configs.voice_parameters(n)
     v = np.arange(n, dtype=np.uint32)
-    w = configs.Workload("allpass", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_ALLPASS_DELAY, delayed_changes_per_block=2),
+    w = configs.Workload("allpass", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(kind, delayed_changes_per_block=2),
                                      Stage(L.STAGE_MUL_CONST)], n, bs, sample_type, 2)
     max_delay = 0.003 + 0.0001 * (v % 30)
     ring = np.array([int(s * 282240000.0) * 48000 // 282240000 for s in max_delay])  # Seconds::to_samples for s < 1
@@ -540,6 +542,8 @@ def test_allpass_delay(knh, oracle, sample_type):
         return d / 48000.0
 
     def ev(block, bank):
+        if kind == L.STAGE_ALLPASS_FB_DELAY and block in (1, 8):
+            bank.param_apply_many(v, 2, 1, L.VALUE_FLOAT, (0.3 + 0.005 * v) * (1.0 if block == 1 else -0.9))
         if block == 2:
             bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, delay_seconds(0))
         if block == 6:

@@ -26,6 +26,7 @@ PROCESSORS = [
     (L.STAGE_MUL_ENVELOPE, [(0, 0.5, 2.0)]),
     (L.STAGE_SAFETY_LIMITER, []),
     (L.STAGE_ALLPASS_DELAY, [(0, 0.0001, 0.004)]),
+    (L.STAGE_ALLPASS_FB_DELAY, [(0, 0.0001, 0.004), (1, -0.8, 0.8)]),
 ]
 WRAPPERS = [L.STAGE_WR_MUL, L.STAGE_WR_ADD, L.STAGE_WR_SUB, L.STAGE_WR_VSUB, L.STAGE_WR_DIV, L.STAGE_WR_POWI]
 
@@ -42,7 +43,7 @@ def ctor_for(kind, n, rng, p):
         return None
     if kind in (L.STAGE_MUL_ENV_ASR, L.STAGE_MUL_ENV_AR):
         return np.stack([p["attack"] * 0.2, p["release"] * 0.02], axis=1)
-    if kind in (L.STAGE_SAMPLE_DELAY, L.STAGE_ALLPASS_DELAY):
+    if kind in (L.STAGE_SAMPLE_DELAY, L.STAGE_ALLPASS_DELAY, L.STAGE_ALLPASS_FB_DELAY):
         return rng.uniform(0.0045, 0.006, (n, 1))
     if kind == L.STAGE_MUL_ENVELOPE:  # [start, time_scale, looping, n_segments, (duration, value) * 4]
         a = np.zeros((n, 12))
@@ -80,7 +81,7 @@ def random_chain(seed):
             ctor[len(stages) - 1] = ctor_for(kind, n, rng, p)
             continue
         kind, params = PROCESSORS[int(rng.integers(0, len(PROCESSORS)))]
-        if kind in (L.STAGE_SAMPLE_DELAY, L.STAGE_ALLPASS_DELAY):
+        if kind in (L.STAGE_SAMPLE_DELAY, L.STAGE_ALLPASS_DELAY, L.STAGE_ALLPASS_FB_DELAY):
             if have_delay:
                 continue
             have_delay = True
