@@ -81,7 +81,8 @@ pub const KNH_STAGE_SAFETY_LIMITER: u16 = 23;
 pub const KNH_STAGE_POLYBLEP: u16 = 24;
 pub const KNH_STAGE_ALLPASS_DELAY: u16 = 25;
 pub const KNH_STAGE_ALLPASS_FB_DELAY: u16 = 26;
-pub const KNH_STAGE_KIND_COUNT: u16 = 27;
+pub const KNH_STAGE_BUFFER_READER: u16 = 27;
+pub const KNH_STAGE_KIND_COUNT: u16 = 28;
 
 // knh_svf_type = SvfFilterType, knaster_core_dsp/src/ugens/svf.rs:19-39
 pub const KNH_SVF_LOW: u32 = 0;
@@ -113,6 +114,7 @@ unsafe extern "C" {
     pub fn knh_chain_ugen_count(stages: *const knh_stage_desc, n_stages: u32) -> i32;
     pub fn knh_bank_create(desc: *const knh_bank_desc, out_bank: *mut *mut knh_bank) -> i32;
     pub fn knh_bank_set_ctor_args(bank: *mut knh_bank, stage: u32, first_voice: u32, count: u32, args: *const f64, n_args: u32) -> i32;
+    pub fn knh_bank_set_buffer(bank: *mut knh_bank, stage: u32, samples: *const c_void, n_frames: usize, buffer_sample_rate: f64) -> i32;
     pub fn knh_bank_init(bank: *mut knh_bank, sample_rate: u32, block_size: usize) -> i32;
     pub fn knh_bank_destroy(bank: *mut knh_bank);
     pub fn knh_bank_inputs(bank: *const knh_bank) -> u16;

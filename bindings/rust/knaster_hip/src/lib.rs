@@ -51,8 +51,8 @@ use knaster_core::{
 pub mod ffi;
 use ffi::*;
 
-/// Upper bound of parameters per stage (SvfFilter has 5: svf.rs:244-270).
-pub const MAX_PARAMS: usize = 5;
+/// Upper bound of parameters per stage (BufferReader has 6: buffer.rs:62-103).
+pub const MAX_PARAMS: usize = 6;
 
 /// One stage of a voice chain (`knh_stage_desc`); the table of kinds is in `include/knaster_hip.h`.
 pub type Stage = knh_stage_desc;

@@ -114,6 +114,11 @@ typedef enum knh_value_kind {
  * KNH_STAGE_ALLPASS_FB_DELAY  x >> g.push(AllpassFeedbackDelay::new(Seconds::from_secs_f64(max_delay)))  delay.rs:210-306  1  max_delay (s)
  *     the Schroeder allpass around an AllpassDelay.  params: 0 delay_time (seconds; longer than the ring: ignored -- the
  *     reference does not check and would index out of bounds), 1 feedback
+ * KNH_STAGE_BUFFER_READER   g.push(BufferReader::<F, U1>::new(buffer, rate, looping).start_at(start))  buffer.rs:19-191  1  rate, looping (0/1), start (s)
+ *     a source: plays the single-channel Buffer given to knh_bank_set_buffer (shared by every voice) with linear
+ *     interpolation; one-shot voices mark done at the frame after their last one and are silent afterwards.
+ *     params: 0 rate, 1 looping(bool), 2 start_s, 3 duration_s, 4 end_s, 5 t_restart(trigger).  Not combinable with
+ *     delayed_changes_per_block (the reference's block loop ignores partial blocks).  At most one per chain.
  * KNH_STAGE_PHASOR          g.push(Phasor::new(freq))           osc.rs:172-214       1    freq
  *     a source like SinWt: a 0..1 ramp, f64 phase and step whatever F is.  params: 0 freq
  * KNH_STAGE_POLYBLEP        g.push(PolyBlep::new(waveform, freq))   polyblep.rs:123-508   1    waveform (0..13), freq
@@ -156,7 +161,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_POLYBLEP = 24,
   KNH_STAGE_ALLPASS_DELAY = 25,
   KNH_STAGE_ALLPASS_FB_DELAY = 26,
-  KNH_STAGE_KIND_COUNT = 27
+  KNH_STAGE_BUFFER_READER = 27,
+  KNH_STAGE_KIND_COUNT = 28
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,
@@ -249,6 +255,9 @@ int32_t knh_bank_set_ctor_args(knh_bank* bank, uint32_t stage, uint32_t first_vo
                                const double* args, uint32_t n_args);
 /* UGen::init(sample_rate, block_size) -- knaster_core/src/ugen.rs:242-246; runs
  * on the control thread, may allocate (graph.rs:462-475).  Uploads all state. */
+/* Buffer::from_vec(samples, sample_rate) (dsp/buffer.rs:58-66) for the chain's BufferReader stage: `n_frames` samples of
+ * the bank's sample type, copied into device memory at init.  Before knh_bank_init. */
+int32_t knh_bank_set_buffer(knh_bank* bank, uint32_t stage, const void* samples, size_t n_frames, double buffer_sample_rate);
 int32_t knh_bank_init(knh_bank* bank, uint32_t sample_rate, size_t block_size);
 void knh_bank_destroy(knh_bank* bank);
 

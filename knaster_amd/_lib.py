@@ -24,7 +24,7 @@ VALUE_FLOAT, VALUE_TRIGGER, VALUE_INTEGER, VALUE_BOOL, VALUE_SMOOTHING = 0, 1, 2
 (STAGE_SIN_WT, STAGE_SIN_NUMERIC, STAGE_SVF, STAGE_ONEPOLE_LPF, STAGE_ONEPOLE_HPF, STAGE_MUL_ENV_ASR,
  STAGE_MUL_ENV_AR, STAGE_MUL_CONST, STAGE_ADD_CONST, STAGE_SUB_CONST, STAGE_DIV_CONST, STAGE_WR_MUL,
  STAGE_WR_ADD, STAGE_WR_SUB, STAGE_MUL_ENVELOPE, STAGE_WR_VSUB, STAGE_WR_DIV, STAGE_WR_VDIV, STAGE_WR_POWF,
- STAGE_WR_POWI, STAGE_POW_CONST, STAGE_SAMPLE_DELAY, STAGE_PHASOR, STAGE_SAFETY_LIMITER, STAGE_POLYBLEP, STAGE_ALLPASS_DELAY, STAGE_ALLPASS_FB_DELAY) = range(27)
+ STAGE_WR_POWI, STAGE_POW_CONST, STAGE_SAMPLE_DELAY, STAGE_PHASOR, STAGE_SAFETY_LIMITER, STAGE_POLYBLEP, STAGE_ALLPASS_DELAY, STAGE_ALLPASS_FB_DELAY, STAGE_BUFFER_READER) = range(28)
 STAGE_FLAG_AR_FREQ = 1
 STAGE_FLAG_SMOOTH_PARAMS = 2
 # knh_svf_type
@@ -38,7 +38,7 @@ STAGE_CTOR_ARGS = {  # STAGE_MUL_ENVELOPE takes 4 + 2 * n_max (variable)
     STAGE_SIN_WT: 1, STAGE_SIN_NUMERIC: 1, STAGE_SVF: 4, STAGE_ONEPOLE_LPF: 1, STAGE_ONEPOLE_HPF: 0,
     STAGE_MUL_ENV_ASR: 2, STAGE_MUL_ENV_AR: 2, STAGE_MUL_CONST: 1, STAGE_ADD_CONST: 1, STAGE_SUB_CONST: 1,
     STAGE_DIV_CONST: 1, STAGE_WR_MUL: 1, STAGE_WR_ADD: 1, STAGE_WR_SUB: 1,
-    STAGE_WR_VSUB: 1, STAGE_WR_DIV: 1, STAGE_WR_VDIV: 1, STAGE_WR_POWF: 1, STAGE_WR_POWI: 1, STAGE_POW_CONST: 1, STAGE_SAMPLE_DELAY: 1, STAGE_PHASOR: 1, STAGE_SAFETY_LIMITER: 0, STAGE_POLYBLEP: 2, STAGE_ALLPASS_DELAY: 1, STAGE_ALLPASS_FB_DELAY: 1,
+    STAGE_WR_VSUB: 1, STAGE_WR_DIV: 1, STAGE_WR_VDIV: 1, STAGE_WR_POWF: 1, STAGE_WR_POWI: 1, STAGE_POW_CONST: 1, STAGE_SAMPLE_DELAY: 1, STAGE_PHASOR: 1, STAGE_SAFETY_LIMITER: 0, STAGE_POLYBLEP: 2, STAGE_ALLPASS_DELAY: 1, STAGE_ALLPASS_FB_DELAY: 1, STAGE_BUFFER_READER: 3,
 }
 
 
@@ -62,6 +62,7 @@ PROTOTYPES = {
     "knh_chain_ugen_count": (C.c_int32, [C.POINTER(StageDesc), C.c_uint32]),
     "knh_bank_create": (C.c_int32, [C.POINTER(BankDesc), C.POINTER(C.c_void_p)]),
     "knh_bank_set_ctor_args": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "knh_bank_set_buffer": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_double]),
     "knh_bank_init": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_size_t]),
     "knh_bank_destroy": (None, [C.c_void_p]),
     "knh_bank_inputs": (C.c_uint16, [C.c_void_p]),

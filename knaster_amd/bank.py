@@ -88,6 +88,11 @@ class VoiceBank:
         self._check(self._lib.knh_bank_set_ctor_args(self._h, stage, first_voice, a.shape[0],
                                                      a.ctypes.data_as(C.c_void_p), a.shape[1]))
 
+    def set_buffer(self, stage: int, samples, buffer_sample_rate: float):
+        """Buffer::from_vec(samples, sample_rate) for the chain's BufferReader stage (single channel)."""
+        a = np.ascontiguousarray(np.asarray(samples, dtype=self.dtype))
+        self._check(self._lib.knh_bank_set_buffer(self._h, stage, a.ctypes.data_as(C.c_void_p), a.shape[0], float(buffer_sample_rate)))
+
     def init(self, sample_rate: int, block_size: int):
         self._check(self._lib.knh_bank_init(self._h, sample_rate, block_size))
         self.sample_rate, self.block_size = sample_rate, block_size

@@ -68,6 +68,7 @@ class Workload:
     release: tuple = ()  # (stage, param, block) trigger fired on every voice before `block`
     description: str = ""
     delay_times: np.ndarray = None  # D3: per-voice SampleDelay delay_time set before block 0 (stage 3, param 0)
+    buffer: tuple = None  # (stage, samples, sample_rate): the Buffer of a BufferReader stage
 
 
 def config(name: str, n_voices: int | None = None, block_size: int | None = None, sample_type: int | None = None,

@@ -35,7 +35,7 @@ namespace {
 struct KindInfo {
   int n_slots, n_params, n_ctor, n_nodes;
   char sig;
-  const char* params[5];
+  const char* params[6];
 };
 const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* SIN_WT      */ {3, 3, 1, 1, 'W', {"freq", "phase_offset", "reset_phase"}},
@@ -65,6 +65,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* POLYBLEP    */ {5, 3, 2, 1, 'B', {"freq", "pulse_width", "waveform"}},
     /* ALLPASS_DLY */ {7, 1, 1, 1, 'Y', {"delay_time"}},
     /* ALLPASS_FB  */ {8, 2, 1, 1, 'Z', {"delay_time", "feedback"}},
+    /* BUFFER_READ */ {10, 6, 3, 1, 'F', {"rate", "looping", "start_s", "duration_s", "end_s", "t_restart"}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -76,7 +77,7 @@ inline int stage_cost(char c) {
   switch (c) {
     case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
     case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
-    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45; case 'Y': return 14; case 'Z': return 18;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45; case 'Y': return 14; case 'Z': return 18; case 'F': return 16;
     default: return 1;
   }
 }
@@ -110,6 +111,7 @@ int expected_value_kind(uint16_t kind, uint32_t param) {
     case KNH_STAGE_MUL_ENV_AR: return param == 2 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
     case KNH_STAGE_MUL_ENVELOPE: return param == 0 ? KNH_VALUE_FLOAT : param == 1 ? KNH_VALUE_INTEGER : KNH_VALUE_TRIGGER;
     case KNH_STAGE_POLYBLEP: return param == 2 ? KNH_VALUE_INTEGER : KNH_VALUE_FLOAT;
+    case KNH_STAGE_BUFFER_READER: return param == 1 ? KNH_VALUE_BOOL : param == 5 ? KNH_VALUE_TRIGGER : KNH_VALUE_FLOAT;
     default: return KNH_VALUE_FLOAT;
   }
 }
@@ -205,6 +207,7 @@ struct knh_bank {
   int device = 0;
 
   virtual int set_ctor(uint32_t stage, uint32_t first, uint32_t count, const double* args, uint32_t n_args) = 0;
+  virtual int set_buffer(uint32_t stage, const void* samples, size_t n_frames, double buffer_sample_rate) = 0;
   virtual int init(uint32_t sr, size_t bs) = 0;
   virtual int param_apply(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i) = 0;
   virtual int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) = 0;
@@ -297,6 +300,11 @@ struct Bank final : knh_bank {
   float* d_sine = nullptr;
   double* d_seg_table = nullptr;  // segment Envelope: [voice][seg_max][3]
   uint32_t seg_max = 0;
+  F* d_buffer = nullptr;          // BufferReader's shared Buffer (device copy), staged in h_buffer until init
+  std::vector<F> h_buffer;
+  double buffer_sr = 0.0;
+  std::vector<double> buf_start, buf_dur, buf_rate;  // BufferReader shadows per voice: start_frame, dur_frame, rate
+  double buf_base_rate = 0.0;
   void* d_delay = nullptr;        // SampleDelay rings: [voice][delay_stride] of F
   uint32_t delay_stride = 0;
   std::vector<uint32_t> delay_len;  // ring length per voice (samples)
@@ -331,7 +339,7 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_partials, d_out, d_voices, d_done, d_flags};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
     void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out};
@@ -359,6 +367,15 @@ struct Bank final : knh_bank {
     if (static_cast<int>(n_args) != stages[stage].n_ctor) return fail(KNH_ERR_INVALID_ARGUMENT, "wrong number of constructor arguments");
     if (n_args && !args) return fail(KNH_ERR_INVALID_ARGUMENT, "null args");
     std::copy(args, args + static_cast<size_t>(count) * n_args, ctor[stage].begin() + static_cast<size_t>(first) * n_args);
+    return KNH_OK;
+  }
+
+  int set_buffer(uint32_t stage, const void* samples, size_t n_frames, double sr) override {
+    if (initialised) return fail(KNH_ERR_INVALID_ARGUMENT, "knh_bank_set_buffer comes before knh_bank_init");
+    if (stage >= stages.size() || stages[stage].kind != KNH_STAGE_BUFFER_READER) return fail(KNH_ERR_INVALID_ARGUMENT, "not a BufferReader stage");
+    if (!samples || n_frames == 0 || n_frames >= (1ull << 31) || !(sr > 0.0)) return fail(KNH_ERR_INVALID_ARGUMENT, "empty buffer or bad sample rate");
+    h_buffer.assign(static_cast<const F*>(samples), static_cast<const F*>(samples) + n_frames);
+    buffer_sr = sr;
     return KNH_OK;
   }
 
@@ -487,6 +504,31 @@ struct Bank final : knh_bank {
               row[0] = dur; row[1] = 1.0 / dur; row[2] = val;  // EnvelopeSegment::new, envelopes.rs:327-333
             }
           } break;
+          case KNH_STAGE_BUFFER_READER: {  // buffer.rs:40-57 (new, start_at), :106-115 (init)
+            if (h_buffer.empty()) return fail(KNH_ERR_INVALID_ARGUMENT, "BufferReader stage without knh_bank_set_buffer");
+            if (S.dcpb > 0) return fail(KNH_ERR_INVALID_ARGUMENT, "BufferReader cannot be wrapped in WrPreciseTiming here");
+            if (v == 0) { buf_start.assign(nv, 0.0); buf_dur.assign(nv, 0.0); buf_rate.assign(nv, 0.0); }
+            buf_base_rate = buffer_sr / static_cast<double>(sr);  // Buffer::buf_rate_scale
+            const double length_seconds = static_cast<double>(h_buffer.size()) / buffer_sr;
+            auto secs_to_frames = [&](double secs) {  // Seconds::from_secs_f64(secs).to_samples_f64(buffer_sr), time.rs:59-64,92-96
+              const double whole = std::floor(secs);
+              const uint32_t tes = sat_u32((secs - std::trunc(secs)) * 282240000.0);
+              return static_cast<double>(sat_u32(whole)) * buffer_sr + (static_cast<double>(tes) * buffer_sr) / 282240000.0;
+            };
+            const double start = secs_to_frames(a[2]), dur = secs_to_frames(length_seconds);
+            buf_start[v] = start; buf_dur[v] = dur; buf_rate[v] = a[0];
+            auto put2 = [&](int rel, double d) {
+              const uint64_t b = to_bits(d);
+              slot(S.slot_base + rel, v) = static_cast<W>(static_cast<uint32_t>(b));
+              slot(S.slot_base + rel + 1, v) = static_cast<W>(static_cast<uint32_t>(b >> 32));
+            };
+            put2(0, start);                   // jump_to(start_frame)
+            put2(2, buf_base_rate * a[0]);    // base_rate * rate, the per-sample step
+            put2(4, start);
+            put2(6, start + dur);
+            slot(S.slot_base + 8, v) = 0;
+            slot(S.slot_base + 9, v) = a[1] != 0.0 ? 1u : 0u;
+          } break;
           case KNH_STAGE_PHASOR: {  // osc.rs:181-188 (new), :197-200 (init: step = freq * (1 / sample_rate))
             const double step = a[0] * (1.0 / static_cast<double>(sr));
             const uint64_t sb = to_bits(step);
@@ -564,6 +606,10 @@ struct Bank final : knh_bank {
       for (int i = 0; i < 16384; ++i) table[i] = static_cast<float>(std::sin((static_cast<double>(i) / 16384.0) * PI * 2.0));
       KNH_HIP(hipMalloc(&d_sine, 16384 * sizeof(float)));
       KNH_HIP(hipMemcpy(d_sine, table.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (!h_buffer.empty()) {
+      KNH_HIP(hipMalloc(&d_buffer, h_buffer.size() * sizeof(F)));
+      KNH_HIP(hipMemcpy(d_buffer, h_buffer.data(), h_buffer.size() * sizeof(F), hipMemcpyHostToDevice));
     }
     if (!delay_len.empty()) {
       uint32_t mx = 0;
@@ -788,6 +834,26 @@ struct Bank final : knh_bank {
           set(0, 1);  // t_restart: state = Attacking, t untouched (envelopes.rs:47-49,131-133)
         }
         break;
+      case KNH_STAGE_BUFFER_READER: {  // buffer.rs:62-103
+        auto set2 = [&](int rel, double d) {
+          const uint64_t b = to_bits(d);
+          set(rel, static_cast<uint32_t>(b));
+          set(rel + 1, static_cast<uint32_t>(b >> 32));
+        };
+        auto secs_to_frames = [&](double secs) {
+          const double whole = std::floor(secs);
+          const uint32_t tes = sat_u32((secs - std::trunc(secs)) * 282240000.0);
+          return static_cast<double>(sat_u32(whole)) * buffer_sr + (static_cast<double>(tes) * buffer_sr) / 282240000.0;
+        };
+        switch (param) {
+          case 0: buf_rate[v] = f; set2(2, buf_base_rate * f); break;
+          case 1: set(9, iv != 0 ? 1u : 0u); break;
+          case 2: buf_start[v] = secs_to_frames(f); set2(4, buf_start[v]); set2(6, buf_start[v] + buf_dur[v]); break;
+          case 3: buf_dur[v] = secs_to_frames(f); set2(6, buf_start[v] + buf_dur[v]); break;
+          case 4: set2(6, secs_to_frames(f)); break;
+          default: set2(0, buf_start[v]); set(8, 0); break;  // t_restart -> reset -> jump_to(start_frame)
+        }
+      } break;
       case KNH_STAGE_POLYBLEP: {  // polyblep.rs:158-182
         const F srf = static_cast<F>(sample_rate);
         if (param == 0) {
@@ -1075,6 +1141,8 @@ struct Bank final : knh_bank {
     a.seg_max = seg_max;
     a.delay_ring = d_delay;
     a.delay_stride = delay_stride;
+    a.buffer = d_buffer;
+    a.buffer_frames = static_cast<uint32_t>(h_buffer.size());
     a.ev_start = have_events ? h_ev_start : nullptr;  // pinned host memory, device-visible
     a.events = h_events;
     a.partials = d_partials;
@@ -1132,7 +1200,8 @@ struct Bank final : knh_bank {
       uint32_t fl = 0;
       if (h_flags[0]) fl |= KNH_FLAG_ANY_DONE;
       bool has_env = false;
-      for (const StageInfo& st : stages) has_env = has_env || st.kind == KNH_STAGE_MUL_ENV_ASR || st.kind == KNH_STAGE_MUL_ENV_AR || st.kind == KNH_STAGE_MUL_ENVELOPE;
+      for (const StageInfo& st : stages) has_env = has_env || st.kind == KNH_STAGE_MUL_ENV_ASR || st.kind == KNH_STAGE_MUL_ENV_AR || st.kind == KNH_STAGE_MUL_ENVELOPE ||
+                          st.kind == KNH_STAGE_BUFFER_READER;
       if (has_env && h_flags[1] == 0) fl |= KNH_FLAG_ALL_DONE;  // a chain without an envelope never finishes
       *out_flags = fl;
     }
@@ -1222,7 +1291,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
   for (uint32_t i = 0; i < n; ++i) {
     if (st[i].kind >= KNH_STAGE_KIND_COUNT) { *why = "unknown stage kind"; return KNH_ERR_INVALID_ARGUMENT; }
     const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC || st[i].kind == KNH_STAGE_PHASOR ||
-                        st[i].kind == KNH_STAGE_POLYBLEP;
+                        st[i].kind == KNH_STAGE_POLYBLEP || st[i].kind == KNH_STAGE_BUFFER_READER;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ)) { *why = "SMOOTH_PARAMS and AR_FREQ cannot be combined"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1356,6 +1425,10 @@ void knh_bank_destroy(knh_bank* bank) { delete bank; }
 int32_t knh_bank_set_ctor_args(knh_bank* bank, uint32_t stage, uint32_t first_voice, uint32_t count, const double* args, uint32_t n_args) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   return bank->set_ctor(stage, first_voice, count, args, n_args);
+}
+int32_t knh_bank_set_buffer(knh_bank* bank, uint32_t stage, const void* samples, size_t n_frames, double buffer_sample_rate) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  return bank->set_buffer(stage, samples, n_frames, buffer_sample_rate);
 }
 int32_t knh_bank_init(knh_bank* bank, uint32_t sample_rate, size_t block_size) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
@@ -1491,6 +1564,7 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_SAMPLE_DELAY: w += word; break;
       case KNH_STAGE_PHASOR: w += word * 2; break;
       case KNH_STAGE_POLYBLEP: w += word; break;
+      case KNH_STAGE_BUFFER_READER: w += word * 3; break;  // + two Buffer samples read per frame
       case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)
       default: break;
     }

@@ -72,6 +72,8 @@ struct Ctx {
   u32 seg_max;
   void* delay_ring;         // SampleDelay: [voice][delay_stride] samples of F, each voice's ring contiguous
   u32 delay_stride;
+  const void* buffer;       // BufferReader: the bank's shared single-channel Buffer, samples of F
+  u32 buffer_frames;
 };
 
 // ---------------------------------------------------------------------------
@@ -88,6 +90,7 @@ struct SinWtT {
   static constexpr bool kUsesSine = true;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { u32 phase, off, inc; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
@@ -132,6 +135,7 @@ struct Phasor {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { double phase, step; };
   template <typename W> static __device__ __forceinline__ double ld2(const W* s, long st, int k) {
     const u64 lo = (u32)s[(long)k * st], hi = (u32)s[(long)(k + 1) * st];
@@ -179,6 +183,7 @@ struct SafetyLimiter {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs {};
   template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>&, const W*, long) {}
   template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
@@ -207,6 +212,7 @@ struct PolyBlepOsc {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F t, dt, pw; u32 wf, fast; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -394,6 +400,81 @@ struct PolyBlepOsc {
   }
 };
 
+// BufferReader<F, U1> -- buffer.rs:19-191: plays the bank's shared Buffer (dsp/buffer.rs) from an f64 read pointer with
+// linear interpolation (Buffer::get_linear_interp_f64, :100-110), per-voice rate, start and end, looping or one-shot
+// (mark_done(i + 1) at the frame after the last one, then silence).  All positions are f64 for any F.
+// slots: 0,1 read_pointer  2,3 step (= base_rate * rate)  4,5 start_frame  6,7 end_frame  8 finished  9 looping
+struct BufferReader {
+  static constexpr int kSlots = 10;
+  static constexpr u32 kMutableMask = 0b0100000011u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = true;  // it marks done and can be "stopped"
+  static constexpr bool kNeedsBind = true;
+  static constexpr bool kHasSeg = true;
+  template <typename F> struct Regs { double rp, step, start, end; u32 finished, looping, seg; const F* buf; u32 n; };
+  template <typename F> static __device__ __forceinline__ bool is_stopped(const Regs<F>& r) { return r.finished != 0u; }
+  template <typename W> static __device__ __forceinline__ double ld2(const W* s, long st, int k) {
+    const u64 lo = (u32)s[(long)k * st], hi = (u32)s[(long)(k + 1) * st];
+    return __builtin_bit_cast(double, lo | (hi << 32));
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.rp = ld2(s, st, 0); r.step = ld2(s, st, 2); r.start = ld2(s, st, 4); r.end = ld2(s, st, 6);
+    r.finished = (u32)s[8 * st]; r.looping = (u32)s[9 * st];
+    r.seg = 0; r.buf = nullptr; r.n = 0;
+  }
+  template <typename F>
+  static __device__ __forceinline__ void bind(Regs<F>& r, const Ctx& c) {
+    r.buf = reinterpret_cast<const F*>(c.buffer);
+    r.n = c.buffer_frames;
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    const u64 b = __builtin_bit_cast(u64, r.rp);
+    s[0] = (W)(u32)b; s[st] = (W)(u32)(b >> 32); s[8 * st] = (W)r.finished;
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx& c, u32 frame, u32& done_frame) {
+    bind<F>(r, c);
+    if (r.finished || r.n == 0u) return (F)0;
+    // get_linear_interp_f64: mix = fract(index); buffer[i] * (1 - mix) + buffer[(i + 1) % len] * mix.  `index as usize`
+    // saturates at 0; an index past the end is undefined behaviour in the reference, clamped here.
+    const double ip = __builtin_trunc(r.rp);
+    const F mix = (F)(r.rp - ip);
+    u32 i = r.rp > 0.0 ? (r.rp < 4294967040.0 ? (u32)r.rp : 0xFFFFFFFFu) : 0u;
+    if (i >= r.n) i = r.n - 1u;
+    const u32 i1 = i + 1u == r.n ? 0u : i + 1u;
+    const F y = r.buf[i] * ((F)1 - mix) + r.buf[i1] * mix;
+    r.rp += r.step;
+    if (r.rp >= r.end) {  // process_block, :166-173
+      if (r.looping) { r.rp = r.start; }
+      else { r.finished = 1u; done_frame = frame + 1u - r.seg; }
+    }
+    return y;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 frame) {
+    if (op & EV_SPLIT) r.seg = frame;
+    if ((op & 0x7Fu) != EV_SET) return;
+    const u32 w = (u32)bits;
+    auto lo = [](double d, u32 v) { return __builtin_bit_cast(double, (__builtin_bit_cast(u64, d) & 0xFFFFFFFF00000000ull) | (u64)v); };
+    auto hi = [](double d, u32 v) { return __builtin_bit_cast(double, (__builtin_bit_cast(u64, d) & 0x00000000FFFFFFFFull) | ((u64)v << 32)); };
+    switch (rel) {
+      case 0: r.rp = lo(r.rp, w); break;      case 1: r.rp = hi(r.rp, w); break;
+      case 2: r.step = lo(r.step, w); break;  case 3: r.step = hi(r.step, w); break;
+      case 4: r.start = lo(r.start, w); break; case 5: r.start = hi(r.start, w); break;
+      case 6: r.end = lo(r.end, w); break;    case 7: r.end = hi(r.end, w); break;
+      case 8: r.finished = w; break;
+      default: r.looping = w; break;
+    }
+  }
+};
+
 // SinNumeric -- osc.rs:222-271.  slots: 0 phase, 1 phase_offset, 2 phase_increment
 struct SinNum {
   static constexpr int kSlots = 3;
@@ -401,6 +482,7 @@ struct SinNum {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F phase, off, inc; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
@@ -441,6 +523,7 @@ struct Svf {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m0, m1, m2; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -554,6 +637,7 @@ struct OnePoleT {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F y, a0, b1; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -592,6 +676,7 @@ struct MulEnvT {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = true;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = true;  // r.seg: start of the (partial) block, for mark_done
   template <typename F> struct Regs { u32 state; F t, ar, rr, scale; u32 seg; };
   template <typename F> static __device__ __forceinline__ bool is_stopped(const Regs<F>& r) { return r.state == 0u; }
   template <typename F, typename W>
@@ -782,6 +867,7 @@ struct MulSegEnv {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = true;
   static constexpr bool kNeedsBind = true;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs {
     u32 running, cur, n_seg, looping, seg;
     double time, from, dt, dur, recip, val;
@@ -897,6 +983,7 @@ struct SampleDelay {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = true;
+  static constexpr bool kHasSeg = false;
   static constexpr int kPrefetch = 32;  // largest tile that is read one tile ahead
   template <typename F> struct Regs {
     u32 wp, off, len, row;
@@ -1020,6 +1107,7 @@ struct AllpassDelayT {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = true;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { u32 wp, rp, len, row; F coeff, pin, pout, fb; F* ring; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -1124,6 +1212,7 @@ struct ValT {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F v; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.v = word_to_f<F>(s[0]); }
@@ -1165,6 +1254,7 @@ struct PowiVal {
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { int n; };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.n = (int)(u32)s[0]; }
@@ -1251,7 +1341,7 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   }
   __device__ __forceinline__ void begin_block(u32 frame_begin, const Ctx& c) {
     if constexpr (S0::kNeedsBind) S0::template bind<F>(r, c);
-    else if constexpr (S0::kIsEnv) r.seg = frame_begin;
+    if constexpr (S0::kIsEnv && S0::kHasSeg) r.seg = frame_begin;
     rest.begin_block(frame_begin, c);
   }
 };
@@ -1273,6 +1363,8 @@ struct VoiceKernelArgs {
   u32 seg_max;
   void* delay_ring;                 // SampleDelay rings [n_voices][delay_stride] of F, or null
   u32 delay_stride;
+  const void* buffer;               // BufferReader's shared Buffer (single channel, F), or null
+  u32 buffer_frames;
   const u32* ev_start;              // [n_voices + 1] or null when the block has no events
   const Event* events;
   F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its 64 voices
@@ -1320,6 +1412,8 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ctx.seg_max = a.seg_max;
   ctx.delay_ring = a.delay_ring;
   ctx.delay_stride = a.delay_stride;
+  ctx.buffer = a.buffer;
+  ctx.buffer_frames = a.buffer_frames;
 
   const u32 wave_global = blockIdx.x * WAVES + wave;
   const u32 v0 = wave_global * 64u;

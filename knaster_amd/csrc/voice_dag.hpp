@@ -202,6 +202,8 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
   ctx.seg_max = a.seg_max;
   ctx.delay_ring = a.delay_ring;
   ctx.delay_stride = a.delay_stride;
+  ctx.buffer = a.buffer;
+  ctx.buffer_frames = a.buffer_frames;
 
   // Each role walks the same (block, tile) sequence, `lag` steps behind wave 0.
   auto role_loop = [&](int lag, auto&& body, auto&& block_end) {

@@ -60,6 +60,8 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   ctx.seg_max = a.seg_max;
   ctx.delay_ring = a.delay_ring;
   ctx.delay_stride = a.delay_stride;
+  ctx.buffer = a.buffer;
+  ctx.buffer_frames = a.buffer_frames;
   const bool live = (u32)lane < nv;
   const u32 voice = live ? v0 + lane : v0 + nv - 1;
   ChainT chain;

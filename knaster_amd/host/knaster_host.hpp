@@ -328,7 +328,8 @@ class Graph {
     }
     const UGenSpec& s = n.spec;
     if (s.is_env || s.is_constant) throw GraphError("an envelope/constant must be an operand of * + - /");
-    const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR || s.kind == KNH_STAGE_POLYBLEP;
+    const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR || s.kind == KNH_STAGE_POLYBLEP ||
+                        s.kind == KNH_STAGE_BUFFER_READER;
     uint16_t flags = 0;
     if (source) {
       if (n.link_source >= 0) {

@@ -120,6 +120,10 @@ struct Seconds {
     r.subsecond_tesimals = sat_u32(static_cast<double>(subsec_nanos) * conversion_factor);
     return r;
   }
+  double to_samples_f64(double sample_rate) const {  // time.rs:92-96
+    return static_cast<double>(seconds) * sample_rate +
+           (static_cast<double>(subsecond_tesimals) * sample_rate) / static_cast<double>(SUBSECOND_TESIMALS_PER_SECOND);
+  }
   double to_secs_f64() const {  // time.rs:71-74
     return static_cast<double>(seconds) + (static_cast<double>(subsecond_tesimals) / static_cast<double>(SUBSECOND_TESIMALS_PER_SECOND));
   }
@@ -249,6 +253,10 @@ struct ParameterValue {
   uint64_t integer_or_panic() const {
     if (kind != Integer) throw std::runtime_error("parameter value is expected to be an integer");
     return i;
+  }
+  bool bool_or_panic() const {
+    if (kind != Bool) throw std::runtime_error("parameter value is expected to be a bool");
+    return b;
   }
 };
 
@@ -893,6 +901,94 @@ struct Envelope : UGen<F> {
         running = false;
         break;
       default: break;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Buffer (single channel) -- knaster_core_dsp/src/dsp/buffer.rs:38-133;  BufferReader<F, U1> -- ugens/buffer.rs:19-191
+// ---------------------------------------------------------------------------
+template <typename F>
+struct Buffer {
+  std::vector<F> buffer;
+  double sample_rate = 48000.0;
+  double num_frames() const { return static_cast<double>(buffer.size()); }
+  double buf_rate_scale(uint32_t server_sample_rate) const { return sample_rate / static_cast<double>(server_sample_rate); }
+  double length_seconds() const { return num_frames() / sample_rate; }
+  F get_linear_interp_f64(double index) const {  // :100-110 with num_channels = 1, channel = 0
+    const F mix = fnew<F>(index - std::trunc(index));
+    size_t index_u = index > 0.0 ? static_cast<size_t>(index) : 0;  // `as usize` saturates
+    if (index_u >= buffer.size()) index_u = buffer.size() - 1;       // undefined behaviour in the reference; the product clamps
+    return buffer[index_u] * (F(1) - mix) + buffer[(index_u + 1) % buffer.size()] * mix;
+  }
+};
+template <typename F>
+struct BufferReader : UGen<F> {
+  std::shared_ptr<const Buffer<F>> buffer;
+  double read_pointer = 0.0, rate, base_rate = 0.0;
+  bool finished = false, looping;
+  double start_frame = 0.0, dur_frame, end_frame;
+  BufferReader(std::shared_ptr<const Buffer<F>> b, double rate_, bool looping_, double start_at_seconds = 0.0)
+      : buffer(std::move(b)), rate(rate_), looping(looping_), start_frame(start_at_seconds) {
+    dur_frame = end_frame = buffer->length_seconds();
+  }
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 6; }
+  std::vector<std::string> param_descriptions() const override { return {"rate", "looping", "start_s", "duration_s", "end_s", "t_restart"}; }
+  void jump_to(double p) { read_pointer = p; finished = false; }
+  void init(uint32_t sample_rate, size_t) override {  // :106-115
+    base_rate = buffer->buf_rate_scale(sample_rate);
+    start_frame = Seconds::from_secs_f64(start_frame).to_samples_f64(buffer->sample_rate);
+    dur_frame = Seconds::from_secs_f64(dur_frame).to_samples_f64(buffer->sample_rate);
+    end_frame = start_frame + dur_frame;
+    jump_to(start_frame);
+  }
+  void process(AudioCtx&, UGenFlags& flags, const F*, F* out) override {  // :119-141 (unused by the graph: it calls process_block)
+    if (finished) { out[0] = F(0); return; }
+    out[0] = buffer->get_linear_interp_f64(read_pointer);
+    read_pointer += base_rate * rate;
+    if (read_pointer >= end_frame) {
+      finished = true;
+      if (looping) jump_to(start_frame);
+      else flags.mark_done(0);
+    }
+  }
+  void process_block(AudioCtx& ctx, UGenFlags& flags, const BlockView<F>&, BlockView<F>& output) override {  // :143-190
+    F* o = output.channel(0);
+    size_t stop_sample = SIZE_MAX;
+    if (!finished) {
+      for (size_t i = 0; i < ctx.block_size(); ++i) {
+        o[i] = buffer->get_linear_interp_f64(read_pointer);
+        read_pointer += base_rate * rate;
+        if (read_pointer >= end_frame) {
+          finished = true;
+          if (looping) jump_to(start_frame);
+          else flags.mark_done(static_cast<uint32_t>(i + 1));
+        }
+        if (finished) { stop_sample = i + 1; break; }
+      }
+    } else {
+      stop_sample = 0;
+    }
+    if (stop_sample != SIZE_MAX)
+      for (size_t i = stop_sample; i < ctx.block_size(); ++i) o[i] = F(0);
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {  // :62-103
+    switch (index) {
+      case 0: rate = v.float_or_panic(); break;
+      case 1: looping = v.bool_or_panic(); break;
+      case 2:
+        start_frame = Seconds::from_secs_f64(v.float_or_panic()).to_samples_f64(buffer->sample_rate);
+        end_frame = start_frame + dur_frame;
+        break;
+      case 3:
+        dur_frame = Seconds::from_secs_f64(v.float_or_panic()).to_samples_f64(buffer->sample_rate);
+        end_frame = start_frame + dur_frame;
+        break;
+      case 4: end_frame = Seconds::from_secs_f64(v.float_or_panic()).to_samples_f64(buffer->sample_rate); break;
+      case 5: jump_to(start_frame); break;
+      default: ctx.rt_log("Unknown parameter set for BufferReader");
     }
   }
 };

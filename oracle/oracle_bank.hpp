@@ -27,6 +27,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_POW_CONST: case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_PHASOR: case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: return 1;
     case KNH_STAGE_SAFETY_LIMITER: return 0;
     case KNH_STAGE_POLYBLEP: return 2;
+    case KNH_STAGE_BUFFER_READER: return 3;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -46,6 +47,7 @@ struct ParamTarget {
 template <typename F>
 struct VoiceChainBuilder {
   const std::vector<knh_stage_desc>& stages;
+  std::shared_ptr<const Buffer<F>> buffer;  // the bank's shared Buffer, for a BufferReader stage
   explicit VoiceChainBuilder(const std::vector<knh_stage_desc>& s) : stages(s) {}
 
   // Builds one voice in `g`, returns the node producing the voice's signal and
@@ -70,6 +72,10 @@ struct VoiceChainBuilder {
         case KNH_STAGE_ONEPOLE_LPF: core = std::make_unique<OnePoleLpf<F>>(fnew<F>(a[0])); break;
         case KNH_STAGE_ONEPOLE_HPF: core = std::make_unique<OnePoleHpf<F>>(); break;
         case KNH_STAGE_PHASOR: core = std::make_unique<Phasor<F>>(a[0]); break;
+        case KNH_STAGE_BUFFER_READER:
+          if (!buffer) throw std::runtime_error("BufferReader stage without a buffer");
+          core = std::make_unique<BufferReader<F>>(buffer, a[0], a[1] != 0.0, a[2]);
+          break;
         case KNH_STAGE_POLYBLEP:
           core = std::make_unique<PolyBlep<F>>(waveform_from_pinteger(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u), fnew<F>(a[1]));
           break;
@@ -141,7 +147,7 @@ struct VoiceChainBuilder {
         math = std::make_unique<WrPreciseTiming<F>>(stages[s2 - 1].delayed_changes_per_block, std::move(math));
 
       const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC || st.kind == KNH_STAGE_PHASOR ||
-                             st.kind == KNH_STAGE_POLYBLEP;
+                             st.kind == KNH_STAGE_POLYBLEP || st.kind == KNH_STAGE_BUFFER_READER;
       const bool ar = st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ);
       NodeKey core_key = g.push(std::move(core));
       targets[s].node = core_key;
@@ -200,10 +206,12 @@ struct OracleBank {
     for (uint32_t v = 0; v < nv; ++v)
       for (uint32_t s = 0; s < n_stages; ++s) ctor[v][s].assign(static_cast<size_t>(std::max(0, stage_n_ctor_args(stages[s].kind))), 0.0);
   }
+  std::shared_ptr<Buffer<F>> buffer;
   void init(uint32_t sr, size_t bs) {
     sample_rate = sr;
     block_size = bs;
     VoiceChainBuilder<F> b(stages);
+    b.buffer = buffer;
     if (want_mix) {
       mix_graph = std::make_unique<Graph<F>>(0, out_channels, bs, sr);
       mix_targets.resize(n_voices);

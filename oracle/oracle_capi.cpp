@@ -14,6 +14,7 @@ struct BankBase {
   virtual ~BankBase() = default;
   virtual int set_ctor(uint32_t stage, uint32_t first, uint32_t count, const double* args, uint32_t n_args) = 0;
   virtual int init(uint32_t sr, size_t bs) = 0;
+  virtual int set_buffer(const void* samples, size_t n_frames, double sample_rate) = 0;
   virtual int param_apply(uint32_t voice, uint32_t stage, uint32_t param, ParameterValue v) = 0;
   virtual int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) = 0;
   virtual int schedule(uint32_t voice, uint32_t stage, uint32_t param, ParameterValue v, int mode, uint32_t s, uint32_t t) = 0;
@@ -36,6 +37,13 @@ struct BankImpl : BankBase {
       b.ctor[first + i][stage].assign(n_args, 0.0);
       for (uint32_t a = 0; a < n_args; ++a) b.ctor[first + i][stage][a] = args[static_cast<size_t>(i) * n_args + a];
     }
+    return KNH_OK;
+  }
+  int set_buffer(const void* samples, size_t n_frames, double sample_rate) override {
+    auto buf = std::make_shared<Buffer<F>>();
+    buf->buffer.assign(static_cast<const F*>(samples), static_cast<const F*>(samples) + n_frames);
+    buf->sample_rate = sample_rate;
+    b.buffer = buf;
     return KNH_OK;
   }
   int init(uint32_t sr, size_t bs) override {
@@ -110,6 +118,9 @@ void kno_bank_destroy(void* h) { delete static_cast<BankBase*>(h); }
 const char* kno_bank_last_error(void* h) { return static_cast<BankBase*>(h)->err.c_str(); }
 int kno_bank_set_ctor_args(void* h, uint32_t stage, uint32_t first, uint32_t count, const double* args, uint32_t n_args) {
   return static_cast<BankBase*>(h)->set_ctor(stage, first, count, args, n_args);
+}
+int kno_bank_set_buffer(void* h, const void* samples, size_t n_frames, double sample_rate) {
+  return static_cast<BankBase*>(h)->set_buffer(samples, n_frames, sample_rate);
 }
 int kno_bank_init(void* h, uint32_t sr, size_t bs) { return static_cast<BankBase*>(h)->init(sr, bs); }
 int kno_bank_param_apply(void* h, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i) {

@@ -53,6 +53,8 @@ def load() -> C.CDLL:
         lib.kno_bank_last_error.restype = C.c_char_p
         lib.kno_bank_last_error.argtypes = [vp]
         lib.kno_bank_set_ctor_args.argtypes = [vp, u32, u32, u32, vp, u32]
+        lib.kno_bank_set_buffer.argtypes = [vp, vp, C.c_size_t, C.c_double]
+        lib.kno_bank_set_buffer.restype = C.c_int
         lib.kno_bank_init.argtypes = [vp, u32, sz]
         lib.kno_bank_param_apply.argtypes = [vp, u32, u32, u32, u32, f64, i64]
         lib.kno_bank_set_delay_within_block_for_param.argtypes = [vp, u32, u32, u32, u16]
@@ -121,6 +123,10 @@ class OracleBank:
         if a.ndim == 1:
             a = a.reshape(-1, 1)
         self._check(self._lib.kno_bank_set_ctor_args(self._h, stage, first_voice, a.shape[0], a.ctypes.data_as(C.c_void_p), a.shape[1]))
+
+    def set_buffer(self, stage, samples, buffer_sample_rate):
+        a = np.ascontiguousarray(np.asarray(samples, dtype=self.dtype))
+        self._check(self._lib.kno_bank_set_buffer(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], float(buffer_sample_rate)))
 
     def init(self, sample_rate, block_size):
         self._check(self._lib.kno_bank_init(self._h, sample_rate, block_size))

@@ -11,6 +11,8 @@ def make_oracle(oracle, w: configs.Workload, want_mix=True, want_voices=True):
     b = oracle.OracleBank(w.stages, w.n_voices, w.sample_type, w.out_channels, want_mix, want_voices)
     for s, a in w.ctor.items():
         b.set_ctor_args(s, a)
+    if w.buffer is not None:
+        b.set_buffer(*w.buffer)
     b.init(configs.SAMPLE_RATE, w.block_size)
     return b
 
@@ -19,6 +21,8 @@ def make_gpu(knh, w: configs.Workload, mix_mode=L.MIX_TREE, allow_fma=False):
     b = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, mix_mode, -1, allow_fma)
     for s, a in w.ctor.items():
         b.set_ctor_args(s, a)
+    if w.buffer is not None:
+        b.set_buffer(*w.buffer)
     b.init(configs.SAMPLE_RATE, w.block_size)
     return b
 

@@ -552,3 +552,34 @@ def test_allpass_delay(knh, oracle, sample_type, kind):
             want = np.where(v % 2 == 0, (ring + 3.0) / 48000.0, delay_seconds(7))
             bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, want)
     run_pair(knh, oracle, w, 14, ev, L.MIX_LEFT_FOLD)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_buffer_reader_sampler_bank(knh, oracle, sample_type):
+    """BufferReader<F, U1> (buffer.rs:19-191) on one shared Buffer at another sample rate: per-voice rate, start and
+    length, looping and one-shot voices (done at the frame after the last one, then silence), every parameter."""
+    n, bs = 100, 64
+    v = np.arange(n, dtype=np.uint32)
+    rng = np.random.default_rng(3)
+    t = np.arange(3000) / 44100.0
+    samples = 0.5 * np.sin(2 * np.pi * 300.0 * t) + 0.3 * np.sin(2 * np.pi * 1234.5 * t) + 0.1 * rng.uniform(-1, 1, 3000)
+    w = configs.Workload("sampler", [Stage(L.STAGE_BUFFER_READER), Stage(L.STAGE_MUL_CONST)], n, bs, sample_type, 2)
+    rate = 0.25 + 0.03 * v
+    looping = (v % 3 == 0).astype(np.float64)
+    start = np.where(v % 4 == 0, 0.011 + 0.0001 * v, 0.0)
+    w.ctor = {0: np.stack([rate, looping, start], axis=1), 1: np.full((n, 1), 1.0 / n)}
+    w.buffer = (0, samples, 44100.0)
+
+    def ev(block, bank):
+        if block == 3:
+            bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, rate * 2.5)                 # rate
+            bank.param_apply_many(v[::2], 0, 3, L.VALUE_FLOAT, 0.004 + 0.0002 * v[::2])  # duration_s
+        if block == 5:
+            bank.param_apply_many(v, 0, 2, L.VALUE_FLOAT, 0.02 + 0.0001 * v)         # start_s
+            bank.param_apply_many(v, 0, 5, L.VALUE_TRIGGER)                           # t_restart
+        if block == 8:
+            bank.param_apply_many(v[1::2], 0, 4, L.VALUE_FLOAT, 0.05 + 0.0001 * v[1::2])  # end_s
+            bank.param_apply_many(v, 0, 1, L.VALUE_BOOL, ivalues=(v % 2).astype(np.int64))  # looping
+        if block == 10:
+            bank.param_apply_many(v, 0, 5, L.VALUE_TRIGGER)
+    run_pair(knh, oracle, w, 14, ev, L.MIX_LEFT_FOLD)
