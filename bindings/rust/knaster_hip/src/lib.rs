@@ -137,6 +137,13 @@ impl<F: Float> GpuVoiceBank<F> {
         Ok(Self { h, n_stages: stages.len(), n_voices, _f: PhantomData })
     }
 
+    /// `Buffer::from_vec(samples, sample_rate)` for the chain's `BufferReader` stage: one single-channel buffer shared
+    /// by every voice of the bank.  Before the bank is pushed (init runs at push time, graph.rs:462-475).
+    pub fn set_buffer(&mut self, stage: usize, samples: &[F], buffer_sample_rate: f64) -> Result<(), BankError> {
+        let rc = unsafe { knh_bank_set_buffer(self.h, stage as u32, samples.as_ptr() as *const c_void, samples.len(), buffer_sample_rate) };
+        if rc != KNH_OK { Err(last_error(self.h)) } else { Ok(()) }
+    }
+
     /// Flat parameter index of (`voice`, `stage`, parameter name), e.g. `"cutoff_freq"`, `"t_restart"`, `"wr_mul"`.
     pub fn index(&self, voice: u32, stage: usize, name: &str) -> Result<usize, BankError> {
         if voice >= self.n_voices || stage >= self.n_stages {
