@@ -370,6 +370,71 @@ static void gpu_segment_envelopes_of_ragged_length() {
   CHECK(worst <= 1e-5 && peak > 1e-3);
 }
 
+// The UGens added on the same skeleton, through the graph API: a band-limited oscillator into a Schroeder allpass
+// and a limiter, and a Phasor voice through a sample delay, against the same nodes in the reference-shaped graph.
+static void gpu_polyblep_delay_limiter_voices() {
+  const int B = 64, N = 50;
+  auto voices = c3_voices(N);
+  auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+  kno::Graph<float> ref(0, 2, B, 48000);
+  std::vector<Sig<float>::Parameter> delay_params;
+  std::vector<std::pair<kno::NodeKey, double>> ref_delays;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int i = 0; i < N; ++i) {
+      const auto& v = voices[i];
+      const double dly = 0.0005 + 0.00003 * i;
+      if (i % 2 == 0) {
+        const int wf = (i / 2) % 3 == 0 ? 0 : ((i / 2) % 3 == 1 ? 4 : 12);  // saw, square, fixed trapezoid: the exact ones
+        auto o = g.push(PolyBlep(wf, v.freq).wr_mul(3.0 * v.gain * N));
+        auto d = g.push(AllpassFeedbackDelay(0.004));
+        auto l = g.push(SafetyLimiter());
+        ((o >> d >> l) * (1.0 / N)).out({0, 0}).to_graph_out();
+        delay_params.push_back(d.param("delay_time"));
+        auto ro = ref.push(std::make_unique<kno::WrMath<float>>(
+            std::make_unique<kno::PolyBlep<float>>(kno::waveform_from_pinteger(wf), float(v.freq)), kno::WrOp::Mul, float(3.0 * v.gain * N)));
+        auto rd = ref.push(std::make_unique<kno::AllpassFeedbackDelay<float>>(kno::Seconds::from_secs_f64(0.004)));
+        auto rl = ref.push(std::make_unique<kno::SafetyLimiter<float>>());
+        ref.connect_to_node(ro, 0, 0, rd, false);
+        ref.connect_to_node(rd, 0, 0, rl, false);
+        auto m = ref.math_with_constant(rl, 0, kno::MathOp::Mul, float(1.0 / N));
+        ref.connect_to_output(m, 0, 0, true); ref.connect_to_output(m, 0, 1, true);
+        ref_delays.emplace_back(rd, dly);
+      } else {
+        auto o = g.push(Phasor(v.freq * 0.25));
+        auto d = g.push(SampleDelay(0.004));
+        ((o >> d) * v.gain).out({0, 0}).to_graph_out();
+        delay_params.push_back(d.param("delay_time"));
+        auto ro = ref.push(std::make_unique<kno::Phasor<float>>(v.freq * 0.25));
+        auto rd = ref.push(std::make_unique<kno::SampleDelay<float>>(kno::Seconds::from_secs_f64(0.004)));
+        ref.connect_to_node(ro, 0, 0, rd, false);
+        auto m = ref.math_with_constant(rd, 0, kno::MathOp::Mul, float(v.gain));
+        ref.connect_to_output(m, 0, 0, true); ref.connect_to_output(m, 0, 1, true);
+        ref_delays.emplace_back(rd, dly);
+      }
+    }
+  });
+  ref.commit_changes();
+  CHECK(graph->num_banks() == 2);
+  for (size_t i = 0; i < delay_params.size(); ++i) {
+    delay_params[i].set(ref_delays[i].second);
+    ref.set(ref_delays[i].first, 0, kno::ParameterValue::Flt(ref_delays[i].second));
+  }
+  std::vector<float> want(2 * B);
+  double worst = 0, peak = 0;
+  for (int block = 0; block < 8; ++block) {
+    processor->run_without_inputs();
+    ref.run({}, want.data());
+    auto out = processor->output_block();
+    for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < B; ++i) {
+        worst = std::max(worst, std::fabs(double(out.read(c, i)) - double(want[c * B + i])));
+        peak = std::max(peak, std::fabs(double(want[c * B + i])));
+      }
+  }
+  std::printf("  PolyBlep/allpass/limiter + Phasor/delay voices: max |gpu - reference-shaped graph| = %.3g (peak %.3g)\n", worst, peak);
+  CHECK(worst <= 1e-5 && peak > 1e-3);
+}
+
 int main(int argc, char** argv) {
   bool plan = false, gpu = false;
   for (int i = 1; i < argc; ++i) {
@@ -391,6 +456,7 @@ int main(int argc, char** argv) {
     RUN(gpu_run_blocks_equals_block_by_block);
     RUN(gpu_heterogeneous_voices_mix_on_device);
     RUN(gpu_segment_envelopes_of_ragged_length);
+    RUN(gpu_polyblep_delay_limiter_voices);
   }
   std::printf("%s (%d failures)\n", g_fail ? "HOST MIRROR FAILED" : "HOST MIRROR PASSED", g_fail);
   return g_fail ? 1 : 0;
