@@ -299,3 +299,47 @@ def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_vo
             if v0 is not None:
                 assert_bit_equal(v0, v1, f"per-voice, wide {other}")
                 assert f0 == f1 and np.array_equal(d0, d1)
+
+
+def test_long_run_stays_bit_exact(knh, oracle):
+    """A few seconds of audio: 240 blocks of the C3 chain in 16-block launches with notes restarting and releasing at
+    voice-dependent blocks and cutoff changes in between, every launch compared with the oracle's block-by-block run."""
+    n, bs, per_launch, launches = 192, 256, 16, 15
+    w = configs.config("C3", n_voices=n, block_size=bs)
+    g = make_gpu(knh, w)
+    o = make_oracle(oracle, w, want_mix=False)
+    v = np.arange(n, dtype=np.uint32)
+    p = configs.voice_parameters(n)
+    rng = np.random.default_rng(99)
+    for launch in range(launches):
+        per_block = []
+        for i in range(per_launch):
+            blk = launch * per_launch + i
+            ev = []
+            on = v[(v * 7 + blk) % 23 == 0]
+            off = v[(v * 5 + blk) % 31 == 0]
+            if len(on):
+                ev.append((on, w.restart[0], w.restart[1], L.VALUE_TRIGGER, None))
+            if len(off):
+                ev.append((off, w.release[0], w.release[1], L.VALUE_TRIGGER, None))
+            if blk % 9 == 4:
+                sel = v[rng.random(n) < 0.3]
+                if len(sel):
+                    ev.append((sel, 2, 0, L.VALUE_FLOAT, p["cutoff"][sel] * rng.uniform(0.5, 1.5, len(sel))))
+            per_block.append(ev)
+            for (sel, s, pi, kind, f) in ev:
+                g.param_apply_many(sel, s, pi, kind, f, block_offset=i)
+        got, _ = g.process_blocks(per_launch)
+        for i in range(per_launch):
+            for (sel, s, pi, kind, f) in per_block[i]:
+                o.param_apply_many(sel, s, pi, kind, f)
+            _, voices, _, _ = o.process_block()
+            want = voices.astype(np.float64).sum(axis=0)
+            tol = 1e-5 * max(1.0, float(np.abs(voices).max(axis=1).sum()))
+            assert np.max(np.abs(got[i, 0].astype(np.float64) - want)) <= tol, f"launch {launch} block {i}"
+    # and the state itself: one more single block, per voice, bit for bit
+    _, gv, _ = g.process_block_voices()
+    _, ov, _, _ = o.process_block()
+    assert_bit_equal(gv, ov, "per-voice signals after 240 blocks")
+    g.close()
+    o.close()
