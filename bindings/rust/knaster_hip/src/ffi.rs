@@ -113,6 +113,7 @@ unsafe extern "C" {
     pub fn knh_last_error(bank: *const knh_bank) -> *const c_char;
     pub fn knh_chain_ugen_count(stages: *const knh_stage_desc, n_stages: u32) -> i32;
     pub fn knh_bank_create(desc: *const knh_bank_desc, out_bank: *mut *mut knh_bank) -> i32;
+    pub fn knh_bank_create_sharded(desc: *const knh_bank_desc, host_threads: u32, out_bank: *mut *mut knh_bank) -> i32;
     pub fn knh_bank_set_ctor_args(bank: *mut knh_bank, stage: u32, first_voice: u32, count: u32, args: *const f64, n_args: u32) -> i32;
     pub fn knh_bank_set_buffer(bank: *mut knh_bank, stage: u32, samples: *const c_void, n_frames: usize, buffer_sample_rate: f64) -> i32;
     pub fn knh_bank_init(bank: *mut knh_bank, sample_rate: u32, block_size: usize) -> i32;

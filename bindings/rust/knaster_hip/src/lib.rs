@@ -111,6 +111,12 @@ impl<F: Float> GpuVoiceBank<F> {
     /// `ctor[stage]` = row-major `[n_voices][n_args]` constructor arguments (`SinWt::new(freq)` → `[freq]`,
     /// `SvfFilter::new(ty, cutoff, q, gain)` → `[ty as f64, cutoff, q, gain]`, ...; table in knaster_hip.h).
     pub fn new(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>]) -> Result<Self, BankError> {
+        Self::with_host_threads(stages, n_voices, ctor, 0)
+    }
+    /// The same bank with the host side of its sample-accurate parameter changes (the `WrPreciseTiming` queues of
+    /// every voice and the per-block event lists built from them) spread over `host_threads` threads; worth it when
+    /// every voice receives changes every block (`knh_bank_create_sharded` in knaster_hip.h).
+    pub fn with_host_threads(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>], host_threads: u32) -> Result<Self, BankError> {
         let desc = knh_bank_desc {
             abi_version: KNH_ABI_VERSION,
             n_voices,
@@ -123,7 +129,7 @@ impl<F: Float> GpuVoiceBank<F> {
             allow_fma: 0,
         };
         let mut h = core::ptr::null_mut();
-        if unsafe { knh_bank_create(&desc, &mut h) } != KNH_OK {
+        if unsafe { knh_bank_create_sharded(&desc, host_threads, &mut h) } != KNH_OK {
             return Err(last_error(core::ptr::null()));
         }
         for (s, args) in ctor.iter().enumerate() {

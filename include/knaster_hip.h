@@ -248,6 +248,16 @@ int32_t knh_chain_ugen_count(const knh_stage_desc* stages, uint32_t n_stages);
 /* Construction = the reference's `SomeUGen::new(args)` for every node of every
  * voice (osc.rs:110, svf.rs:64, envelopes.rs:33,187, util.rs:43).  */
 int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank);
+/* The same bank with its HOST work on `host_threads` threads.  WrPreciseTiming's change queues
+ * (precise_timing.rs:65-135) and the per-block assembly of the device event lists are per node, hence per
+ * voice: the bank is cut into up to `host_threads` contiguous ranges of whole 64-voice groups, a worker thread
+ * per range does that range's share of knh_bank_param_apply_many[_at] and of process, the ranges' kernels run
+ * side by side on their own streams, and their mixes are summed in range order on the caller's stream.  Every
+ * call keeps its meaning and stays single-caller.  Meant for banks whose voices all receive sample-accurate
+ * changes (BASELINE config C5), where one core assembling the lists is slower than the kernel.
+ * host_threads 0 or 1, KNH_MIX_LEFT_FOLD banks and banks of at most 64 voices: identical to knh_bank_create.
+ * The mix is a sum of per-range tree mixes: deterministic, within the tree mix's tolerance of the left fold. */
+int32_t knh_bank_create_sharded(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank);
 /* Constructor arguments of stage `stage` for `count` voices starting at
  * `first_voice`; `args` is [count][n_args] row-major, n_args as in the table
  * above.  Must be called before knh_bank_init; unset stages use zeros. */

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "knh_last_error": (C.c_char_p, [C.c_void_p]),
     "knh_chain_ugen_count": (C.c_int32, [C.POINTER(StageDesc), C.c_uint32]),
     "knh_bank_create": (C.c_int32, [C.POINTER(BankDesc), C.POINTER(C.c_void_p)]),
+    "knh_bank_create_sharded": (C.c_int32, [C.POINTER(BankDesc), C.c_uint32, C.POINTER(C.c_void_p)]),
     "knh_bank_set_ctor_args": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]),
     "knh_bank_set_buffer": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_double]),
     "knh_bank_init": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_size_t]),

@@ -39,7 +39,7 @@ def chain_ugen_count(stages: Sequence[Stage]) -> int:
 
 class VoiceBank:
     def __init__(self, stages: Sequence[Stage], n_voices: int, sample_type: int = L.F32, out_channels: int = 2,
-                 mix_mode: int = L.MIX_TREE, device: int = -1, allow_fma: bool = False):
+                 mix_mode: int = L.MIX_TREE, device: int = -1, allow_fma: bool = False, host_threads: int = 0):
         self._lib = L.load()
         self.stages = list(stages)
         self.n_voices = int(n_voices)
@@ -50,7 +50,10 @@ class VoiceBank:
         desc = L.BankDesc(L.KNH_ABI_VERSION, self.n_voices, sample_type, len(self.stages), self._stage_arr,
                           out_channels, mix_mode, device, 1 if allow_fma else 0)
         h = C.c_void_p()
-        rc = self._lib.knh_bank_create(C.byref(desc), C.byref(h))
+        if host_threads >= 2:  # host work (change queues, event lists) on several threads: knh_bank_create_sharded
+            rc = self._lib.knh_bank_create_sharded(C.byref(desc), int(host_threads), C.byref(h))
+        else:
+            rc = self._lib.knh_bank_create(C.byref(desc), C.byref(h))
         if rc != L.OK:
             raise L.KnasterHipError(rc, (self._lib.knh_last_error(None) or b"").decode())
         self._h = h
@@ -141,6 +144,12 @@ class VoiceBank:
         self._check(self._lib.knh_bank_set_delay_within_block_for_param(self._h, voice, stage, param, delay))
 
     def param_apply_many(self, voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None, block_offset=0):
+        self.param_apply_prepared(self.prepare_many(voices, stages, params, kinds, fvalues, ivalues, delays), block_offset)
+
+    @staticmethod
+    def prepare_many(voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None):
+        """The argument arrays of knh_bank_param_apply_many[_at] in the C layout, made once (a caller that sends the same
+        kind of batch every block keeps the result instead of converting numpy arrays on every call)."""
         v = np.ascontiguousarray(voices, dtype=np.uint32)
         n = v.shape[0]
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(stages, dtype=np.uint32), (n,)))
@@ -149,12 +158,15 @@ class VoiceBank:
         f = None if fvalues is None else np.ascontiguousarray(np.broadcast_to(np.asarray(fvalues, dtype=np.float64), (n,)))
         i = None if ivalues is None else np.ascontiguousarray(np.broadcast_to(np.asarray(ivalues, dtype=np.int64), (n,)))
         d = None if delays is None else np.ascontiguousarray(np.broadcast_to(np.asarray(delays, dtype=np.uint16), (n,)))
-        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        arrays = (v, s, p, k, f, i, d)
+        return n, arrays, tuple(None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrays)
+
+    def param_apply_prepared(self, batch, block_offset=0):
+        n, _arrays, ptrs = batch
         if block_offset:
-            self._check(self._lib.knh_bank_param_apply_many_at(self._h, block_offset, n, ptr(v), ptr(s), ptr(p), ptr(k), ptr(f),
-                                                               ptr(i), ptr(d)))
+            self._check(self._lib.knh_bank_param_apply_many_at(self._h, block_offset, n, *ptrs))
         else:
-            self._check(self._lib.knh_bank_param_apply_many(self._h, n, ptr(v), ptr(s), ptr(p), ptr(k), ptr(f), ptr(i), ptr(d)))
+            self._check(self._lib.knh_bank_param_apply_many(self._h, n, *ptrs))
 
     def process_block(self, frames_to_process: Optional[int] = None, block_start_offset: int = 0, frame_clock: int = 0,
                       out: Optional[np.ndarray] = None):

@@ -215,6 +215,21 @@ struct knh_bank {
                       int64_t i, uint16_t delay) = 0;
   virtual int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t clock, void* out_host, void* out_device,
                       void* voices_host, uint32_t* out_flags, void* stream, bool sync, bool accumulate = false) = 0;
+  // knh_bank_param_apply_many[_at]: the calls in array order (block_offset 0 = now); a host-sharded bank spreads them
+  // over its threads (host_shards.hpp)
+  virtual int apply_many(uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stgs, const uint32_t* params,
+                         const uint32_t* kinds, const double* fvalues, const int64_t* ivalues, const uint16_t* delays) {
+    int rc = KNH_OK;
+    for (size_t k = 0; k < count; ++k) {
+      if (delays && delays[k] > 0) {
+        int r = call_at(block_offset, true, voices[k], stgs[k], params[k], 0, 0.0, 0, delays[k]);
+        if (r != KNH_OK) { rc = r; continue; }
+      }
+      int r = call_at(block_offset, false, voices[k], stgs[k], params[k], kinds[k], fvalues ? fvalues[k] : 0.0, ivalues ? ivalues[k] : 0, 0);
+      if (r != KNH_OK) rc = r;
+    }
+    return rc;
+  }
   virtual int read_done_frames(uint32_t* out) = 0;
   virtual int synchronize() = 0;
   virtual int debug_read(uint32_t* out16) = 0;
@@ -1361,6 +1376,34 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
 
 }  // namespace
 
+#include "host_shards.hpp"
+
+namespace {
+// K host threads: the bank is cut into K voice ranges of whole 64-voice groups (fewer when there are fewer groups).
+template <typename F>
+knh_bank* make_sharded(const knh_bank_desc& d, const knh::KernelEntry* entry, const std::string& sig, uint32_t host_threads) {
+  const uint32_t groups = (d.n_voices + 63u) / 64u;
+  const uint32_t k = std::min(host_threads, groups);
+  const uint32_t per = ((groups + k - 1) / k) * 64u;
+  auto* b = new ShardedBank<F>();
+  b->desc = d;
+  b->nv = d.n_voices;
+  b->per_shard = per;
+  for (uint32_t v = 0; v < d.n_voices; v += per) {
+    knh_bank_desc dk = d;
+    dk.n_voices = std::min(per, d.n_voices - v);
+    b->base.push_back(v);
+    b->shard.emplace_back(make_bank<F>(dk, entry, sig));
+  }
+  b->base.push_back(d.n_voices);
+  b->stages = b->shard[0]->stages;
+  b->n_slots = b->shard[0]->n_slots;
+  b->n_params_total = b->shard[0]->n_params_total;
+  b->desc.stages = nullptr;
+  return b;
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------
 // extern "C" boundary
 // ---------------------------------------------------------------------------
@@ -1403,7 +1446,7 @@ int32_t knh_chain_ugen_count(const knh_stage_desc* stages, uint32_t n_stages) {
   return n;
 }
 
-int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank) {
+static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank) {
   if (out_bank) *out_bank = nullptr;
   if (!desc || !out_bank) { g_create_error = "null argument"; return KNH_ERR_INVALID_ARGUMENT; }
   if (desc->abi_version != KNH_ABI_VERSION) { g_create_error = "ABI version mismatch"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1411,13 +1454,29 @@ int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank) {
   if (desc->sample_type > KNH_F64) { g_create_error = "unknown sample type"; return KNH_ERR_INVALID_ARGUMENT; }
   if (desc->out_channels < 1 || desc->out_channels > 2) { g_create_error = "out_channels must be 1 or 2"; return KNH_ERR_INVALID_ARGUMENT; }
   if (desc->mix_mode > KNH_MIX_LEFT_FOLD) { g_create_error = "unknown mix mode"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (host_threads > 64) { g_create_error = "host_threads must be at most 64"; return KNH_ERR_INVALID_ARGUMENT; }
   std::string sig, why;
   int rc = build_signature(desc->stages, desc->n_stages, &sig, &why);
   if (rc != KNH_OK) { g_create_error = why; return rc; }
   // a chain without a pre-built kernel is fused at knh_bank_init time (hiprtc); entry == nullptr marks it
   const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
-  *out_bank = desc->sample_type == KNH_F64 ? make_bank<double>(*desc, entry, sig) : make_bank<float>(*desc, entry, sig);
+  // the reference's exact mix order (KNH_MIX_LEFT_FOLD) and banks of a single voice group keep one range
+  if (host_threads >= 2 && desc->mix_mode == KNH_MIX_TREE && desc->n_voices > 64)
+    *out_bank = desc->sample_type == KNH_F64 ? make_sharded<double>(*desc, entry, sig, host_threads) : make_sharded<float>(*desc, entry, sig, host_threads);
+  else
+    *out_bank = desc->sample_type == KNH_F64 ? make_bank<double>(*desc, entry, sig) : make_bank<float>(*desc, entry, sig);
   return KNH_OK;
+}
+
+int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank) {
+  // KNH_HOST_THREADS=K: every bank created through this entry point gets K host threads (A/B runs of existing programs)
+  const char* env = std::getenv("KNH_HOST_THREADS");
+  const long k = env ? std::strtol(env, nullptr, 10) : 0;
+  return create_bank(desc, k >= 2 && k <= 64 ? static_cast<uint32_t>(k) : 0u, out_bank);
+}
+
+int32_t knh_bank_create_sharded(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank) {
+  return create_bank(desc, host_threads, out_bank);
 }
 
 void knh_bank_destroy(knh_bank* bank) { delete bank; }
@@ -1456,16 +1515,7 @@ int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* 
                                   const uint32_t* kinds, const double* fvalues, const int64_t* ivalues, const uint16_t* delays) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
-  int rc = KNH_OK;
-  for (size_t k = 0; k < count; ++k) {
-    if (delays && delays[k] > 0) {
-      int r = bank->set_delay(voices[k], stages[k], params[k], delays[k]);
-      if (r != KNH_OK) { rc = r; continue; }
-    }
-    int r = bank->param_apply(voices[k], stages[k], params[k], kinds[k], fvalues ? fvalues[k] : 0.0, ivalues ? ivalues[k] : 0);
-    if (r != KNH_OK) rc = r;
-  }
-  return rc;
+  return bank->apply_many(0, count, voices, stages, params, kinds, fvalues, ivalues, delays);
 }
 int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, uint32_t* out_flags) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
@@ -1515,17 +1565,7 @@ int32_t knh_bank_param_apply_many_at(knh_bank* bank, uint32_t block_offset, size
                                      const uint16_t* delays) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
-  int rc = KNH_OK;
-  for (size_t k = 0; k < count; ++k) {
-    if (delays && delays[k] > 0) {
-      int r = bank->call_at(block_offset, true, voices[k], stages[k], params[k], 0, 0.0, 0, delays[k]);
-      if (r != KNH_OK) { rc = r; continue; }
-    }
-    int r = bank->call_at(block_offset, false, voices[k], stages[k], params[k], kinds[k], fvalues ? fvalues[k] : 0.0,
-                          ivalues ? ivalues[k] : 0, 0);
-    if (r != KNH_OK) rc = r;
-  }
-  return rc;
+  return bank->apply_many(block_offset, count, voices, stages, params, kinds, fvalues, ivalues, delays);
 }
 int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;

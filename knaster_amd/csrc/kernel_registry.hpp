@@ -53,4 +53,11 @@ hipError_t launch_fold_f32(bool tree, const float* rows, unsigned n_rows, unsign
 hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
                            unsigned frame_end, double* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate, hipStream_t s);
 
+// Host-sharded banks (host_shards.hpp): out[i] (+)= shards[0][i] + shards[1][i] + ... in shard order, for the frames
+// [frame_begin, frame_end) of every block of `block_size` frames; n = elements per shard, shard k starts at k * shard_stride.
+hipError_t launch_sum_shards_f32(const float* shards, unsigned n_shards, size_t shard_stride, size_t n, unsigned block_size,
+                                 unsigned frame_begin, unsigned frame_end, float* out, bool accumulate, hipStream_t s);
+hipError_t launch_sum_shards_f64(const double* shards, unsigned n_shards, size_t shard_stride, size_t n, unsigned block_size,
+                                 unsigned frame_begin, unsigned frame_end, double* out, bool accumulate, hipStream_t s);
+
 }  // namespace knh

@@ -166,4 +166,34 @@ hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsig
   return launch_fold<double>(tree, rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, n_blocks, accumulate, s);
 }
 
+
+template <typename F>
+__global__ void __launch_bounds__(256) sum_shards_kernel(const F* shards, unsigned n_shards, size_t shard_stride, size_t n,
+                                                         unsigned block_size, unsigned frame_begin, unsigned frame_end, F* out,
+                                                         unsigned accumulate) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const unsigned frame = (unsigned)(i % block_size);
+  if (frame < frame_begin || frame >= frame_end) return;
+  F acc = shards[i];
+  for (unsigned k = 1; k < n_shards; ++k) acc = acc + shards[k * shard_stride + i];
+  out[i] = accumulate ? out[i] + acc : acc;
+}
+template <typename F>
+static hipError_t launch_sum_shards(const F* shards, unsigned n_shards, size_t shard_stride, size_t n, unsigned block_size,
+                                    unsigned frame_begin, unsigned frame_end, F* out, bool accumulate, hipStream_t s) {
+  if (n == 0 || n_shards == 0 || frame_end <= frame_begin) return hipSuccess;
+  hipLaunchKernelGGL((sum_shards_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, shards, n_shards, shard_stride, n,
+                     block_size, frame_begin, frame_end, out, accumulate ? 1u : 0u);
+  return hipGetLastError();
+}
+hipError_t launch_sum_shards_f32(const float* shards, unsigned n_shards, size_t shard_stride, size_t n, unsigned block_size,
+                                 unsigned frame_begin, unsigned frame_end, float* out, bool accumulate, hipStream_t s) {
+  return launch_sum_shards<float>(shards, n_shards, shard_stride, n, block_size, frame_begin, frame_end, out, accumulate, s);
+}
+hipError_t launch_sum_shards_f64(const double* shards, unsigned n_shards, size_t shard_stride, size_t n, unsigned block_size,
+                                 unsigned frame_begin, unsigned frame_end, double* out, bool accumulate, hipStream_t s) {
+  return launch_sum_shards<double>(shards, n_shards, shard_stride, n, block_size, frame_begin, frame_end, out, accumulate, s);
+}
+
 }  // namespace knh

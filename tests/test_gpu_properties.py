@@ -343,3 +343,60 @@ def test_long_run_stays_bit_exact(knh, oracle):
     assert_bit_equal(gv, ov, "per-voice signals after 240 blocks")
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("name,n_voices,block_size,threads", [("C5", 1100, 128, 4), ("C5", 4096, 128, 8), ("C3", 700, 96, 3),
+                                                              ("C4", 300, 64, 2), ("C5", 100, 128, 5)])
+def test_host_sharded_bank_equals_single_bank(knh, name, n_voices, block_size, threads):
+    """knh_bank_create_sharded: K host threads, K voice ranges, K kernels -- every voice's samples, done frames and
+    flags are those of the one-range bank, the mix is the sum of the ranges' tree mixes (tolerance of the tree mix),
+    through the single-call and the batched entry points, one block or many per launch, whole and split blocks."""
+    w = configs.config(name, n_voices=n_voices, block_size=block_size)
+    tol = 2e-5 if w.sample_type == L.F32 else 1e-12
+
+    def script(block, bank, offset):
+        if name == "C5":
+            e = configs.c5_events(w, block)
+            if e is not None:
+                bank.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5], block_offset=offset)
+        else:
+            c3_script(w, block, bank, offset)
+    a = make_gpu(knh, w)
+    b = make_gpu(knh, w, host_threads=threads)
+    for block in range(5):
+        script(block, a, 0)
+        script(block, b, 0)
+        if block == 3:  # a block in two parts
+            half = block_size // 2
+            oa0, va0, _ = a.process_block_voices(half, 0)
+            oa1, va1, fa = a.process_block_voices(block_size - half, half)
+            ob0, vb0, _ = b.process_block_voices(half, 0)
+            ob1, vb1, fb = b.process_block_voices(block_size - half, half)
+            assert_bit_equal(vb0[:, :half], va0[:, :half], "first part")
+            assert_bit_equal(vb1[:, half:], va1[:, half:], "second part")
+            np.testing.assert_allclose(ob0[:, :half], oa0[:, :half], rtol=0, atol=tol * max(1.0, float(np.abs(oa0).max())))
+            np.testing.assert_allclose(ob1[:, half:], oa1[:, half:], rtol=0, atol=tol * max(1.0, float(np.abs(oa1).max())))
+        else:
+            oa, va, fa = a.process_block_voices()
+            ob, vb, fb = b.process_block_voices()
+            assert_bit_equal(vb, va, f"voices, block {block}")
+            np.testing.assert_allclose(ob, oa, rtol=0, atol=tol * max(1.0, float(np.abs(oa).max())))
+        assert fa == fb
+        assert np.array_equal(a.read_done_frames(), b.read_done_frames())
+    # several blocks per launch, changes addressed to later blocks, device-side output
+    n_blocks = 6
+    for k in range(n_blocks):
+        script(5 + k, a, k)
+        script(5 + k, b, k)
+    ma, fa = a.process_blocks(n_blocks)
+    mb, fb = b.process_blocks(n_blocks)
+    np.testing.assert_allclose(mb, ma, rtol=0, atol=tol * max(1.0, float(np.abs(ma).max())))
+    assert fa == fb
+    assert_bit_equal(b.process_block_voices()[1], a.process_block_voices()[1], "state after the launch")
+    # errors keep their codes
+    with pytest.raises(L.KnasterHipError) as e:
+        b.param_apply(n_voices, 0, 0, 1.0)
+    assert e.value.status == L.ERR_OUT_OF_RANGE
+    with pytest.raises(L.KnasterHipError) as e:
+        b.param_apply(n_voices - 1, 99, 0, 1.0)
+    assert e.value.status == L.ERR_OUT_OF_RANGE

@@ -13,9 +13,9 @@ import knaster_amd
 from knaster_amd import _lib as L, configs
 
 
-def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
+def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False, host_threads=0):
     w = configs.config(name, n_voices=n_voices)
-    b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE, -1, allow_fma)
+    b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE, -1, allow_fma, host_threads)
     for s, a in w.ctor.items():
         b.set_ctor_args(s, a)
     b.init(configs.SAMPLE_RATE, w.block_size)
@@ -26,14 +26,18 @@ def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
         b.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times)
     step = [0]
     # the application's own work of deciding what changes when is not the engine's: C5's event arrays are made up front
-    c5 = {blk: configs.c5_events(w, blk) for blk in range(blocks * (launches + 1))} if name == "C5" else {}
+    c5 = {}
+    if name == "C5":
+        for blk in range(blocks * (launches + 1)):
+            e = configs.c5_events(w, blk)
+            c5[blk] = None if e is None else b.prepare_many(e[0], e[1], e[2], e[3], e[4], None, e[5])
 
     def events(k):
         for i in range(k):
             if name == "C5":
                 e = c5[step[0] + i]
                 if e is not None:
-                    b.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5], block_offset=i)
+                    b.param_apply_prepared(e, block_offset=i)
             elif w.release and (step[0] + i) % 64 == 32:
                 b.param_apply_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER, block_offset=i)
             elif w.restart and (step[0] + i) % 64 == 0 and step[0] + i > 0:
@@ -59,13 +63,17 @@ def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False):
         rd += 4 * w.block_size
         wr += 4 * w.block_size
     print(json.dumps({"config": name, "voices": w.n_voices, "block_size": w.block_size, "sample_type": "f64" if w.sample_type else "f32",
-                      "ugens_per_voice": ugens, "allow_fma": allow_fma, "ugen_samples_per_s": work / dt,
+                      "ugens_per_voice": ugens, "allow_fma": allow_fma, "host_threads": max(1, host_threads), "ugen_samples_per_s": work / dt,
                       "kernel_only_ugen_samples_per_s": work / (kms * 1e-3), "us_per_block_kernel": kms * 1e3 / (n * blocks),
                       "hbm_algorithmic_GBps": (rd + wr) * w.n_voices * blocks * n / (kms * 1e-3) / 1e9}), flush=True)
     b.close()
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "c5":  # the host-bound config against the number of host threads
+        for k in (0, 2, 4, 8, 12):
+            run("C5", host_threads=k, launches=16)
+        sys.exit(0)
     run("C1")
     run("C2")
     run("C3")
@@ -75,6 +83,7 @@ if __name__ == "__main__":
     run("C4", n_voices=8192)
     run("C4")
     run("C5")
+    run("C5", host_threads=4)
     run("B3")
     run("D3")
     run("D3", n_voices=65536)
