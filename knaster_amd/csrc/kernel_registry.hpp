@@ -24,10 +24,11 @@ struct KernelEntry {
 struct PipeEntry {
   const char* signature;
   int n_groups;
+  bool big;  // 64-sample tiles (f64: 32), the last stage group folds (no mixer wavefront)
   VoiceLaunchFn<float> f32[2];
   VoiceLaunchFn<double> f64[2];
 };
-const PipeEntry* find_pipe(const char* signature);
+const PipeEntry* find_pipe(const char* signature, bool allow_big = true);
 // Five-role (dependence-cut) pipeline for source -> SVF -> x*envelope -> post chains, f32 banks (voice_dag.hpp).
 struct DagEntry {
   const char* signature;

@@ -46,15 +46,19 @@ static const KernelEntry kEntries[] = {
     KNH_CHAIN("BmSA", PolyBlepOsc, MulVal, Svf, MulAsr),         // the C3 voice with a band-limited oscillator
 };
 
-template <typename F, bool FMA, typename... Gs>
+// BIG: 64-sample tiles (32 for f64) with the fold done by the last stage group instead of a mixer wavefront
+template <typename F, bool FMA, bool BIG, typename... Gs>
 static hipError_t launch_pipe(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
   if (n_wavefronts == 0) return hipSuccess;
-  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, Gs...>), dim3(n_wavefronts), dim3((sizeof...(Gs) + 1) * 64), 0, stream, args);
+  constexpr int T = BIG ? PipeTile<F>::big : PipeTile<F>::value;
+  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, BIG, Gs...>), dim3(n_wavefronts), dim3((sizeof...(Gs) + (BIG ? 0 : 1)) * 64), 0, stream, args);
   return hipGetLastError();
 }
-#define KNH_PIPE(sig, n, ...)                                                             \
-  {sig, n, {launch_pipe<float, false, __VA_ARGS__>, launch_pipe<float, true, __VA_ARGS__>}, \
-   {launch_pipe<double, false, __VA_ARGS__>, launch_pipe<double, true, __VA_ARGS__>}}
+#define KNH_PIPE_AS(sig, n, big, ...)                                                               \
+  {sig, n, big, {launch_pipe<float, false, big, __VA_ARGS__>, launch_pipe<float, true, big, __VA_ARGS__>}, \
+   {launch_pipe<double, false, big, __VA_ARGS__>, launch_pipe<double, true, big, __VA_ARGS__>}}
+#define KNH_PIPE(sig, n, ...) KNH_PIPE_AS(sig, n, false, __VA_ARGS__)
+#define KNH_PIPE_BIG(sig, n, ...) KNH_PIPE_AS(sig, n, true, __VA_ARGS__)
 
 typedef Group<SinWt, MulVal> G_Wm;
 typedef Group<SinWt> G_W;
@@ -70,7 +74,8 @@ typedef Group<SampleDelay, MulAsr> G_DA;
 typedef Group<PolyBlepOsc, MulVal> G_Bm;
 
 static const PipeEntry kPipes[] = {
-    KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope (+ mixer wave)
+    KNH_PIPE_BIG("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope + fold, 64-sample tiles
+    KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),       // the same with 32-sample tiles and a mixer wavefront (KNH_PIPE_BIG=0)
     KNH_PIPE("WSAm", 3, G_W, G_S, G_Am),
     KNH_PIPE("WSA", 3, G_W, G_S, G_A),
     KNH_PIPE("WS", 2, G_W, G_S),
@@ -80,9 +85,9 @@ static const PipeEntry kPipes[] = {
     KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA),  // the delay's HBM traffic rides in the envelope wave
     KNH_PIPE("BmSA", 3, G_Bm, G_S, G_A),
 };
-const PipeEntry* find_pipe(const char* signature) {
+const PipeEntry* find_pipe(const char* signature, bool allow_big) {
   for (const PipeEntry& e : kPipes)
-    if (std::strcmp(e.signature, signature) == 0) return &e;
+    if (std::strcmp(e.signature, signature) == 0 && (allow_big || !e.big)) return &e;
   return nullptr;
 }
 

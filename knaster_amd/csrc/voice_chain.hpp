@@ -787,6 +787,25 @@ struct MulEnvT {
       const F step = isA ? r.ar : (isR ? -r.rr : (F)0);  // t - rr == t + (-rr) exactly
       const F scale = isR ? r.scale : konst;
       F t = moving ? r.t : konst;
+      {
+        // Most moving tiles are nowhere near a threshold: t after the tile, estimated in one step, is further from it
+        // than any T roundings could carry the real sequence (|error| < T * 2^-24 * 2 << 2^-10).  Those run here with
+        // no per-sample test and nothing kept but the running t; anything closer (or NaN) takes the exact code below.
+        const F reach = t + (F)(T + 1) * step;
+        const F margin = (F)0.0009765625;  // 2^-10
+        const bool maybe = isA ? !(reach < (F)1 - margin && t < (F)1 - margin) : (isR ? !(reach > margin && t > margin) : false);
+        if (__builtin_amdgcn_ballot_w64(maybe) == 0) {
+          if (anyR) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) { const F tj = t; t = t + step; x[j] = x[j] * ((tj * (tj * tj)) * scale); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) { const F tj = t; t = t + step; x[j] = x[j] * tj; }
+          }
+          if (moving) r.t = t;
+          return;
+        }
+      }
       F tt[T];
 #pragma unroll
       for (int j = 0; j < T; ++j) { tt[j] = t; t = t + step; }

@@ -27,13 +27,20 @@ template <typename F, bool FMA, int BASE, typename... S> struct GroupChain<F, FM
   typedef Chain<F, FMA, BASE, S...> type;
 };
 
-template <typename F> struct PipeTile { static constexpr int value = sizeof(F) == 4 ? 32 : 16; };  // samples per pipeline step
+// Samples per pipeline step.  `value`: three double-buffered edges + the mixer's beside the 64 KiB sine table.
+// `big`: twice that, for pipelines whose last stage group does the fold itself (FOLD, below) -- one edge buffer
+// fewer and no mixer wavefront, so the doubled tiles still fit the 160 KiB; the per-tile costs of the busiest wave
+// (LDS hand-over, block/event bookkeeping, the barrier) are then paid half as often.
+template <typename F> struct PipeTile {
+  static constexpr int value = sizeof(F) == 4 ? 32 : 16;
+  static constexpr int big = 2 * value;
+};
 
 // Edge tiles between stage groups: [edge][2 buffers][64 lanes][kEdgeStride] -- each lane's T samples are
 // contiguous and moved with 16-byte LDS accesses; the row padding (T + 16 B) keeps both ds_write_b128
 // (8-lane groups, 32 banks) and ds_read_b128 (16-lane groups, 64 banks) conflict-free.
-template <typename F> struct EdgeLayout {
-  static constexpr int T = PipeTile<F>::value;
+template <typename F, int TILE> struct EdgeLayout {
+  static constexpr int T = TILE;
   static constexpr int VW = 16 / (int)sizeof(F);          // elements per 16-byte access
   static constexpr int stride = T + VW;                   // elements per lane row
   static constexpr int tile = 64 * stride;                // elements per buffer
@@ -41,16 +48,18 @@ template <typename F> struct EdgeLayout {
 };
 template <typename F> struct PipeShared {
   float* sine;
-  F* edge;  // [NG][2][64][EdgeLayout<F>::stride]; edge i carries group i's output, the last one to the mixer
+  F* edge;  // [NG][2][64][stride]; edge i carries group i's output, the last one to the mixer (FOLD: one private buffer)
 };
 
 // One stage group = one wavefront.  I: group index, NG: number of chain groups (mixer excluded),
 // LAST_ENV: index of the group holding the chain's last envelope stage (-1: none).
-template <typename F, bool FMA, int NG, int I, int BASE, int LAST_ENV, typename G>
-__device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
+// FOLD: the last group also folds its tile over the voices (what pipe_run_mixer does in a wavefront of its own
+// otherwise): it stores the tile in a buffer no other wavefront touches and reads it back column-wise.
+template <typename F, bool FMA, int T, bool FOLD, int NG, int I, int BASE, int LAST_ENV, typename G>
+__device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv) {
   typedef typename GroupChain<F, FMA, BASE, G>::type ChainT;
   typedef typename WordOf<F>::type W;
-  constexpr int T = PipeTile<F>::value;
+  constexpr bool FOLDS = FOLD && I == NG - 1;
   constexpr u32 SLOT_LO = (u32)BASE, SLOT_HI = (u32)(BASE + GroupInfo<G>::slots);
 
   Ctx ctx;
@@ -89,7 +98,8 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   const u32 n_frames = a.frame_end - a.frame_begin;
   const int tpb = (int)((n_frames + T - 1) / T);           // tiles per block
   const int n_tiles = tpb * (int)a.n_blocks;
-  const int n_steps = n_tiles + NG;
+  const int n_steps = n_tiles + NG - (FOLD ? 1 : 0);
+  const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   int blk = 0, ti = 0;                                      // position of this group's next tile
 #ifdef KNH_DAG_STAMPS  // diagnostic build only: cycles this wavefront is busy per tile (tools/pipe_stamps.py)
   u64 busy = 0, busy_in = 0, busy_out = 0;
@@ -103,10 +113,10 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       // the tile's LDS reads go out first, so that their latency runs under the block/event bookkeeping below
       F x[T];
       if (I > 0) {
-        typedef typename EdgeLayout<F>::Vec Vec;
-        constexpr int VW = EdgeLayout<F>::VW;
-        const Vec* in = reinterpret_cast<const Vec*>(sh.edge + (long)((I - 1) * 2 + (g & 1)) * EdgeLayout<F>::tile +
-                                                     (long)lane * EdgeLayout<F>::stride);
+        typedef typename EdgeLayout<F, T>::Vec Vec;
+        constexpr int VW = EdgeLayout<F, T>::VW;
+        const Vec* in = reinterpret_cast<const Vec*>(sh.edge + (long)((I - 1) * 2 + (g & 1)) * EdgeLayout<F, T>::tile +
+                                                     (long)lane * EdgeLayout<F, T>::stride);
 #pragma unroll
         for (int j = 0; j < T / VW; ++j) {
           const Vec v = in[j];
@@ -122,33 +132,44 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
       apply_events_upto(base + n);
       const bool ev_inside = next_frame < base + n + T;
-#ifdef KNH_DAG_STAMPS
+#if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#ifdef KNH_DAG_STAMPS
       const u64 t1 = __builtin_amdgcn_s_memtime();
       busy_in += t1 - t0;
 #endif
-      if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev_inside)) {
-        chain.template tick_tile<T>(x, ctx, n);
-      } else {
-        for (u32 j = 0; j < m; ++j) {
-          apply_events_upto(base + n + j);
-          x[j] = chain.tick(x[j], ctx, n + j);
-        }
-      }
-      {  // every group, the last one included, hands its tile on as 64 rows of T samples (16-byte LDS stores)
-        typedef typename EdgeLayout<F>::Vec Vec;
-        constexpr int VW = EdgeLayout<F>::VW;
-        Vec* out = reinterpret_cast<Vec*>(sh.edge + (long)(I * 2 + (g & 1)) * EdgeLayout<F>::tile + (long)lane * EdgeLayout<F>::stride);
+      {  // every group, the last one included, hands its tile on as 64 rows of T samples
+        typedef typename EdgeLayout<F, T>::Vec Vec;
+        constexpr int VW = EdgeLayout<F, T>::VW;
+        F* out_tile = sh.edge + (long)(I * 2 + (FOLDS ? 0 : (g & 1))) * EdgeLayout<F, T>::tile;
+        F* out_row = out_tile + (long)lane * EdgeLayout<F, T>::stride;
+        if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev_inside)) {
+          chain.template tick_tile<T>(x, ctx, n);
+          Vec* out = reinterpret_cast<Vec*>(out_row);  // 16-byte LDS stores
 #pragma unroll
-        for (int j = 0; j < T / VW; ++j) {
-          Vec v;
+          for (int j = 0; j < T / VW; ++j) {
+            Vec v;
 #pragma unroll
-          for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
-          out[j] = v;
+            for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
+            out[j] = v;
+          }
+        } else {
+          // sample by sample, each sample straight from the input row to the output row in LDS: the register tile is
+          // never indexed by a run-time value (that would put all of it, the fast path's too, in scratch memory)
+          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride;
+          for (u32 j = 0; j < m; ++j) {
+            apply_events_upto(base + n + j);
+            const F v = I > 0 ? in_row[j] : (F)0;
+            out_row[j] = chain.tick(v, ctx, n + j);
+          }
         }
+        if constexpr (FOLDS) pipe_fold_tile<F, T>(out_tile, a, lane, wave_global, n_waves_total, blk, n, m, v0, nv);
       }
-#ifdef KNH_DAG_STAMPS
+#if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("" ::: "memory");
+#endif
+#ifdef KNH_DAG_STAMPS
       const u64 t2 = __builtin_amdgcn_s_memtime();
 #endif
       if (++ti == tpb) {  // block finished for this group
@@ -157,8 +178,10 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
         ++blk;
         base += a.block_size;
       }
-#ifdef KNH_DAG_STAMPS
+#if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#ifdef KNH_DAG_STAMPS
       const u64 t3 = __builtin_amdgcn_s_memtime();
       busy += t3 - t0;
       busy_out += t3 - t2;
@@ -183,15 +206,41 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   return done_frame;
 }
 
-// The mixer wavefront: lane j folds frame j of the tile the last chain group finished in the previous step over
-// the wave's voices, in voice order (a left fold, like the reference's chain of Add nodes over those voices).
-// The tile is stored voice-major ([voice][T], the common edge format), so a read of one voice's row by lanes
-// 0..T-1 is conflict-free and the transposition costs nothing.
-template <typename F, int NG>
+// Lane j folds frame j of a finished tile over the wave's voices, in voice order (a left fold, like the reference's
+// chain of Add nodes over those voices).  The tile is stored voice-major ([voice][T], the common edge format), so a
+// read of one voice's row by lanes 0..T-1 is conflict-free and the transposition costs nothing.
+template <typename F, int T>
+__device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 n_waves_total,
+                                               int blk, u32 n0, u32 len, u32 v0, u32 nv) {
+  constexpr int ST = EdgeLayout<F, T>::stride;
+  if ((u32)lane < len) {
+    const F* col = tile + lane;
+    F acc;
+    if (nv == 64u) {
+#pragma unroll
+      for (int vb = 0; vb < 64; vb += 16) {
+        F t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = col[(vb + k) * ST];
+        if (vb == 0) acc = t[0];
+#pragma unroll
+        for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
+      }
+    } else {
+      acc = col[0];
+      for (u32 v = 1; v < nv; ++v) acc = acc + col[v * ST];
+    }
+    a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
+    if (a.voices_out) {
+      for (u32 v = 0; v < nv; ++v) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = col[v * ST];
+    }
+  }
+}
+
+// The mixer wavefront: folds the tile the last chain group finished in the previous step.
+template <typename F, int T, int NG>
 __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global,
                                                u32 v0, u32 nv) {
-  constexpr int T = PipeTile<F>::value;
-  constexpr int ST = EdgeLayout<F>::stride;
   const u32 n_frames = a.frame_end - a.frame_begin;
   const int tpb = (int)((n_frames + T - 1) / T);
   const int n_tiles = tpb * (int)a.n_blocks;
@@ -209,30 +258,8 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
 #endif
       const u32 rel = (u32)ti * T;
       const u32 len = n_frames - rel < (u32)T ? n_frames - rel : (u32)T;
-      const u32 n0 = a.frame_begin + rel;
-      const F* tile = sh.edge + (long)((NG - 1) * 2 + (g & 1)) * EdgeLayout<F>::tile;
-      if ((u32)lane < len) {
-        const F* col = tile + lane;
-        F acc;
-        if (nv == 64u) {
-#pragma unroll
-          for (int vb = 0; vb < 64; vb += 16) {
-            F t[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = col[(vb + k) * ST];
-            if (vb == 0) acc = t[0];
-#pragma unroll
-            for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
-          }
-        } else {
-          acc = col[0];
-          for (u32 v = 1; v < nv; ++v) acc = acc + col[v * ST];
-        }
-        a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
-        if (a.voices_out) {
-          for (u32 v = 0; v < nv; ++v) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = col[v * ST];
-        }
-      }
+      const F* tile = sh.edge + (long)((NG - 1) * 2 + (g & 1)) * EdgeLayout<F, T>::tile;
+      pipe_fold_tile<F, T>(tile, a, lane, wave_global, n_waves_total, blk, a.frame_begin + rel, len, v0, nv);
       if (++ti == tpb) { ti = 0; ++blk; }
 #ifdef KNH_DAG_STAMPS
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -246,11 +273,11 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
 #endif
 }
 
-template <typename F, bool FMA, int NG, int I, int BASE, int LAST_ENV, typename G, typename... Rest>
-__device__ __forceinline__ u32 pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 v0, u32 nv) {
-  if (wave == I) return pipe_run_group<F, FMA, NG, I, BASE, LAST_ENV, G>(sh, a, lane, v0, nv);
+template <typename F, bool FMA, int T, bool FOLD, int NG, int I, int BASE, int LAST_ENV, typename G, typename... Rest>
+__device__ __forceinline__ u32 pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv) {
+  if (wave == I) return pipe_run_group<F, FMA, T, FOLD, NG, I, BASE, LAST_ENV, G>(sh, a, lane, wave_global, v0, nv);
   if constexpr (sizeof...(Rest) > 0)
-    return pipe_dispatch<F, FMA, NG, I + 1, BASE + GroupInfo<G>::slots, LAST_ENV, Rest...>(wave, sh, a, lane, v0, nv);
+    return pipe_dispatch<F, FMA, T, FOLD, NG, I + 1, BASE + GroupInfo<G>::slots, LAST_ENV, Rest...>(wave, sh, a, lane, wave_global, v0, nv);
   return 0xFFFFFFFFu;
 }
 
@@ -261,15 +288,16 @@ template <int I, typename G, typename... Rest> struct LastEnv<I, G, Rest...> {
   static constexpr int value = later >= 0 ? later : (GroupInfo<G>::has_env ? I : -1);
 };
 
-// One workgroup = 64 voices = (number of groups + 1) wavefronts.
-template <typename F, bool FMA, typename... Gs>
-__global__ void __launch_bounds__((sizeof...(Gs) + 1) * 64) voice_pipe_kernel(VoiceKernelArgs<F> a) {
+// One workgroup = 64 voices = (number of groups + 1) wavefronts, or (number of groups) with FOLD.
+template <typename F, bool FMA, int T, bool FOLD, typename... Gs>
+__global__ void __launch_bounds__((sizeof...(Gs) + (FOLD ? 0 : 1)) * 64) voice_pipe_kernel(VoiceKernelArgs<F> a) {
   constexpr int NG = (int)sizeof...(Gs);
-  constexpr int WAVES = NG + 1;
-  constexpr int T = PipeTile<F>::value;
+  constexpr int WAVES = NG + (FOLD ? 0 : 1);
+  static_assert(T <= 64 && T % 8 == 0, "a tile column per lane of the folding wavefront");
   constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
   __shared__ float sine[kSine ? 16384 : 1];
-  __shared__ __attribute__((aligned(16))) F edge[NG * 2 * EdgeLayout<F>::tile];  // the last edge feeds the mixer
+  // the last edge feeds the mixer; with FOLD it is one buffer private to the last group
+  __shared__ __attribute__((aligned(16))) F edge[(NG * 2 - (FOLD ? 1 : 0)) * EdgeLayout<F, T>::tile];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -291,8 +319,8 @@ __global__ void __launch_bounds__((sizeof...(Gs) + 1) * 64) voice_pipe_kernel(Vo
   const u32 v0 = wave_global * 64u;
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
   u32 done_frame = 0xFFFFFFFFu;
-  if (wave == NG) pipe_run_mixer<F, NG>(sh, a, lane, wave_global, v0, nv);
-  else done_frame = pipe_dispatch<F, FMA, NG, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, v0, nv);
+  if (wave == NG) pipe_run_mixer<F, T, NG>(sh, a, lane, wave_global, v0, nv);
+  else done_frame = pipe_dispatch<F, FMA, T, FOLD, NG, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
   // mark_done of a voice = that of the last node in task order that set one: combine the groups in chain order
   constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);
   if constexpr (kAnyEnv) {

@@ -76,11 +76,13 @@ def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pip
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C4", 300, 100), ("C5", 260, 128), ("C2", 200, 48),
                                                       ("D3", 500, 512), ("B3", 300, 256)])
 def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
-    """KNH_PIPELINE 0 = one wavefront per 64 voices, 1 = linear wave pipeline, 2 = five-role pipeline where built."""
+    """KNH_PIPELINE 0 = one wavefront per 64 voices, 1 = linear wave pipeline, 2 = five-role pipeline where built;
+    "1big" = the linear pipeline with 64-sample tiles and the fold in its last stage group (KNH_PIPE_BIG=1, where built)."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
     outs = {}
-    for pipeline in ("0", "1", "2"):
-        monkeypatch.setenv("KNH_PIPELINE", pipeline)
+    for pipeline in ("0", "1", "2", "1big"):
+        monkeypatch.setenv("KNH_PIPELINE", pipeline[0])
+        monkeypatch.setenv("KNH_PIPE_BIG", "1" if pipeline.endswith("big") else "0")
         g = make_gpu(knh, w)
         res = []
         for block in range(6):
@@ -94,7 +96,7 @@ def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_vo
             res.append((out, voices, flags, g.read_done_frames()))
         outs[pipeline] = res
         g.close()
-    for other in ("1", "2"):
+    for other in ("1", "2", "1big"):
         for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["0"], outs[other]):
             assert_bit_equal(v0, v1, f"per-voice, pipeline {other}")
             assert_bit_equal(o0, o1, f"mix, pipeline {other}")
