@@ -30,12 +30,13 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_OPS = 78.6e12        # 157.3 TFLOP/s FP32 vector counts an FMA as 2: 78.6e12 non-fused ops/s
 OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per voice-sample / 4 UGens
-# The filter wavefront of the C3 pipeline kernel executes ~400 instructions per 32-sample tile on its fast path (ISA of the
-# shipped kernel: 339 in the tile body, 320 of them VALU = 10 per sample, + ~60 of loop, event-cursor and LDS bookkeeping);
-# a wavefront alone on its SIMD issues one instruction of that scalar/packed mix per 2.45 ns
-# (tools/micro/valu_issue.hip, profiles/r01_micro_valu_issue.txt: "8-instr pk/scalar mix").
-SVF_WAVE_INSTRUCTIONS_PER_TILE = 400
-LONE_WAVE_ISSUE_NS = 2.45
+# The filter wavefront of the C3 pipeline kernel issues ten VALU instructions per sample (five of them packed); a wavefront
+# alone on its SIMD needs 44 shader-clock cycles for those ten (tools/micro/svf_chain.hip, profiles/r01_micro_svf_chain.txt),
+# 18.3 ns at the 2.4 GHz the chip holds under this load (tools/micro/clock_share.hip).  That is the floor of the kernel's
+# time per sample: the serial filter recurrence of one 64-voice group cannot be spread over more wavefronts.
+SVF_STEP_CYCLES = 44.0
+SHADER_CLOCK_GHZ = 2.4
+PIPE_TILE = 64                 # samples per pipeline step of the shipped C3 kernel (voice_pipe.hpp)
 REDUCE_EVERY = 64              # blocks per RCCL reduce
 
 
@@ -239,7 +240,7 @@ def main():
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes)" if traffic else None,
-                "kernel": "voice_pipe_kernel<float,false,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>",
+                "kernel": "voice_pipe_kernel<float,false,64,true,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>",
                 "kernel_avg_ms": kernel_avg_ms, "launches": launches, "blocks_per_launch": blocks_per_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "note": "fused kernel moves 92 B per voice per block; it is bound by the instruction issue of its busiest "
@@ -251,18 +252,19 @@ def main():
                 "ops_per_ugen_sample": OPS_PER_UGEN_SAMPLE, "kernel_only_ugen_samples_per_s": kernel_rate,
             },
             # What actually bounds this kernel at 16 384 voices (one 64-voice group per CU, one wavefront per SIMD): the
-            # filter wavefront's instruction stream.  Instruction count from the ISA of the shipped kernel, issue period of
-            # a wavefront alone on its SIMD from tools/micro/valu_issue.hip (profiles/r01_micro_valu_issue.txt).
+            # filter wavefront's instruction stream.
             "issue": {
                 "bound": "instruction issue of the busiest wavefront (SVF), one wavefront per SIMD",
-                "instructions_per_32_sample_tile": SVF_WAVE_INSTRUCTIONS_PER_TILE,
-                "tile_step_ns": kernel_avg_ms * 1e6 / (blocks_per_launch * (bs / 32.0)) if kernel_avg_ms > 0 else None,
-                "ns_per_instruction": kernel_avg_ms * 1e6 / (blocks_per_launch * (bs / 32.0)) / SVF_WAVE_INSTRUCTIONS_PER_TILE
-                if kernel_avg_ms > 0 and not args.allow_fma and bs % 32 == 0 else None,
-                "lone_wave_issue_period_ns_microbenchmark": LONE_WAVE_ISSUE_NS,
-                "note": "the whole tile step divided by the filter wavefront's instruction count, against the issue period of "
-                        "a wavefront alone on its SIMD measured in a separate short kernel (clock not pinned): at or below "
-                        "that period means this wavefront issues back to back for the entire step",
+                "filter_step_cycles_per_sample_alone": SVF_STEP_CYCLES,
+                "floor_ns_per_sample": SVF_STEP_CYCLES / SHADER_CLOCK_GHZ,
+                "kernel_ns_per_sample": kernel_avg_ms * 1e6 / (blocks_per_launch * bs) if kernel_avg_ms > 0 else None,
+                "frac": (SVF_STEP_CYCLES / SHADER_CLOCK_GHZ) / (kernel_avg_ms * 1e6 / (blocks_per_launch * bs))
+                if kernel_avg_ms > 0 and not args.allow_fma else None,
+                "tile_samples": PIPE_TILE,
+                "note": "floor = the ten instructions of one filter step issued by a wavefront alone on its SIMD (44 cycles, "
+                        "micro-benchmark) at 2.4 GHz; the rest of the kernel's time per sample is that wavefront's LDS hand-over, "
+                        "block/event bookkeeping and barrier once per 64-sample tile, and tiles in which the envelope "
+                        "wavefront (which also folds the voices) is the slower one",
             },
             "output_finite": sane,
             "host_output": None if host_rate is None else {

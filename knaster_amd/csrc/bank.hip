@@ -1340,11 +1340,11 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
     const char* env = std::getenv("KNH_PIPELINE");
     const int level = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : 1;
     b->pipeline_level = level;
-    // KNH_PIPE_BIG=1: the 64-sample-tile form with the fold in the last stage group, where one is built (kernels.hip);
-    // measured within +-2 % of the default on C3 (the envelope wave, now also folding, becomes the busiest one in
-    // release phases), so it stays opt-in
+    // The 64-sample-tile form with the fold in the last stage group is used where one is built (kernels.hip): measured
+    // 3 % faster than the 32-sample form over C3's note cycle, 12 % with every envelope at rest.  KNH_PIPE_BIG=0 keeps the
+    // 32-sample tiles and the mixer wavefront (A/B runs).
     const char* big_env = std::getenv("KNH_PIPE_BIG");
-    if (b->entry && level >= 1) b->pipe = knh::find_pipe(sig.c_str(), big_env && big_env[0] == '1');
+    if (b->entry && level >= 1) b->pipe = knh::find_pipe(sig.c_str(), !(big_env && big_env[0] == '0'));
     if (b->entry && level >= 2 && d.sample_type == KNH_F32) b->dag = knh::find_dag(sig.c_str());
     // Occupancy regime: the wave pipeline minimises latency when every 64-voice group can have a CU to
     // itself (<= ~1.5 groups per CU); beyond that throughput wins and the groups are packed 4 or 8 to a

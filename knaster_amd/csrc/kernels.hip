@@ -76,7 +76,9 @@ typedef Group<PolyBlepOsc, MulVal> G_Bm;
 static const PipeEntry kPipes[] = {
     KNH_PIPE_BIG("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope + fold, 64-sample tiles
     KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),       // the same with 32-sample tiles and a mixer wavefront (KNH_PIPE_BIG=0)
+    KNH_PIPE_BIG("WSAm", 3, G_W, G_S, G_Am),
     KNH_PIPE("WSAm", 3, G_W, G_S, G_Am),
+    KNH_PIPE_BIG("WSA", 3, G_W, G_S, G_A),
     KNH_PIPE("WSA", 3, G_W, G_S, G_A),
     KNH_PIPE("WS", 2, G_W, G_S),
     KNH_PIPE("WmaRm", 2, G_Wma, G_Rm),     // C5: modulator | carrier

@@ -764,6 +764,60 @@ struct MulEnvT {
 #pragma unroll
     for (int j = 0; j < T; ++j) e[j] = env_next<F>(r, frame0 + j, done_frame);
   }
+  // f32 tiles with Releasing lanes and no Attacking one: x[j] *= (t*(t*t))*scale, t += step, as hand-scheduled packed
+  // code -- per four samples four single adds (the running t, a chain that cannot be packed: each t is the rounded
+  // previous one plus step) and eight v_pk_mul_f32 on sample pairs, every packed result read two instructions later
+  // at the earliest.  Same roundings as the scalar expression.  CLAMP: each envelope value is max(value, 0) before
+  // it is used, which is what Releasing -> Stopped means for this sequence: t falls monotonically, a sample whose t
+  // is <= 0 lies after the stop (envelopes.rs:72-78) and its cube times a non-negative scale is <= 0.
+  // registers: v[120:121] / v[122:123] the two sample pairs' t (v120 carries the running t across blocks),
+  // v[124:127] their envelope values
+  template <int T, bool CLAMP>
+  static __device__ __forceinline__ void release_tile_packed(float (&x)[T], float& t_io, float step, float scale) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static_assert(T % 8 == 0, "blocks of eight samples");
+    const f2 sc = {scale, scale};
+    float t = t_io;
+#define KNH_REL_HALF(XA, XB)                                                  \
+      "v_add_f32 v121, v120, %[st]\n\t"                                       \
+      "v_add_f32 v122, v121, %[st]\n\t"                                       \
+      "v_add_f32 v123, v122, %[st]\n\t"                                       \
+      "v_pk_mul_f32 v[124:125], v[120:121], v[120:121]\n\t"                   \
+      "v_pk_mul_f32 v[126:127], v[122:123], v[122:123]\n\t"                   \
+      "v_pk_mul_f32 v[124:125], v[120:121], v[124:125]\n\t"                   \
+      "v_pk_mul_f32 v[126:127], v[122:123], v[126:127]\n\t"                   \
+      "v_add_f32 v120, v123, %[st]\n\t"                                       \
+      "v_pk_mul_f32 v[124:125], v[124:125], %[sc]\n\t"                        \
+      "v_pk_mul_f32 v[126:127], v[126:127], %[sc]\n\t"
+#define KNH_REL_CLAMP                                                         \
+      "v_max_f32 v124, 0, v124\n\t"                                           \
+      "v_max_f32 v125, 0, v125\n\t"                                           \
+      "v_max_f32 v126, 0, v126\n\t"                                           \
+      "v_max_f32 v127, 0, v127\n\t"
+#define KNH_REL_OUT(XA, XB)                                                   \
+      "v_pk_mul_f32 %[" #XA "], %[" #XA "], v[124:125]\n\t"                    \
+      "v_pk_mul_f32 %[" #XB "], %[" #XB "], v[126:127]\n\t"
+#pragma unroll
+    for (int j = 0; j < T; j += 8) {
+      f2 p0 = {x[j], x[j + 1]}, p1 = {x[j + 2], x[j + 3]}, p2 = {x[j + 4], x[j + 5]}, p3 = {x[j + 6], x[j + 7]};
+      if constexpr (CLAMP)
+        asm volatile(KNH_REL_HALF(p0, p1) KNH_REL_CLAMP KNH_REL_OUT(p0, p1) KNH_REL_HALF(p2, p3) KNH_REL_CLAMP KNH_REL_OUT(p2, p3) "s_nop 0"
+                     : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), "+{v120}"(t)
+                     : [st] "v"(step), [sc] "v"(sc)
+                     : "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+      else
+        asm volatile(KNH_REL_HALF(p0, p1) KNH_REL_OUT(p0, p1) KNH_REL_HALF(p2, p3) KNH_REL_OUT(p2, p3) "s_nop 0"
+                     : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), "+{v120}"(t)
+                     : [st] "v"(step), [sc] "v"(sc)
+                     : "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+      x[j] = p0.x; x[j + 1] = p0.y; x[j + 2] = p1.x; x[j + 3] = p1.y;
+      x[j + 4] = p2.x; x[j + 5] = p2.y; x[j + 6] = p3.x; x[j + 7] = p3.y;
+    }
+#undef KNH_REL_HALF
+#undef KNH_REL_CLAMP
+#undef KNH_REL_OUT
+    t_io = t;
+  }
   // x[j] *= envelope, T samples at once.  The tile is first run under the assumption that no lane changes state
   // inside it, as straight-line code with no per-sample select: in a tile without Releasing lanes every lane's
   // envelope is its t (lanes that are not Attacking hold t = 1 or 0 with step 0); in a tile without Attacking
@@ -787,6 +841,39 @@ struct MulEnvT {
       const F step = isA ? r.ar : (isR ? -r.rr : (F)0);  // t - rr == t + (-rr) exactly
       const F scale = isR ? r.scale : konst;
       F t = moving ? r.t : konst;
+#ifndef KNH_PACKED_RELEASE_MIN_TILE
+// Only the 64-sample tiles of the big pipeline form (voice_pipe.hpp), where the envelope wavefront also folds and is
+// the busiest one while notes release.  Measured on one box: 8-sample tiles (the many-wave kernels, two waves per SIMD,
+// where packed f32 runs at half rate) 43.4 -> 46.3 us per block at 65 536 voices with it; 32-sample tiles neutral on
+// C3 and 3 % slower on the delay chain (35.7 -> 36.8 us).
+#define KNH_PACKED_RELEASE_MIN_TILE 64
+#endif
+      if constexpr (sizeof(F) == 4 && T % 8 == 0 && T >= KNH_PACKED_RELEASE_MIN_TILE) {
+        // Releasing lanes, none Attacking (f32): one packed pass whatever happens in the tile.  The NaN and
+        // negative-scale cases (never produced by the setters) keep to the exact per-sample code further down.
+        const bool odd = isR && !(t == t && step == step && scale >= (F)0);
+        if (anyR && __builtin_amdgcn_ballot_w64(odd) == 0) {
+          const F t0 = t;
+          const F reach = t + (F)(T + 1) * step;
+          const bool near = isR && !(reach > (F)0.0009765625 && t > (F)0.0009765625);  // could a lane run out in this tile?
+          if (__builtin_amdgcn_ballot_w64(near) == 0) release_tile_packed<T, false>(x, t, step, scale);
+          else release_tile_packed<T, true>(x, t, step, scale);
+          const F t1 = t0 + step;
+          const bool hit = isR && (t1 <= (F)0 || t <= (F)0);
+          if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+            // mark_done's frame: the samples before the stop are those whose t is positive (the sequence again, adds only)
+            u32 alive = 0;
+            F tq = t0;
+#pragma unroll
+            for (int j = 0; j < T; ++j) { alive += !(tq <= (F)0) ? 1u : 0u; tq = tq + step; }
+            if (hit) { r.state = 0u; r.t = (F)0; done_frame = frame0 + alive - 1u - r.seg; }
+            else if (moving) r.t = t;
+          } else if (moving) {
+            r.t = t;
+          }
+          return;
+        }
+      }
       {
         // Most moving tiles are nowhere near a threshold: t after the tile, estimated in one step, is further from it
         // than any T roundings could carry the real sequence (|error| < T * 2^-24 * 2 << 2^-10).  Those run here with

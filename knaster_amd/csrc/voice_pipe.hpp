@@ -217,15 +217,14 @@ __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelA
     const F* col = tile + lane;
     F acc;
     if (nv == 64u) {
+      // all 64 reads go out before the first add: the LDS latency is paid once, not once per group of rows
+      // (the adds are one dependent chain whatever is done, in voice order)
+      F t[64];
 #pragma unroll
-      for (int vb = 0; vb < 64; vb += 16) {
-        F t[16];
+      for (int k = 0; k < 64; ++k) t[k] = col[k * ST];
+      acc = t[0];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t[k] = col[(vb + k) * ST];
-        if (vb == 0) acc = t[0];
-#pragma unroll
-        for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
-      }
+      for (int k = 1; k < 64; ++k) acc = acc + t[k];
     } else {
       acc = col[0];
       for (u32 v = 1; v < nv; ++v) acc = acc + col[v * ST];

@@ -70,6 +70,12 @@ def run(name, n_voices=None, launches=8, blocks=32, allow_fma=False, host_thread
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ab":  # the configs that run on kernels other than the headline one
+        run("C3", n_voices=65536)
+        run("C3", n_voices=262144, launches=4)
+        run("D3")
+        run("D3", n_voices=65536)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c5":  # the host-bound config against the number of host threads
         for k in (0, 2, 4, 8, 12):
             run("C5", host_threads=k, launches=16)
