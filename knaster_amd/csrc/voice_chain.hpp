@@ -764,80 +764,24 @@ struct MulEnvT {
 #pragma unroll
     for (int j = 0; j < T; ++j) e[j] = env_next<F>(r, frame0 + j, done_frame);
   }
-  // f32 tiles with Releasing lanes and no Attacking one: x[j] *= (t*(t*t))*scale, t += step, as hand-scheduled packed
-  // code, eight samples at a time: eight single adds (the running t, a chain that cannot be packed: each t is the
-  // rounded previous one plus step), then sixteen v_pk_mul_f32 on the four sample pairs, interleaved so that every
-  // packed result is read four instructions later (a wavefront alone on its SIMD has nothing else to hide the
-  // latency of a dependent packed instruction behind; the first version, two pairs at a time, ran at 25 cycles per
-  // sample, slower than the scalar code).  Same roundings as the scalar expression.  CLAMP: each envelope value is
-  // max(value, 0) before it is used, which is what Releasing -> Stopped means for this sequence: t falls
-  // monotonically, a sample whose t is <= 0 lies after the stop (envelopes.rs:72-78) and its cube times a
-  // non-negative scale is <= 0.  t_block[k] = t of the first sample after block k (for mark_done's frame).
-  // registers: v[120:127] the eight t (v120 carries the running t across blocks), v[128:135] the envelope values
-  template <int T, bool CLAMP>
-  static __device__ __forceinline__ void release_tile_packed(float (&x)[T], float& t_io, float step, float scale, float (&t_block)[T / 8]) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
+  // Tiles with Releasing lanes (none Attacking) in which a lane may run out: x[j] *= max((t*(t*t))*scale, 0), t += step,
+  // straight-line for every lane.  The clamp is what Releasing -> Stopped means for this sequence: t falls
+  // monotonically, a sample whose t is <= 0 lies after the stop (envelopes.rs:72-78) and its cube times a non-negative
+  // scale is <= 0.  t_block[k] = t of the first sample after the k-th block of eight (for mark_done's frame).
+  // (Two hand-scheduled packed versions of this loop were measured slower than what the compiler makes of it:
+  // 4 060 against 3 500 cycles per 64-sample tile for the envelope wave, tools/env_stamps.py.)
+  template <typename F, int T>
+  static __device__ __forceinline__ void release_tile_clamped(F (&x)[T], F& t_io, F step, F scale, F (&t_block)[T / 8]) {
     static_assert(T % 8 == 0, "blocks of eight samples");
-    const f2 sc = {scale, scale};
-    float t = t_io;
-#define KNH_REL_T                                                             \
-      "v_add_f32 v121, v120, %[st]\n\t"                                       \
-      "v_add_f32 v122, v121, %[st]\n\t"                                       \
-      "v_add_f32 v123, v122, %[st]\n\t"                                       \
-      "v_add_f32 v124, v123, %[st]\n\t"                                       \
-      "v_add_f32 v125, v124, %[st]\n\t"                                       \
-      "v_add_f32 v126, v125, %[st]\n\t"                                       \
-      "v_add_f32 v127, v126, %[st]\n\t"                                       \
-      "v_pk_mul_f32 v[128:129], v[120:121], v[120:121]\n\t"                   \
-      "v_pk_mul_f32 v[130:131], v[122:123], v[122:123]\n\t"                   \
-      "v_pk_mul_f32 v[132:133], v[124:125], v[124:125]\n\t"                   \
-      "v_pk_mul_f32 v[134:135], v[126:127], v[126:127]\n\t"                   \
-      "v_add_f32 %[te], v127, %[st]\n\t"                                      \
-      "v_pk_mul_f32 v[128:129], v[120:121], v[128:129]\n\t"                   \
-      "v_pk_mul_f32 v[130:131], v[122:123], v[130:131]\n\t"                   \
-      "v_pk_mul_f32 v[132:133], v[124:125], v[132:133]\n\t"                   \
-      "v_pk_mul_f32 v[134:135], v[126:127], v[134:135]\n\t"                   \
-      "v_mov_b32 v120, %[te]\n\t"                                             \
-      "v_pk_mul_f32 v[128:129], v[128:129], %[sc]\n\t"                        \
-      "v_pk_mul_f32 v[130:131], v[130:131], %[sc]\n\t"                        \
-      "v_pk_mul_f32 v[132:133], v[132:133], %[sc]\n\t"                        \
-      "v_pk_mul_f32 v[134:135], v[134:135], %[sc]\n\t"
-#define KNH_REL_CLAMP                                                         \
-      "v_max_f32 v128, 0, v128\n\t"                                           \
-      "v_max_f32 v129, 0, v129\n\t"                                           \
-      "v_max_f32 v130, 0, v130\n\t"                                           \
-      "v_max_f32 v131, 0, v131\n\t"                                           \
-      "v_max_f32 v132, 0, v132\n\t"                                           \
-      "v_max_f32 v133, 0, v133\n\t"                                           \
-      "v_max_f32 v134, 0, v134\n\t"                                           \
-      "v_max_f32 v135, 0, v135\n\t"
-#define KNH_REL_OUT                                                           \
-      "v_pk_mul_f32 %[p0], %[p0], v[128:129]\n\t"                             \
-      "v_pk_mul_f32 %[p1], %[p1], v[130:131]\n\t"                             \
-      "v_pk_mul_f32 %[p2], %[p2], v[132:133]\n\t"                             \
-      "v_pk_mul_f32 %[p3], %[p3], v[134:135]\n\t"                             \
-      "s_nop 0"
+    F t = t_io;
 #pragma unroll
-    for (int j = 0; j < T; j += 8) {
-      f2 p0 = {x[j], x[j + 1]}, p1 = {x[j + 2], x[j + 3]}, p2 = {x[j + 4], x[j + 5]}, p3 = {x[j + 6], x[j + 7]};
-      float te;
-      if constexpr (CLAMP)
-        asm volatile(KNH_REL_T KNH_REL_CLAMP KNH_REL_OUT
-                     : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [te] "=&v"(te), "+{v120}"(t)
-                     : [st] "v"(step), [sc] "v"(sc)
-                     : "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
-      else
-        asm volatile(KNH_REL_T KNH_REL_OUT
-                     : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [te] "=&v"(te), "+{v120}"(t)
-                     : [st] "v"(step), [sc] "v"(sc)
-                     : "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
-      t_block[j / 8] = te;
-      x[j] = p0.x; x[j + 1] = p0.y; x[j + 2] = p1.x; x[j + 3] = p1.y;
-      x[j + 4] = p2.x; x[j + 5] = p2.y; x[j + 6] = p3.x; x[j + 7] = p3.y;
+    for (int j = 0; j < T; ++j) {
+      const F tj = t;
+      t = t + step;
+      const F e = (tj * (tj * tj)) * scale;
+      x[j] = x[j] * (e > (F)0 ? e : (F)0);
+      if (j % 8 == 7) t_block[j / 8] = t;
     }
-#undef KNH_REL_T
-#undef KNH_REL_CLAMP
-#undef KNH_REL_OUT
     t_io = t;
   }
   // x[j] *= envelope, T samples at once.  The tile is first run under the assumption that no lane changes state
@@ -863,24 +807,19 @@ struct MulEnvT {
       const F step = isA ? r.ar : (isR ? -r.rr : (F)0);  // t - rr == t + (-rr) exactly
       const F scale = isR ? r.scale : konst;
       F t = moving ? r.t : konst;
-#ifndef KNH_PACKED_RELEASE_MIN_TILE
-// Only the 64-sample tiles of the big pipeline form (voice_pipe.hpp), where the envelope wavefront also folds and is
-// the busiest one while notes release.  Measured on one box: 8-sample tiles (the many-wave kernels, two waves per SIMD,
-// where packed f32 runs at half rate) 43.4 -> 46.3 us per block at 65 536 voices with it; 32-sample tiles neutral on
-// C3 and 3 % slower on the delay chain (35.7 -> 36.8 us).
-#define KNH_PACKED_RELEASE_MIN_TILE 64
+#ifndef KNH_CLAMPED_RELEASE_MIN_TILE
+#define KNH_CLAMPED_RELEASE_MIN_TILE 32  // the pipeline kernels' tiles; 8-sample tiles keep the code below
 #endif
-      if constexpr (sizeof(F) == 4 && T % 8 == 0 && T >= KNH_PACKED_RELEASE_MIN_TILE) {
-        // Releasing lanes, none Attacking (f32): one packed pass whatever happens in the tile.  The NaN and
-        // negative-scale cases (never produced by the setters) keep to the exact per-sample code further down.
+      if constexpr (T % 8 == 0 && T >= KNH_CLAMPED_RELEASE_MIN_TILE) {
+        // Releasing lanes, none Attacking, and some lane may run out inside the tile: one straight-line clamped pass.
+        // NaN and negative-scale cases (never produced by the setters) keep to the exact per-sample code further down.
         const bool odd = isR && !(t == t && step == step && scale >= (F)0);
-        if (anyR && __builtin_amdgcn_ballot_w64(odd) == 0) {
+        const F reach = t + (F)(T + 1) * step;
+        const bool near = isR && !(reach > (F)0.0009765625 && t > (F)0.0009765625);
+        if (anyR && __builtin_amdgcn_ballot_w64(odd) == 0 && __builtin_amdgcn_ballot_w64(near) != 0) {
           const F t0 = t;
-          const F reach = t + (F)(T + 1) * step;
-          const bool near = isR && !(reach > (F)0.0009765625 && t > (F)0.0009765625);  // could a lane run out in this tile?
-          float tb[T / 8];  // t of the first sample after each block of eight
-          if (__builtin_amdgcn_ballot_w64(near) == 0) release_tile_packed<T, false>(x, t, step, scale, tb);
-          else release_tile_packed<T, true>(x, t, step, scale, tb);
+          F tb[T / 8];  // t of the first sample after each block of eight
+          release_tile_clamped<F, T>(x, t, step, scale, tb);
           const F t1 = t0 + step;
           const bool hit = isR && (t1 <= (F)0 || t <= (F)0);
           if (__builtin_amdgcn_ballot_w64(hit) != 0) {
