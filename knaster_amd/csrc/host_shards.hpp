@@ -12,88 +12,9 @@
 // Only for KNH_MIX_TREE banks: the tree mix is already "deterministic, within 1e-5 of the left fold", and a sum of K
 // range mixes is one more such grouping; KNH_MIX_LEFT_FOLD (the reference's exact order) keeps one range.
 #pragma once
-#include <atomic>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <thread>
+#include "shard_workers.hpp"
 
 namespace {
-
-inline void cpu_relax() {
-#if defined(__x86_64__)
-  asm volatile("pause");
-#endif
-}
-
-// K-1 persistent workers; run(fn) executes fn(0) on the caller and fn(1..K-1) on the workers, and returns when all are done.
-// Workers spin briefly for the next job (back-to-back batched calls arrive microseconds apart) before they sleep.
-class ShardWorkers {
- public:
-  explicit ShardWorkers(int n) : n_(n) {
-    for (int k = 1; k < n; ++k) threads_.emplace_back([this, k] { loop(k); });
-  }
-  ~ShardWorkers() {
-    {
-      std::lock_guard<std::mutex> l(m_);
-      stop_ = true;
-      epoch_.fetch_add(1, std::memory_order_release);
-    }
-    cv_job_.notify_all();
-    for (std::thread& t : threads_) t.join();
-  }
-  void run(const std::function<void(int)>& fn) {
-    if (n_ > 1) {
-      {
-        std::lock_guard<std::mutex> l(m_);
-        job_ = &fn;
-        remaining_.store(n_ - 1, std::memory_order_relaxed);
-        epoch_.fetch_add(1, std::memory_order_release);
-      }
-      cv_job_.notify_all();
-    }
-    fn(0);
-    if (n_ > 1) {
-      for (int spin = 0; spin < 20000 && remaining_.load(std::memory_order_acquire) != 0; ++spin) cpu_relax();
-      if (remaining_.load(std::memory_order_acquire) != 0) {
-        std::unique_lock<std::mutex> l(m_);
-        cv_done_.wait(l, [this] { return remaining_.load(std::memory_order_acquire) == 0; });
-      }
-    }
-  }
-
- private:
-  void loop(int k) {
-    uint64_t seen = 0;
-    while (true) {
-      for (int spin = 0; spin < 20000 && epoch_.load(std::memory_order_acquire) == seen; ++spin) cpu_relax();
-      if (epoch_.load(std::memory_order_acquire) == seen) {
-        std::unique_lock<std::mutex> l(m_);
-        cv_job_.wait(l, [&] { return epoch_.load(std::memory_order_acquire) != seen; });
-      }
-      seen = epoch_.load(std::memory_order_acquire);
-      const std::function<void(int)>* job;
-      {
-        std::lock_guard<std::mutex> l(m_);
-        if (stop_) return;
-        job = job_;
-      }
-      (*job)(k);
-      if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-        std::lock_guard<std::mutex> l(m_);
-        cv_done_.notify_one();
-      }
-    }
-  }
-  int n_;
-  std::vector<std::thread> threads_;
-  std::mutex m_;
-  std::condition_variable cv_job_, cv_done_;
-  const std::function<void(int)>* job_ = nullptr;
-  std::atomic<uint64_t> epoch_{0};
-  std::atomic<int> remaining_{0};
-  bool stop_ = false;
-};
 
 template <typename F>
 struct ShardedBank final : knh_bank {

@@ -30,3 +30,13 @@ def test_graph_api_end_to_end_on_gpu(knh):
     for name in ("gpu_readme_example", "gpu_voice_graph_matches_reference_shaped_graph", "gpu_run_blocks_equals_block_by_block",
                  "gpu_heterogeneous_voices_mix_on_device"):
         assert f"ok   {name}" in res.stdout
+
+
+def test_shard_worker_pool_plain_and_under_thread_sanitizer():
+    """knaster_amd/csrc/shard_workers.hpp (the threads of knh_bank_create_sharded) has no HIP in it: run it on the CPU,
+    once as built for the library and once under ThreadSanitizer."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-C", cpp, "bin/shard_workers_test", "bin/shard_workers_test_tsan"], check=True, capture_output=True)
+    for name in ("shard_workers_test", "shard_workers_test_tsan"):
+        res = subprocess.run([os.path.join(cpp, "bin", name)], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and "ok   shard_workers" in res.stdout, name + ":\n" + res.stdout + res.stderr
