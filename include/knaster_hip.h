@@ -126,6 +126,13 @@ typedef enum knh_value_kind {
  *     full-wave rectified sine, triangular pulse, fixed and variable trapezoid (the reference's Waveform order; any other
  *     value is Sawtooth).  params: 0 freq, 1 pulse_width, 2 waveform(integer).  Bit-exact except where the reference
  *     calls sin/cos (waveforms 1, 2, 9, 10, and every waveform at or above sample_rate / 4): device libm there.
+ * KNH_STAGE_WHITE_NOISE     g.push(WhiteNoise::new())   noise.rs:26-47     1    seed
+ * KNH_STAGE_PINK_NOISE      g.push(PinkNoise::new())    noise.rs:49-111    1    seed
+ * KNH_STAGE_BROWN_NOISE     g.push(BrownNoise::new())   noise.rs:119-156   1    seed
+ *     sources; no parameters.  seed = the value the UGen's constructor got from next_randomness_seed()
+ *     (noise.rs:11-22: a process-wide counter, 0, 1, 2, ... in construction order).  The generator is the
+ *     `fastrand` crate's (2.3.0, not vendored with the reference): restated from its published algorithm, parity
+ *     unpinned.
  * KNH_STAGE_SAFETY_LIMITER  x >> g.push(SafetyLimiter::new())   dynamics.rs:9-31     1    (none)
  *     clamp to [-1, 1], NaN -> 0; no parameters, no state
  *     WrMul: params: 0 = the reference's "wr_mul" (index T::Parameters of the
@@ -162,7 +169,10 @@ typedef enum knh_stage_kind {
   KNH_STAGE_ALLPASS_DELAY = 25,
   KNH_STAGE_ALLPASS_FB_DELAY = 26,
   KNH_STAGE_BUFFER_READER = 27,
-  KNH_STAGE_KIND_COUNT = 28
+  KNH_STAGE_WHITE_NOISE = 28,
+  KNH_STAGE_PINK_NOISE = 29,
+  KNH_STAGE_BROWN_NOISE = 30,
+  KNH_STAGE_KIND_COUNT = 31
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

@@ -66,6 +66,9 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* ALLPASS_DLY */ {7, 1, 1, 1, 'Y', {"delay_time"}},
     /* ALLPASS_FB  */ {8, 2, 1, 1, 'Z', {"delay_time", "feedback"}},
     /* BUFFER_READ */ {10, 6, 3, 1, 'F', {"rate", "looping", "start_s", "duration_s", "end_s", "t_restart"}},
+    /* WHITE_NOISE */ {2, 0, 1, 1, 'U', {nullptr}},
+    /* PINK_NOISE  */ {14, 0, 1, 1, 'K', {nullptr}},
+    /* BROWN_NOISE */ {3, 0, 1, 1, 'O', {nullptr}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -77,7 +80,7 @@ inline int stage_cost(char c) {
   switch (c) {
     case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
     case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
-    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'X': return 4; case 'B': return 45; case 'Y': return 14; case 'Z': return 18; case 'F': return 16;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'U': return 14; case 'O': return 19; case 'K': return 50; case 'X': return 4; case 'B': return 45; case 'Y': return 14; case 'Z': return 18; case 'F': return 16;
     default: return 1;
   }
 }
@@ -553,6 +556,17 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 3, v) = static_cast<W>(static_cast<uint32_t>(sb >> 32));
           } break;
           case KNH_STAGE_SAFETY_LIMITER: break;
+          case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: {
+            // fastrand::Rng::with_seed(next_randomness_seed()) (noise.rs:34,66,134): the state is the seed
+            const uint64_t seed = a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u;
+            slot(S.slot_base + 0, v) = static_cast<W>(static_cast<uint32_t>(seed));
+            slot(S.slot_base + 1, v) = static_cast<W>(static_cast<uint32_t>(seed >> 32));
+            if (S.kind == KNH_STAGE_BROWN_NOISE) slot(S.slot_base + 2, v) = to_bits(F(0));
+            if (S.kind == KNH_STAGE_PINK_NOISE) {  // noise.rs:64-75: counter 1, everything else zero
+              slot(S.slot_base + 2, v) = 1u;
+              for (int k = 3; k < 14; ++k) slot(S.slot_base + k, v) = to_bits(F(0));
+            }
+          } break;
           case KNH_STAGE_POLYBLEP: {  // polyblep.rs:136-153: new(waveform, freq), init -> set_freq: dt = freq / sample_rate
             const F srf = static_cast<F>(sr);  // F::from(sample_rate)
             const F freq = static_cast<F>(a[1]);
@@ -1306,6 +1320,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
   for (uint32_t i = 0; i < n; ++i) {
     if (st[i].kind >= KNH_STAGE_KIND_COUNT) { *why = "unknown stage kind"; return KNH_ERR_INVALID_ARGUMENT; }
     const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC || st[i].kind == KNH_STAGE_PHASOR ||
+                        st[i].kind == KNH_STAGE_WHITE_NOISE || st[i].kind == KNH_STAGE_PINK_NOISE || st[i].kind == KNH_STAGE_BROWN_NOISE ||
                         st[i].kind == KNH_STAGE_POLYBLEP || st[i].kind == KNH_STAGE_BUFFER_READER;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1607,6 +1622,9 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
       case KNH_STAGE_SAMPLE_DELAY: w += word; break;
       case KNH_STAGE_PHASOR: w += word * 2; break;
+      case KNH_STAGE_WHITE_NOISE: w += word * 2; break;
+      case KNH_STAGE_PINK_NOISE: w += word * 14; break;
+      case KNH_STAGE_BROWN_NOISE: w += word * 3; break;
       case KNH_STAGE_POLYBLEP: w += word; break;
       case KNH_STAGE_BUFFER_READER: w += word * 3; break;  // + two Buffer samples read per frame
       case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)

@@ -176,6 +176,161 @@ struct Phasor {
   }
 };
 
+// WhiteNoise / PinkNoise / BrownNoise -- knaster_core_dsp/src/ugens/noise.rs:26-156.  Sources.  Their random numbers come
+// from the `fastrand` crate (Cargo.lock: 2.3.0), which is not vendored in the reference tree: restated here from its
+// published algorithm (PARITY UNPINNED): Rng(seed) is a u64; every draw does
+//   s += 0x2d358dccaa6c78a5;  t = (u128)s * (s ^ 0x8bb84b93962eacc9);  r = lo64(t) ^ hi64(t)
+// (wyrand, final v4.2 constants); u32() takes the low 32 bits; f32() = from_bits(0x3F800000 + (u32() >> 9)) - 1.0.
+// The reference seeds each UGen with next_randomness_seed() (a process-wide counter, noise.rs:11-22): the constructor
+// argument.  Every sample is `F::new(rng.f32() * 2.0 - 1.0)`: f32 arithmetic, then the cast.
+struct NoiseRng {
+  u64 s;
+  __device__ __forceinline__ float f32() {
+    s += 0x2d358dccaa6c78a5ull;
+    const u64 b = s ^ 0x8bb84b93962eacc9ull;
+    const u64 lo = s * b;
+    const u64 hi = __umul64hi(s, b);
+    const u32 r = (u32)(lo ^ hi);
+    return __builtin_bit_cast(float, 0x3F800000u + (r >> 9)) - 1.0f;
+  }
+  __device__ __forceinline__ float bipolar() { return f32() * 2.0f - 1.0f; }
+  template <typename W> __device__ __forceinline__ void load(const W* st, long stride) {
+    s = (u64)(u32)st[0] | ((u64)(u32)st[stride] << 32);
+  }
+  template <typename W> __device__ __forceinline__ void store(W* st, long stride) const {
+    st[0] = (W)(u32)s;
+    st[stride] = (W)(u32)(s >> 32);
+  }
+  __device__ __forceinline__ void patch(u32 rel, u32 w) {
+    s = rel == 0 ? ((s & 0xFFFFFFFF00000000ull) | (u64)w) : ((s & 0x00000000FFFFFFFFull) | ((u64)w << 32));
+  }
+};
+// slots: 0,1 rng state (low, high word)
+struct WhiteNoise {
+  static constexpr int kSlots = 2;
+  static constexpr u32 kMutableMask = 0b11u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs { NoiseRng rng; };
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) { r.rng.load(s, st); }
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) { r.rng.store(s, st); }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) { return (F)r.rng.bipolar(); }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) == EV_SET) r.rng.patch(rel, (u32)bits);
+  }
+};
+// BrownNoise -- noise.rs:119-156: last += white * 0.1; clamp to [-1, 1].  slots: 0,1 rng  2 last_output
+struct BrownNoise {
+  static constexpr int kSlots = 3;
+  static constexpr u32 kMutableMask = 0b111u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs { NoiseRng rng; F last; };
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.rng.load(s, st);
+    r.last = word_to_f<F>(s[2 * st]);
+  }
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    r.rng.store(s, st);
+    s[2 * st] = f_to_word(r.last);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
+    const F white = (F)r.rng.bipolar();
+    F v = r.last + white * (F)0.1;  // F::new(0.1): the f64 literal cast to F
+    // f32::clamp / f64::clamp: NaN stays NaN
+    v = v < (F)-1 ? (F)-1 : v;
+    v = v > (F)1 ? (F)1 : v;
+    r.last = v;
+    return v;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    if (rel < 2) r.rng.patch(rel, (u32)bits);
+    else r.last = word_to_f<F>((typename WordOf<F>::type)bits);
+  }
+};
+// PinkNoise -- noise.rs:49-111 (Voss-McCartney, nine octaves).  slots: 0,1 rng  2 counter  3 pink  4 always_on
+// 5..13 white_noises[0..8].  The nine rows live in registers; the row to replace (counter.trailing_zeros()) is picked
+// with selects, not with an indexed access.
+struct PinkNoise {
+  static constexpr int kSlots = 14;
+  static constexpr u32 kMutableMask = 0x3FFFu;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs { NoiseRng rng; u32 counter; F pink, always_on, white[9]; };
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.rng.load(s, st);
+    r.counter = (u32)s[2 * st];
+    r.pink = word_to_f<F>(s[3 * st]);
+    r.always_on = word_to_f<F>(s[4 * st]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.white[k] = word_to_f<F>(s[(long)(5 + k) * st]);
+  }
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    r.rng.store(s, st);
+    s[2 * st] = (W)r.counter;
+    s[3 * st] = f_to_word(r.pink);
+    s[4 * st] = f_to_word(r.always_on);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[(long)(5 + k) * st] = f_to_word(r.white[k]);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
+    const u32 index = (u32)__builtin_ctz(r.counter);  // counter is in 1..=256: index 0..8
+    F old = (F)0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) old = index == (u32)k ? r.white[k] : old;
+    r.pink -= old;
+    const F fresh = (F)r.rng.bipolar();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.white[k] = index == (u32)k ? fresh : r.white[k];
+    r.pink += fresh;
+    r.pink -= r.always_on;
+    r.always_on = (F)r.rng.bipolar();
+    r.pink += r.always_on;
+    r.counter = (r.counter & 255u) + 1u;  // counter &= mask - 1; counter += 1   (mask = 2^8)
+    return r.pink / (F)10;                 // / (PINK_NOISE_OCTAVES + 1)
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    const F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel < 2) r.rng.patch(rel, (u32)bits);
+    else if (rel == 2) r.counter = (u32)bits;
+    else if (rel == 3) r.pink = v;
+    else if (rel == 4) r.always_on = v;
+    else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) r.white[k] = rel == (u32)(5 + k) ? v : r.white[k];
+    }
+  }
+};
+
 // SafetyLimiter -- dynamics.rs:9-31: clamp to [-1, 1] (a NaN passes the clamp), then NaN -> 0.  No state.
 struct SafetyLimiter {
   static constexpr int kSlots = 0;

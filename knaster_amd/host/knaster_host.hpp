@@ -20,6 +20,7 @@
 // the CPU; that is outside this engine).  Header-only; needs libknaster_hip.so.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -114,6 +115,15 @@ inline UGenSpec SinNumeric(double freq) { return UGenSpec(KNH_STAGE_SIN_NUMERIC,
 inline UGenSpec PolyBlep(int waveform, double freq) { return UGenSpec(KNH_STAGE_POLYBLEP, {static_cast<double>(waveform), freq}); }
 inline UGenSpec Phasor(double freq) { return UGenSpec(KNH_STAGE_PHASOR, {freq}); }        // osc.rs:172-214
 inline UGenSpec SafetyLimiter() { return UGenSpec(KNH_STAGE_SAFETY_LIMITER, {}); }        // dynamics.rs:9-31
+// noise.rs:11-22: every randomness UGen takes its seed from one process-wide counter, in construction order, so a
+// graph built in the same order makes the same noise.  WhiteNoise / PinkNoise / BrownNoise::new() -- noise.rs:33,65,133
+inline uint64_t next_randomness_seed() {
+  static std::atomic<uint64_t> next{0};
+  return next.fetch_add(1, std::memory_order_seq_cst);
+}
+inline UGenSpec WhiteNoise() { return UGenSpec(KNH_STAGE_WHITE_NOISE, {static_cast<double>(next_randomness_seed())}); }
+inline UGenSpec PinkNoise() { return UGenSpec(KNH_STAGE_PINK_NOISE, {static_cast<double>(next_randomness_seed())}); }
+inline UGenSpec BrownNoise() { return UGenSpec(KNH_STAGE_BROWN_NOISE, {static_cast<double>(next_randomness_seed())}); }
 inline UGenSpec SvfFilter(SvfFilterType ty, double cutoff, double q, double gain_db) {
   return UGenSpec(KNH_STAGE_SVF, {static_cast<double>(ty), cutoff, q, gain_db});
 }
@@ -245,7 +255,7 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
   switch (kind) {
     case KNH_STAGE_PHASOR: *n = 1; return frq;
     case KNH_STAGE_POLYBLEP: { static const char* pb[] = {"freq", "pulse_width", "waveform"}; *n = 3; return pb; }
-    case KNH_STAGE_SAFETY_LIMITER: *n = 0; return frq;
+    case KNH_STAGE_SAFETY_LIMITER: case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: *n = 0; return frq;
     case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_ALLPASS_DELAY: *n = 1; return dly;
     case KNH_STAGE_ALLPASS_FB_DELAY: { static const char* fbd[] = {"delay_time", "feedback"}; *n = 2; return fbd; }
     case KNH_STAGE_MUL_ENVELOPE: *n = 4; return seg;
@@ -329,7 +339,8 @@ class Graph {
     const UGenSpec& s = n.spec;
     if (s.is_env || s.is_constant) throw GraphError("an envelope/constant must be an operand of * + - /");
     const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR || s.kind == KNH_STAGE_POLYBLEP ||
-                        s.kind == KNH_STAGE_BUFFER_READER;
+                        s.kind == KNH_STAGE_BUFFER_READER || s.kind == KNH_STAGE_WHITE_NOISE || s.kind == KNH_STAGE_PINK_NOISE ||
+                        s.kind == KNH_STAGE_BROWN_NOISE;
     uint16_t flags = 0;
     if (source) {
       if (n.link_source >= 0) {

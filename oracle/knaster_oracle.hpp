@@ -1184,6 +1184,90 @@ struct PolyBlep : UGen<F> {
 };
 
 // ---------------------------------------------------------------------------
+// WhiteNoise / PinkNoise / BrownNoise -- knaster_core_dsp/src/ugens/noise.rs:26-156
+//
+// PARITY UNPINNED.  The random numbers come from the `fastrand` crate (Cargo.lock:937-940: version 2.3.0), which is a
+// crates.io dependency and not in the reference tree, and the reference has no test or golden vector for these UGens.
+// FastRng restates fastrand 2.3.0's published algorithm: `Rng::with_seed(seed)` = `Rng(seed)` (a u64); `gen_u64`:
+//   s = state.wrapping_add(0x2d35_8dcc_aa6c_78a5); state = s; t = (s as u128) * ((s ^ 0x8bb8_4b93_962e_acc9) as u128);
+//   (t as u64) ^ (t >> 64) as u64                              (wyrand with the final v4.2 constants)
+// `u32(..)` over the full range = `gen_u64() as u32`; `f32()` = f32::from_bits((1 << 30) - (1 << 23) + (u32(..) >> 9)) - 1.0.
+// What IS anchored on the reference: the call sites -- one `rng.f32() * 2.0 - 1.0` (f32 arithmetic) per draw, cast with
+// F::new, the order of draws inside PinkNoise::process, the seed = next_randomness_seed() (a process-wide counter
+// from 0, noise.rs:11-22; here the constructor argument).
+// ---------------------------------------------------------------------------
+struct FastRng {
+  uint64_t state;
+  explicit FastRng(uint64_t seed) : state(seed) {}
+  uint64_t gen_u64() {
+    const uint64_t s = state + 0x2d358dccaa6c78a5ull;
+    state = s;
+    const unsigned __int128 t = static_cast<unsigned __int128>(s) * static_cast<unsigned __int128>(s ^ 0x8bb84b93962eacc9ull);
+    return static_cast<uint64_t>(t) ^ static_cast<uint64_t>(t >> 64);
+  }
+  uint32_t u32() { return static_cast<uint32_t>(gen_u64()); }
+  float f32() {
+    const uint32_t bits = (1u << 30) - (1u << 23) + (u32() >> 9);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f - 1.0f;
+  }
+};
+template <typename F>
+struct WhiteNoise : UGen<F> {
+  FastRng rng;
+  explicit WhiteNoise(uint64_t seed) : rng(seed) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 0; }
+  void param_apply(AudioCtx&, size_t, ParameterValue) override {}  // no parameters
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override { out[0] = fnew<F>(rng.f32() * 2.0f - 1.0f); }
+};
+template <typename F>
+struct PinkNoise : UGen<F> {  // noise.rs:49-111
+  static constexpr uint32_t kOctaves = 9;
+  F white_noises[kOctaves] = {}, always_on_white_noise = F(0), pink = F(0);
+  uint32_t counter = 1, mask = 1u << (kOctaves - 1);
+  FastRng rng;
+  explicit PinkNoise(uint64_t seed) : rng(seed) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 0; }
+  void param_apply(AudioCtx&, size_t, ParameterValue) override {}  // no parameters
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override {
+    if (!(counter > 0 && counter <= mask)) throw std::runtime_error("PinkNoise: counter out of range");  // the asserts
+    const uint32_t index = static_cast<uint32_t>(__builtin_ctz(counter));
+    if (index >= kOctaves) throw std::runtime_error("PinkNoise: index out of range");
+    pink -= white_noises[index];
+    white_noises[index] = fnew<F>(rng.f32() * 2.0f - 1.0f);
+    pink += white_noises[index];
+    pink -= always_on_white_noise;
+    always_on_white_noise = fnew<F>(rng.f32() * 2.0f - 1.0f);
+    pink += always_on_white_noise;
+    counter &= mask - 1;
+    counter += 1;
+    out[0] = pink / (F(kOctaves) + F(1));
+  }
+};
+template <typename F>
+struct BrownNoise : UGen<F> {  // noise.rs:119-156
+  FastRng rng;
+  F last_output = F(0);
+  explicit BrownNoise(uint64_t seed) : rng(seed) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 0; }
+  void param_apply(AudioCtx&, size_t, ParameterValue) override {}  // no parameters
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override {
+    const F white = fnew<F>(rng.f32() * 2.0f - 1.0f);
+    last_output += white * fnew<F>(0.1);  // F::new(0.1): the f64 literal cast to F
+    if (last_output < F(-1)) last_output = F(-1);  // clamp: NaN stays
+    if (last_output > F(1)) last_output = F(1);
+    out[0] = last_output;
+  }
+};
+
+// ---------------------------------------------------------------------------
 // Phasor -- knaster_core_dsp/src/ugens/osc.rs:172-214;  SafetyLimiter -- ugens/dynamics.rs:9-31
 // ---------------------------------------------------------------------------
 template <typename F>

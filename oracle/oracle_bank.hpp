@@ -28,6 +28,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_SAFETY_LIMITER: return 0;
     case KNH_STAGE_POLYBLEP: return 2;
     case KNH_STAGE_BUFFER_READER: return 3;
+    case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: return 1;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -72,6 +73,9 @@ struct VoiceChainBuilder {
         case KNH_STAGE_ONEPOLE_LPF: core = std::make_unique<OnePoleLpf<F>>(fnew<F>(a[0])); break;
         case KNH_STAGE_ONEPOLE_HPF: core = std::make_unique<OnePoleHpf<F>>(); break;
         case KNH_STAGE_PHASOR: core = std::make_unique<Phasor<F>>(a[0]); break;
+        case KNH_STAGE_WHITE_NOISE: core = std::make_unique<WhiteNoise<F>>(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u); break;
+        case KNH_STAGE_PINK_NOISE: core = std::make_unique<PinkNoise<F>>(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u); break;
+        case KNH_STAGE_BROWN_NOISE: core = std::make_unique<BrownNoise<F>>(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u); break;
         case KNH_STAGE_BUFFER_READER:
           if (!buffer) throw std::runtime_error("BufferReader stage without a buffer");
           core = std::make_unique<BufferReader<F>>(buffer, a[0], a[1] != 0.0, a[2]);
@@ -147,7 +151,8 @@ struct VoiceChainBuilder {
         math = std::make_unique<WrPreciseTiming<F>>(stages[s2 - 1].delayed_changes_per_block, std::move(math));
 
       const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC || st.kind == KNH_STAGE_PHASOR ||
-                             st.kind == KNH_STAGE_POLYBLEP || st.kind == KNH_STAGE_BUFFER_READER;
+                             st.kind == KNH_STAGE_POLYBLEP || st.kind == KNH_STAGE_BUFFER_READER ||
+                             st.kind == KNH_STAGE_WHITE_NOISE || st.kind == KNH_STAGE_PINK_NOISE || st.kind == KNH_STAGE_BROWN_NOISE;
       const bool ar = st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ);
       NodeKey core_key = g.push(std::move(core));
       targets[s].node = core_key;

@@ -79,6 +79,29 @@ static void plan_groups_voices_by_chain_shape() {
   CHECK(b2.size() == 5 && b2[3].kind == KNH_STAGE_SIN_WT && (b2[3].flags & KNH_STAGE_FLAG_AR_FREQ) && b2[3].delayed_changes_per_block == 4);
   CHECK(b2[1].kind == KNH_STAGE_MUL_CONST && b2[2].kind == KNH_STAGE_ADD_CONST && b2[4].kind == KNH_STAGE_MUL_CONST);
 }
+// noise.rs:11-22: WhiteNoise / PinkNoise / BrownNoise::new() draw their seeds from one process-wide counter, in
+// construction order; the mirror hands that seed to the bank as the stage's constructor argument.
+static void plan_noise_sources_take_seeds_in_construction_order() {
+  auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
+  (void)processor;
+  graph->plan_only = true;
+  const uint64_t first = next_randomness_seed() + 1;
+  graph->edit([&](GraphEdit<float>& g) {
+    (g.push(WhiteNoise()) * 0.1).out({0, 0}).to_graph_out();
+    (g.push(PinkNoise()) * 0.1).out({0, 0}).to_graph_out();
+    auto b = g.push(BrownNoise().wr_mul(0.5));
+    auto f = g.push(OnePoleLpf(800.));
+    (b >> f).out({0, 0}).to_graph_out();
+    (g.push(WhiteNoise()) * 0.2).out({0, 0}).to_graph_out();  // a second voice of the first bank
+  });
+  CHECK(graph->num_banks() == 3);
+  CHECK(graph->bank(0).n_voices == 2 && graph->bank(0).plan.stages[0].kind == KNH_STAGE_WHITE_NOISE);
+  CHECK(graph->bank(1).plan.stages[0].kind == KNH_STAGE_PINK_NOISE && graph->bank(2).plan.stages[0].kind == KNH_STAGE_BROWN_NOISE);
+  CHECK(graph->bank(0).plan.stage_args[0].size() == 1 && graph->bank(0).plan.stage_args[0][0] == double(first));
+  CHECK(graph->bank(1).plan.stage_args[0][0] == double(first + 1));
+  CHECK(graph->bank(2).plan.stage_args[0][0] == double(first + 2));
+  CHECK(next_randomness_seed() == first + 4);
+}
 static void plan_rejects_what_is_not_a_voice_chain() {
   auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
   (void)processor;
@@ -446,6 +469,7 @@ int main(int argc, char** argv) {
   if (plan) {
     RUN(plan_readme_example);
     RUN(plan_groups_voices_by_chain_shape);
+    RUN(plan_noise_sources_take_seeds_in_construction_order);
     RUN(plan_rejects_what_is_not_a_voice_chain);
     RUN(time_and_seconds);
   }

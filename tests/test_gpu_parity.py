@@ -583,3 +583,27 @@ def test_buffer_reader_sampler_bank(knh, oracle, sample_type):
         if block == 10:
             bank.param_apply_many(v, 0, 5, L.VALUE_TRIGGER)
     run_pair(knh, oracle, w, 14, ev, L.MIX_LEFT_FOLD)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+@pytest.mark.parametrize("kind", [L.STAGE_WHITE_NOISE, L.STAGE_PINK_NOISE, L.STAGE_BROWN_NOISE])
+def test_noise_sources(knh, oracle, kind, sample_type):
+    """WhiteNoise / PinkNoise / BrownNoise (noise.rs:26-156), one generator per voice seeded the way the reference's
+    process-wide counter would (0, 1, 2, ...), through a filter and an envelope (a run-time fused pipeline), block after
+    block: the integer generator and the f32 arithmetic around it are bit-identical to the oracle's restatement.
+    (What that restatement is worth against the real `fastrand` crate: parity unpinned)"""
+    n, bs = 200, 96
+    v = np.arange(n, dtype=np.uint32)
+    p = configs.voice_parameters(n)
+    w = configs.Workload("noise", [Stage(kind), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_SVF), Stage(L.STAGE_MUL_ENV_ASR)], n, bs, sample_type, 2)
+    seeds = np.where(v % 50 == 49, 2.0 ** 40 + v, v).astype(np.float64)  # small counters, and a few seeds above 2^32
+    w.ctor = {0: seeds.reshape(n, 1), 1: np.full((n, 1), 1.0 / n),
+              2: np.stack([np.zeros(n), p["cutoff"], p["q"], np.zeros(n)], axis=1),
+              3: np.stack([p["attack"], p["release"]], axis=1)}
+
+    def ev(block, bank):
+        if block == 0:
+            bank.param_apply_many(v, 3, 3, L.VALUE_TRIGGER)
+        if block == 4:
+            bank.param_apply_many(v[::2], 3, 2, L.VALUE_TRIGGER, delays=(v[::2] % bs).astype(np.uint16))
+    run_pair(knh, oracle, w, 7, ev, L.MIX_TREE)

@@ -68,7 +68,11 @@ def random_chain(seed):
     st = L.F64 if seed % 4 == 3 else L.F32
     p = configs.voice_parameters(n)
     src = L.STAGE_PHASOR if seed % 5 == 4 else (L.STAGE_POLYBLEP if seed % 5 == 3 else L.STAGE_SIN_WT)
+    if seed % 10 == 2:
+        src = [L.STAGE_WHITE_NOISE, L.STAGE_PINK_NOISE, L.STAGE_BROWN_NOISE][(seed // 10) % 3]
     src_args = ctor_for(L.STAGE_SIN_WT, n, rng, p)  # a frequency per voice
+    if src in (L.STAGE_WHITE_NOISE, L.STAGE_PINK_NOISE, L.STAGE_BROWN_NOISE):
+        src_args = (1000.0 * seed + np.arange(n)).reshape(n, 1)  # a seed per voice
     if src == L.STAGE_POLYBLEP:  # waveforms without sin: those are bit-exact
         wf = rng.choice([0, 3, 4, 5, 6, 7, 8, 11, 12, 13], n).astype(np.float64)
         src_args = np.stack([wf, src_args[:, 0]], axis=1)

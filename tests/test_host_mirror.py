@@ -18,7 +18,8 @@ def test_graph_api_plans_voice_banks(knh):
     _build(knh)
     res = subprocess.run([BIN, "--plan"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
-    for name in ("plan_readme_example", "plan_groups_voices_by_chain_shape", "plan_rejects_what_is_not_a_voice_chain", "time_and_seconds"):
+    for name in ("plan_readme_example", "plan_groups_voices_by_chain_shape", "plan_rejects_what_is_not_a_voice_chain", "time_and_seconds",
+                 "plan_noise_sources_take_seeds_in_construction_order"):
         assert f"ok   {name}" in res.stdout
 
 

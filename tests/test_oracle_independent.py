@@ -275,3 +275,60 @@ def test_segment_envelope_against_closed_form(oracle):
         got.append(b.process_block()[1][0].copy())
     assert np.array_equal(np.concatenate(got), np.array(env))
     assert done_at is not None
+
+
+def test_noise_generator_is_the_stated_wyrand(oracle):
+    """The oracle's FastRng against the algorithm its header states, in Python integers: s += 0x2d358dccaa6c78a5,
+    r = lo64(s * (s ^ 0x8bb84b93962eacc9)) ^ hi64(...), f32 = from_bits(0x3F800000 + (r as u32 >> 9)) - 1, sample =
+    f32 * 2 - 1 -- and a few sanity properties of the three noise colours.  This pins the restatement to what it says
+    it is; whether that is byte for byte the `fastrand` 2.3.0 the reference links stays unpinned (no crate source,
+    no golden vector)."""
+    from knaster_amd import _lib as L
+    from knaster_amd.bank import Stage
+    n, bs, blocks = 5, 64, 40
+    seeds = np.array([0, 1, 2, 12345, 2 ** 40 + 7], dtype=np.float64)
+
+    def run(kind, st=L.F32):
+        b = oracle.OracleBank([Stage(kind)], n, st, 1, True, True)
+        b.set_ctor_args(0, seeds.reshape(n, 1))
+        b.init(48000, bs)
+        return np.concatenate([b.process_block()[1] for _ in range(blocks)], axis=1)
+
+    def wyrand_f32(seed, count):
+        M = (1 << 64) - 1
+        s, out = int(seed), []
+        for _ in range(count):
+            s = (s + 0x2D358DCCAA6C78A5) & M
+            t = s * (s ^ 0x8BB84B93962EACC9)
+            r = ((t & M) ^ (t >> 64)) & 0xFFFFFFFF
+            f = np.array([0x3F800000 + (r >> 9)], dtype=np.uint32).view(np.float32)[0] - np.float32(1.0)
+            out.append(np.float32(f * np.float32(2.0) - np.float32(1.0)))
+        return np.array(out, dtype=np.float32)
+
+    white = run(L.STAGE_WHITE_NOISE)
+    for i, seed in enumerate(seeds):
+        assert np.array_equal(white[i], wyrand_f32(seed, bs * blocks)), f"seed {seed}"
+    assert white.min() >= -1.0 and white.max() < 1.0 and abs(float(white.mean())) < 0.03
+    assert not np.array_equal(white[0], white[1])
+    # PinkNoise: two draws per sample, the first replaces row trailing_zeros(counter), counter 1..256
+    pink = run(L.STAGE_PINK_NOISE)
+    draws = wyrand_f32(seeds[3], 2 * bs * blocks)
+    rows, always, total, counter, ref = np.zeros(9, np.float32), np.float32(0), np.float32(0), 1, []
+    for k in range(bs * blocks):
+        idx = (counter & -counter).bit_length() - 1
+        total = np.float32(total - rows[idx]); rows[idx] = draws[2 * k]; total = np.float32(total + rows[idx])
+        total = np.float32(total - always); always = draws[2 * k + 1]; total = np.float32(total + always)
+        counter = (counter & 255) + 1
+        ref.append(np.float32(total / np.float32(10.0)))
+    assert np.array_equal(pink[3], np.array(ref, dtype=np.float32))
+    assert np.abs(pink).max() < 1.0
+    # BrownNoise: a clamped random walk of step white * 0.1
+    brown = run(L.STAGE_BROWN_NOISE)
+    w3, last, ref = wyrand_f32(seeds[3], bs * blocks), np.float32(0), []
+    for k in range(bs * blocks):
+        last = np.float32(last + np.float32(w3[k] * np.float32(0.1)))
+        last = np.float32(min(max(last, np.float32(-1.0)), np.float32(1.0)))
+        ref.append(last)
+    assert np.array_equal(brown[3], np.array(ref, dtype=np.float32))
+    # f64 banks: the same f32 draws, cast
+    assert np.array_equal(run(L.STAGE_WHITE_NOISE, L.F64)[2], white[2].astype(np.float64))
