@@ -129,6 +129,9 @@ typedef enum knh_value_kind {
  * KNH_STAGE_WHITE_NOISE     g.push(WhiteNoise::new())   noise.rs:26-47     1    seed
  * KNH_STAGE_PINK_NOISE      g.push(PinkNoise::new())    noise.rs:49-111    1    seed
  * KNH_STAGE_BROWN_NOISE     g.push(BrownNoise::new())   noise.rs:119-156   1    seed
+ * KNH_STAGE_RANDOM_LIN      g.push(RandomLin::new(freq))  noise.rs:158-230   1    seed, freq
+ *     params: 0 freq.  Random values in 0..1 joined by straight lines, a new value freq times a second.
+ *     (The reference seeds this one with next_randomness_seed() * 94 + 53: the shim passes the counter value.)
  *     sources; no parameters.  seed = the value the UGen's constructor got from next_randomness_seed()
  *     (noise.rs:11-22: a process-wide counter, 0, 1, 2, ... in construction order).  The generator is the
  *     `fastrand` crate's (2.3.0, not vendored with the reference): restated from its published algorithm, parity
@@ -172,7 +175,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_WHITE_NOISE = 28,
   KNH_STAGE_PINK_NOISE = 29,
   KNH_STAGE_BROWN_NOISE = 30,
-  KNH_STAGE_KIND_COUNT = 31
+  KNH_STAGE_RANDOM_LIN = 31,
+  KNH_STAGE_KIND_COUNT = 32
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,

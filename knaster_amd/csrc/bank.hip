@@ -69,6 +69,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* WHITE_NOISE */ {2, 0, 1, 1, 'U', {nullptr}},
     /* PINK_NOISE  */ {14, 0, 1, 1, 'K', {nullptr}},
     /* BROWN_NOISE */ {3, 0, 1, 1, 'O', {nullptr}},
+    /* RANDOM_LIN  */ {6, 1, 2, 1, 'G', {"freq"}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -80,7 +81,7 @@ inline int stage_cost(char c) {
   switch (c) {
     case 'W': return 7;  case 'R': return 10; case 'N': return 25; case 'S': return 10; case 'L': return 3;
     case 'H': return 4;  case 'A': return 5;  case 'E': return 5;  case 'V': return 14; case 'D': return 12;
-    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'U': return 14; case 'O': return 19; case 'K': return 50; case 'X': return 4; case 'B': return 45; case 'Y': return 14; case 'Z': return 18; case 'F': return 16;
+    case 'd': case 'q': return 8;  case 'p': return 40; case 'i': return 10; case 'P': return 6; case 'U': return 14; case 'O': return 19; case 'K': return 50; case 'G': return 10; case 'X': return 4; case 'B': return 45; case 'Y': return 14; case 'Z': return 18; case 'F': return 16;
     default: return 1;
   }
 }
@@ -567,6 +568,29 @@ struct Bank final : knh_bank {
               for (int k = 3; k < 14; ++k) slot(S.slot_base + k, v) = to_bits(F(0));
             }
           } break;
+          case KNH_STAGE_RANDOM_LIN: {  // noise.rs:172-200: new() draws the first value, init() turns freq into a step and draws the second
+            uint64_t rng = (a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u) * 94u + 53u;
+            auto draw = [&rng]() {  // fastrand 2.3.0 Rng::f32 (wyrand), restated: voice_chain.hpp NoiseRng
+              rng += 0x2d358dccaa6c78a5ull;
+              const unsigned __int128 t = static_cast<unsigned __int128>(rng) * static_cast<unsigned __int128>(rng ^ 0x8bb84b93962eacc9ull);
+              const uint32_t r = static_cast<uint32_t>(static_cast<uint64_t>(t) ^ static_cast<uint64_t>(t >> 64));
+              const uint32_t bits = 0x3F800000u + (r >> 9);
+              float f;
+              std::memcpy(&f, &bits, 4);
+              return f - 1.0f;
+            };
+            const F first = static_cast<F>(draw());              // current_value: F::new(rng.f32())
+            const F inc = F(1) / static_cast<F>(sr);             // freq_to_phase_inc = F::ONE / F::from(sample_rate)
+            const F step = static_cast<F>(a[1]) * inc;           // phase_step *= freq_to_phase_inc
+            const F old_target = first + F(0);                   // new_value(): current_value + current_change_width
+            const F second = static_cast<F>(draw());
+            slot(S.slot_base + 0, v) = static_cast<W>(static_cast<uint32_t>(rng));
+            slot(S.slot_base + 1, v) = static_cast<W>(static_cast<uint32_t>(rng >> 32));
+            slot(S.slot_base + 2, v) = to_bits(old_target);
+            slot(S.slot_base + 3, v) = to_bits(static_cast<F>(second - old_target));
+            slot(S.slot_base + 4, v) = to_bits(F(0));
+            slot(S.slot_base + 5, v) = to_bits(step);
+          } break;
           case KNH_STAGE_POLYBLEP: {  // polyblep.rs:136-153: new(waveform, freq), init -> set_freq: dt = freq / sample_rate
             const F srf = static_cast<F>(sr);  // F::from(sample_rate)
             const F freq = static_cast<F>(a[1]);
@@ -894,6 +918,10 @@ struct Bank final : knh_bank {
         } else {  // Waveform::from(PInteger): out of range -> default (Sawtooth)
           set(3, iv >= 0 && iv < 14 ? static_cast<uint64_t>(iv) : 0u);
         }
+      } break;
+      case KNH_STAGE_RANDOM_LIN: {  // noise.rs:213-221: phase_step = F::new(value) * freq_to_phase_inc
+        const F inc = F(1) / static_cast<F>(sample_rate);
+        set(5, to_bits(static_cast<F>(static_cast<F>(f) * inc)));
       } break;
       case KNH_STAGE_PHASOR: {  // osc.rs:189-196
         const uint64_t sb = to_bits(f * (1.0 / static_cast<double>(sample_rate)));
@@ -1321,6 +1349,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if (st[i].kind >= KNH_STAGE_KIND_COUNT) { *why = "unknown stage kind"; return KNH_ERR_INVALID_ARGUMENT; }
     const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC || st[i].kind == KNH_STAGE_PHASOR ||
                         st[i].kind == KNH_STAGE_WHITE_NOISE || st[i].kind == KNH_STAGE_PINK_NOISE || st[i].kind == KNH_STAGE_BROWN_NOISE ||
+                        st[i].kind == KNH_STAGE_RANDOM_LIN ||
                         st[i].kind == KNH_STAGE_POLYBLEP || st[i].kind == KNH_STAGE_BUFFER_READER;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1625,6 +1654,7 @@ int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_
       case KNH_STAGE_WHITE_NOISE: w += word * 2; break;
       case KNH_STAGE_PINK_NOISE: w += word * 14; break;
       case KNH_STAGE_BROWN_NOISE: w += word * 3; break;
+      case KNH_STAGE_RANDOM_LIN: w += word * 5; break;
       case KNH_STAGE_POLYBLEP: w += word; break;
       case KNH_STAGE_BUFFER_READER: w += word * 3; break;  // + two Buffer samples read per frame
       case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)

@@ -267,6 +267,51 @@ struct BrownNoise {
     else r.last = word_to_f<F>((typename WordOf<F>::type)bits);
   }
 };
+// RandomLin -- noise.rs:158-230: random values in 0..1, a new one whenever the phase reaches 1, straight lines between.
+// slots: 0,1 rng  2 current_value  3 current_change_width  4 phase  5 phase_step (= freq / sample_rate, host side)
+struct RandomLin {
+  static constexpr int kSlots = 6;
+  static constexpr u32 kMutableMask = 0b011111u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs { NoiseRng rng; F value, width, phase, step; };
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    r.rng.load(s, st);
+    r.value = word_to_f<F>(s[2 * st]); r.width = word_to_f<F>(s[3 * st]);
+    r.phase = word_to_f<F>(s[4 * st]); r.step = word_to_f<F>(s[5 * st]);
+  }
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    r.rng.store(s, st);
+    s[2 * st] = f_to_word(r.value); s[3 * st] = f_to_word(r.width); s[4 * st] = f_to_word(r.phase);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
+    const F out = mad<FMA>(r.phase, r.width, r.value);  // current_value + phase * current_change_width
+    r.phase += r.step;
+    if (r.phase >= (F)1) {  // new_value(), noise.rs:186-192
+      const F old_target = r.value + r.width;
+      const F fresh = (F)r.rng.f32();
+      r.value = old_target;
+      r.width = fresh - old_target;
+      r.phase = (F)0;
+    }
+    return out;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    const F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel < 2) r.rng.patch(rel, (u32)bits);
+    else if (rel == 2) r.value = v; else if (rel == 3) r.width = v; else if (rel == 4) r.phase = v; else r.step = v;
+  }
+};
 // PinkNoise -- noise.rs:49-111 (Voss-McCartney, nine octaves).  slots: 0,1 rng  2 counter  3 pink  4 always_on
 // 5..13 white_noises[0..8].  The nine rows live in registers; the row to replace (counter.trailing_zeros()) is picked
 // with selects, not with an indexed access.

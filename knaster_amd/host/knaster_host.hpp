@@ -124,6 +124,7 @@ inline uint64_t next_randomness_seed() {
 inline UGenSpec WhiteNoise() { return UGenSpec(KNH_STAGE_WHITE_NOISE, {static_cast<double>(next_randomness_seed())}); }
 inline UGenSpec PinkNoise() { return UGenSpec(KNH_STAGE_PINK_NOISE, {static_cast<double>(next_randomness_seed())}); }
 inline UGenSpec BrownNoise() { return UGenSpec(KNH_STAGE_BROWN_NOISE, {static_cast<double>(next_randomness_seed())}); }
+inline UGenSpec RandomLin(double freq) { return UGenSpec(KNH_STAGE_RANDOM_LIN, {static_cast<double>(next_randomness_seed()), freq}); }  // noise.rs:172
 inline UGenSpec SvfFilter(SvfFilterType ty, double cutoff, double q, double gain_db) {
   return UGenSpec(KNH_STAGE_SVF, {static_cast<double>(ty), cutoff, q, gain_db});
 }
@@ -253,7 +254,7 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
   static const char* dly[] = {"delay_time"};
   static const char* frq[] = {"freq"};
   switch (kind) {
-    case KNH_STAGE_PHASOR: *n = 1; return frq;
+    case KNH_STAGE_PHASOR: case KNH_STAGE_RANDOM_LIN: *n = 1; return frq;
     case KNH_STAGE_POLYBLEP: { static const char* pb[] = {"freq", "pulse_width", "waveform"}; *n = 3; return pb; }
     case KNH_STAGE_SAFETY_LIMITER: case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: *n = 0; return frq;
     case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_ALLPASS_DELAY: *n = 1; return dly;
@@ -340,7 +341,7 @@ class Graph {
     if (s.is_env || s.is_constant) throw GraphError("an envelope/constant must be an operand of * + - /");
     const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR || s.kind == KNH_STAGE_POLYBLEP ||
                         s.kind == KNH_STAGE_BUFFER_READER || s.kind == KNH_STAGE_WHITE_NOISE || s.kind == KNH_STAGE_PINK_NOISE ||
-                        s.kind == KNH_STAGE_BROWN_NOISE;
+                        s.kind == KNH_STAGE_BROWN_NOISE || s.kind == KNH_STAGE_RANDOM_LIN;
     uint16_t flags = 0;
     if (source) {
       if (n.link_source >= 0) {

@@ -1250,6 +1250,38 @@ struct PinkNoise : UGen<F> {  // noise.rs:49-111
   }
 };
 template <typename F>
+struct RandomLin : UGen<F> {  // noise.rs:158-230
+  FastRng rng;
+  F current_value, current_change_width = F(0), phase = F(0), phase_step, freq_to_phase_inc = F(0);
+  RandomLin(uint64_t counter, F freq) : rng(counter * 94u + 53u), current_value(fnew<F>(rng.f32())), phase_step(freq) {}
+  size_t inputs() const override { return 0; }
+  size_t outputs() const override { return 1; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"freq"}; }
+  void new_value() {
+    const F old_target = current_value + current_change_width;
+    const F fresh = fnew<F>(rng.f32());
+    current_value = old_target;
+    current_change_width = fresh - old_target;
+    phase = F(0);
+  }
+  void init(uint32_t sample_rate, size_t) override {
+    freq_to_phase_inc = F(1) / static_cast<F>(sample_rate);
+    phase_step *= freq_to_phase_inc;  // freq is stored in phase_step until init
+    new_value();
+  }
+  void process(AudioCtx&, UGenFlags&, const F*, F* out) override {
+    out[0] = current_value + phase * current_change_width;
+    phase += phase_step;
+    if (phase >= F(1)) new_value();
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue v) override {
+    if (index != 0) { ctx.rt_log("Unknown parameter set for RandomLin"); return; }
+    const F value = fnew<F>(v.float_or_panic());
+    phase_step = freq_to_phase_inc == F(0) ? value : value * freq_to_phase_inc;
+  }
+};
+template <typename F>
 struct BrownNoise : UGen<F> {  // noise.rs:119-156
   FastRng rng;
   F last_output = F(0);

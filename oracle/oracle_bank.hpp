@@ -29,6 +29,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_POLYBLEP: return 2;
     case KNH_STAGE_BUFFER_READER: return 3;
     case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: return 1;
+    case KNH_STAGE_RANDOM_LIN: return 2;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -76,6 +77,7 @@ struct VoiceChainBuilder {
         case KNH_STAGE_WHITE_NOISE: core = std::make_unique<WhiteNoise<F>>(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u); break;
         case KNH_STAGE_PINK_NOISE: core = std::make_unique<PinkNoise<F>>(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u); break;
         case KNH_STAGE_BROWN_NOISE: core = std::make_unique<BrownNoise<F>>(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u); break;
+        case KNH_STAGE_RANDOM_LIN: core = std::make_unique<RandomLin<F>>(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u, fnew<F>(a[1])); break;
         case KNH_STAGE_BUFFER_READER:
           if (!buffer) throw std::runtime_error("BufferReader stage without a buffer");
           core = std::make_unique<BufferReader<F>>(buffer, a[0], a[1] != 0.0, a[2]);
@@ -152,7 +154,8 @@ struct VoiceChainBuilder {
 
       const bool is_source = st.kind == KNH_STAGE_SIN_WT || st.kind == KNH_STAGE_SIN_NUMERIC || st.kind == KNH_STAGE_PHASOR ||
                              st.kind == KNH_STAGE_POLYBLEP || st.kind == KNH_STAGE_BUFFER_READER ||
-                             st.kind == KNH_STAGE_WHITE_NOISE || st.kind == KNH_STAGE_PINK_NOISE || st.kind == KNH_STAGE_BROWN_NOISE;
+                             st.kind == KNH_STAGE_WHITE_NOISE || st.kind == KNH_STAGE_PINK_NOISE || st.kind == KNH_STAGE_BROWN_NOISE ||
+                             st.kind == KNH_STAGE_RANDOM_LIN;
       const bool ar = st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ);
       NodeKey core_key = g.push(std::move(core));
       targets[s].node = core_key;

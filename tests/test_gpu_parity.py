@@ -607,3 +607,21 @@ def test_noise_sources(knh, oracle, kind, sample_type):
         if block == 4:
             bank.param_apply_many(v[::2], 3, 2, L.VALUE_TRIGGER, delays=(v[::2] % bs).astype(np.uint16))
     run_pair(knh, oracle, w, 7, ev, L.MIX_TREE)
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_random_lin(knh, oracle, sample_type):
+    """RandomLin (noise.rs:158-230): the two draws of new() and init() happen on the host, the rest on the device;
+    frequencies from well below one value per block to more than one per sample-pair, changed sample-accurately."""
+    n, bs = 130, 64
+    v = np.arange(n, dtype=np.uint32)
+    w = configs.Workload("randomlin", [Stage(L.STAGE_RANDOM_LIN, delayed_changes_per_block=2), Stage(L.STAGE_MUL_CONST)], n, bs, sample_type, 2)
+    freq = 3.0 * 1.07 ** v  # 3 Hz .. 19 kHz
+    w.ctor = {0: np.stack([v.astype(np.float64) + 7.0, freq], axis=1), 1: np.full((n, 1), 1.0 / n)}
+
+    def ev(block, bank):
+        if block == 2:
+            bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, freq[::-1].copy(), delays=(v % bs).astype(np.uint16))
+        if block == 4:
+            bank.param_apply_many(v[::3], 0, 0, L.VALUE_FLOAT, np.full(len(v[::3]), 48000.0))  # a new value every sample
+    run_pair(knh, oracle, w, 7, ev, L.MIX_TREE)

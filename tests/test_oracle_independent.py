@@ -332,3 +332,27 @@ def test_noise_generator_is_the_stated_wyrand(oracle):
     assert np.array_equal(brown[3], np.array(ref, dtype=np.float32))
     # f64 banks: the same f32 draws, cast
     assert np.array_equal(run(L.STAGE_WHITE_NOISE, L.F64)[2], white[2].astype(np.float64))
+    # RandomLin: rng seeded with counter * 94 + 53; one draw in new(), one in init(), one at every phase wrap
+    b = oracle.OracleBank([Stage(L.STAGE_RANDOM_LIN)], 1, L.F32, 1, True, True)
+    b.set_ctor_args(0, np.array([[5.0, 3000.0]]))
+    b.init(48000, bs)
+    got = np.concatenate([b.process_block()[1] for _ in range(blocks)], axis=1)[0]
+    M = (1 << 64) - 1
+    def draws(seed, count):  # rng.f32() itself
+        st, out = int(seed), []
+        for _ in range(count):
+            st = (st + 0x2D358DCCAA6C78A5) & M
+            t = st * (st ^ 0x8BB84B93962EACC9)
+            r = ((t & M) ^ (t >> 64)) & 0xFFFFFFFF
+            out.append(np.array([0x3F800000 + (r >> 9)], dtype=np.uint32).view(np.float32)[0] - np.float32(1.0))
+        return out
+    d = draws(5 * 94 + 53, 400)
+    value, width, phase, step, k, ref = d[0], np.float32(0), np.float32(0), np.float32(np.float32(3000.0) * (np.float32(1.0) / np.float32(48000.0))), 1, []
+    old = np.float32(value + width); value, width = old, np.float32(d[k] - old); k += 1   # init(): new_value()
+    for _ in range(bs * blocks):
+        ref.append(np.float32(value + np.float32(phase * width)))
+        phase = np.float32(phase + step)
+        if phase >= np.float32(1.0):
+            old = np.float32(value + width); value, width, phase = old, np.float32(d[k] - old), np.float32(0); k += 1
+    assert np.array_equal(got, np.array(ref, dtype=np.float32)) and k > 100
+    assert got.min() >= 0.0 and got.max() < 1.0
