@@ -110,6 +110,9 @@ unsafe impl<F: Float> Send for GpuVoiceBank<F> {}
 impl<F: Float> GpuVoiceBank<F> {
     /// `ctor[stage]` = row-major `[n_voices][n_args]` constructor arguments (`SinWt::new(freq)` → `[freq]`,
     /// `SvfFilter::new(ty, cutoff, q, gain)` → `[ty as f64, cutoff, q, gain]`, ...; table in knaster_hip.h).
+    /// The randomness sources (`KNH_STAGE_WHITE_NOISE`, `_PINK_NOISE`, `_BROWN_NOISE`, `_RANDOM_LIN`) take as first argument
+    /// the seed their reference constructor would have drawn: `knaster_core_dsp::noise::next_randomness_seed() as f64`,
+    /// once per voice, in the order the voices would have been constructed.
     pub fn new(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>]) -> Result<Self, BankError> {
         Self::with_host_threads(stages, n_voices, ctor, 0)
     }
