@@ -102,7 +102,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   int blk = 0, ti = 0;                                      // position of this group's next tile
 #ifdef KNH_DAG_STAMPS  // diagnostic build only: cycles this wavefront is busy per tile (tools/pipe_stamps.py)
-  u64 busy = 0, busy_in = 0, busy_out = 0;
+  u64 busy = 0, busy_in = 0, busy_out = 0, busy_tick = 0, busy_fold = 0;
 #endif
   for (int s = 0; s < n_steps; ++s) {
     const int g = s - I;
@@ -146,6 +146,10 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
         F* out_row = out_tile + (long)lane * EdgeLayout<F, T>::stride;
         if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev_inside)) {
           chain.template tick_tile<T>(x, ctx, n);
+#ifdef KNH_DAG_STAMPS
+          asm volatile("" ::: "memory");
+          busy_tick += __builtin_amdgcn_s_memtime() - t1;
+#endif
           Vec* out = reinterpret_cast<Vec*>(out_row);  // 16-byte LDS stores
 #pragma unroll
           for (int j = 0; j < T / VW; ++j) {
@@ -164,7 +168,15 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
             out_row[j] = chain.tick(v, ctx, n + j);
           }
         }
+#ifdef KNH_DAG_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const u64 tf0 = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (FOLDS) pipe_fold_tile<F, T>(out_tile, a, lane, wave_global, n_waves_total, blk, n, m, v0, nv);
+#ifdef KNH_DAG_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        busy_fold += __builtin_amdgcn_s_memtime() - tf0;
+#endif
       }
 #if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("" ::: "memory");
@@ -194,6 +206,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
     const u64 d = (u64)(n_tiles > 0 ? n_tiles : 1);
     a.flags[4 + I] = (u32)(busy / d);
     if (8 + 2 * I + 1 < 16) { a.flags[8 + 2 * I] = (u32)(busy_in / d); a.flags[9 + 2 * I] = (u32)(busy_out / d); }
+    if (FOLDS) { a.flags[14] = (u32)(busy_tick / d); a.flags[15] = (u32)(busy_fold / d); }  // the folding group's stage arithmetic and fold
   }
 #endif
   if (live) chain.store(a.state + voice, a.stride);

@@ -21,7 +21,8 @@ if w.delay_times is not None:
     b.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times)
 for phase in ["attack (blocks 0-8)", "sustain (8-16)"]:
     b.process_blocks(8)
-    print(phase, "busy cycles per tile [osc+gain, svf, env, mixer]:", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
+    print(phase, "busy cycles per tile [osc+gain, svf, env, mixer]:", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14],
+          "last group's arithmetic / fold:", b.debug_words()[14:16])
 b.param_apply_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER)
 b.process_blocks(8)
 print("release", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
@@ -29,4 +30,5 @@ b.process_blocks(32)
 print("stopped", b.debug_words()[4:8], "in/out per group:", b.debug_words()[8:14])
 b.timing_reset(True)
 b.process_blocks(64)
+print("the folding group (64-sample form): stage arithmetic and fold, cycles per tile:", b.debug_words()[14:16])
 print("kernel ms for 64 blocks", b.timing_read())
