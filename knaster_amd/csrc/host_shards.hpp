@@ -163,7 +163,17 @@ struct ShardedBank final : knh_bank {
   int apply_many(uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stgs, const uint32_t* params,
                  const uint32_t* kinds, const double* fvalues, const int64_t* ivalues, const uint16_t* delays) override {
     bool ok = initialised && count >= 256;
-    for (size_t i = 0; ok && i < count; ++i) ok = call_is_valid(block_offset, voices[i], stgs[i], params[i], kinds[i]);
+    {  // a batch usually addresses few (stage, parameter, kind) triples: each is checked once, the voices all
+      uint32_t ls = ~0u, lp = ~0u, lk = ~0u;
+      for (size_t i = 0; ok && i < count; ++i) {
+        if (stgs[i] != ls || params[i] != lp || kinds[i] != lk) {
+          ok = call_is_valid(block_offset, voices[i], stgs[i], params[i], kinds[i]);
+          ls = stgs[i]; lp = params[i]; lk = kinds[i];
+        } else {
+          ok = voices[i] < nv;
+        }
+      }
+    }
     if (!ok)  // small batches, and batches with a call that will be refused: one by one, exactly as the one-range bank does
       return knh_bank::apply_many(block_offset, count, voices, stgs, params, kinds, fvalues, ivalues, delays);
     if (n_deferred == deferred.size()) deferred.emplace_back();
