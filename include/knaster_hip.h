@@ -269,6 +269,8 @@ int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank);
  * side by side on their own streams, and their mixes are summed in range order on the caller's stream.  Every
  * call keeps its meaning and stays single-caller.  Meant for banks whose voices all receive sample-accurate
  * changes (BASELINE config C5), where one core assembling the lists is slower than the kernel.
+ * Measured on C5: 2.4e10 -> 4.8e10 UGen-samples/s with 4 threads; more ranges than the runtime has hardware queues
+ * (4) run their kernels one after another and lose (8: 2.5e10).
  * host_threads 0 or 1, KNH_MIX_LEFT_FOLD banks and banks of at most 64 voices: identical to knh_bank_create.
  * The mix is a sum of per-range tree mixes: deterministic, within the tree mix's tolerance of the left fold. */
 int32_t knh_bank_create_sharded(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank);
