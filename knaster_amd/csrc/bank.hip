@@ -411,6 +411,9 @@ struct Bank final : knh_bank {
     // pipelined form wins by a wide margin, so the chain is cut into at most three stage groups of similar cost
     // (estimated instructions per sample) and instantiated as voice_pipe_kernel; KNH_JIT_PIPE=0 keeps the
     // single-wave form.
+    // The 64-sample-tile pipeline only where the block is made of whole tiles: a partial tile runs sample by sample,
+    // and a 32- or 96-frame block would be half partial tiles (its 32-sample form has none).
+    if (pipe && pipe->big && bs % (sizeof(F) == 4 ? 64u : 32u) != 0) pipe = knh::find_pipe(signature.c_str(), false);
     const unsigned n_groups = (nv + 63u) / 64u;
     const char* jp = std::getenv("KNH_JIT_PIPE");
     // (a single voice group with a pre-built kernel stays on it: nothing to gain, and no compile at init)
