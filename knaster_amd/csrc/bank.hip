@@ -334,6 +334,10 @@ struct Bank final : knh_bank {
   F* d_voices = nullptr;
   uint32_t* d_done = nullptr;
   uint32_t* d_flags = nullptr;
+  uint32_t flags_parity = 0;        // which of the two flag sets the next launch uses
+  uint32_t* flags_last = nullptr;   // the set of the last launch (knh_bank_debug_words)
+  hipStream_t flags_stream = nullptr;  // the stream of the last launch, whose fold kernel cleared the set of this one
+  bool flags_stream_set = false;
   // pinned host staging
   // Event lists are read by the kernel straight from pinned host memory (each is read once, a few hundred KB per
   // launch): no copy in the stream, the kernel's first waves pull them over PCIe while the others start.  Two
@@ -688,8 +692,9 @@ struct Bank final : knh_bank {
     KNH_HIP(hipMemset(d_out, 0, desc.out_channels * bs * sizeof(F)));
     KNH_HIP(hipMalloc(&d_done, static_cast<size_t>(nv) * sizeof(uint32_t)));
     KNH_HIP(hipMemset(d_done, 0xFF, static_cast<size_t>(nv) * sizeof(uint32_t)));
-    KNH_HIP(hipMalloc(&d_flags, 16 * sizeof(uint32_t)));
-    KNH_HIP(hipMemset(d_flags, 0, 16 * sizeof(uint32_t)));
+    // two sets of 16 words, used by alternate launches: the fold kernel of a launch clears the other set's counters
+    KNH_HIP(hipMalloc(&d_flags, 32 * sizeof(uint32_t)));
+    KNH_HIP(hipMemset(d_flags, 0, 32 * sizeof(uint32_t)));
     for (int b = 0; b < 2; ++b) {
       KNH_HIP(hipHostMalloc(&h_ev_start2[b], (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
       KNH_HIP(hipEventCreateWithFlags(&list_done[b], hipEventDisableTiming));
@@ -1186,7 +1191,13 @@ struct Bank final : knh_bank {
       out_blocks = n_blocks;
     }
 
-    KNH_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), s));
+    if (flags_stream_set && flags_stream != s) KNH_HIP(hipStreamSynchronize(flags_stream));  // that set was cleared in the other stream's order
+    flags_stream = s;
+    flags_stream_set = true;
+    uint32_t* const flags_now = d_flags + 16 * flags_parity;
+    uint32_t* const flags_next = d_flags + 16 * (flags_parity ^ 1u);
+    flags_parity ^= 1u;
+    flags_last = flags_now;
     VoiceKernelArgs<F> a;
     a.state = d_state;
     a.stride = stride;
@@ -1208,7 +1219,7 @@ struct Bank final : knh_bank {
     a.partials = d_partials;
     a.voices_out = want_voices ? d_voices : nullptr;
     a.done_frames = d_done;
-    a.flags = d_flags;
+    a.flags = flags_now;
     std::pair<hipEvent_t, hipEvent_t>* tp = nullptr;
     if (timing) {
       if (timing_used == timing_pool.size()) {
@@ -1235,16 +1246,16 @@ struct Bank final : knh_bank {
 
     F* dst = out_device ? static_cast<F*>(out_device) : d_out;
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
-      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), 1, accumulate, s));
+      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), 1, accumulate, flags_next, s));
     else
-      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), n_blocks, accumulate, s));
+      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), n_blocks, accumulate, flags_next, s));
 
     if (!sync) return KNH_OK;
     const size_t blk_elems = desc.out_channels * block_size;
     const size_t out_bytes = static_cast<size_t>(n_blocks) * blk_elems * sizeof(F);
     uint32_t* h_flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h_out) + static_cast<size_t>(out_blocks) * blk_elems * sizeof(F));
     if (out_host) KNH_HIP(hipMemcpyAsync(h_out, dst, out_bytes, hipMemcpyDeviceToHost, s));
-    KNH_HIP(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    KNH_HIP(hipMemcpyAsync(h_flags, flags_now, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (voices_host)
       KNH_HIP(hipMemcpyAsync(voices_host, d_voices, static_cast<size_t>(nv) * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
     KNH_HIP(hipStreamSynchronize(s));
@@ -1283,11 +1294,11 @@ struct Bank final : knh_bank {
     if (pipe) return pipe->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
-  static hipError_t launch_fold(bool tree, const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, unsigned nb, bool acc, hipStream_t s) {
-    return knh::launch_fold_f32(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, s);
+  static hipError_t launch_fold(bool tree, const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, unsigned nb, bool acc, uint32_t* zf, hipStream_t s) {
+    return knh::launch_fold_f32(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, zf, s);
   }
-  static hipError_t launch_fold(bool tree, const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, unsigned nb, bool acc, hipStream_t s) {
-    return knh::launch_fold_f64(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, s);
+  static hipError_t launch_fold(bool tree, const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, unsigned nb, bool acc, uint32_t* zf, hipStream_t s) {
+    return knh::launch_fold_f64(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, zf, s);
   }
 
   int read_done_frames(uint32_t* out) override {
@@ -1302,7 +1313,7 @@ struct Bank final : knh_bank {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
     KNH_HIP(hipSetDevice(device));
     KNH_HIP(hipDeviceSynchronize());
-    KNH_HIP(hipMemcpy(out16, d_flags, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    KNH_HIP(hipMemcpy(out16, flags_last ? flags_last : d_flags, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return KNH_OK;
   }
   int synchronize() override {

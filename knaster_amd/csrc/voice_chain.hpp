@@ -1805,7 +1805,9 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
 // 16 rows ahead of the adds.  out: [channels][out_stride]; frames [frame_begin, frame_end) are written.
 template <typename F>
 __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
-                                                        u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate) {
+                                                        u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate, u32* zero_flags) {
+  // the flag words the NEXT launch's voice kernel accumulates into (two sets alternate; this spares a memset node)
+  if (zero_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { zero_flags[0] = 0u; zero_flags[1] = 0u; }
   const u32 n = frame_begin + blockIdx.x * 64u + threadIdx.x;
   if (n >= frame_end) return;
   rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
@@ -1833,8 +1835,9 @@ __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows
 // One 256-thread workgroup handles 16 frames: thread (g, f) folds group g (+16, +32, ...) for frame f.
 template <typename F>
 __global__ void __launch_bounds__(256) fold_tree_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
-                                                         u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate) {
+                                                         u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate, u32* zero_flags) {
   __shared__ F part[16][17];
+  if (zero_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { zero_flags[0] = 0u; zero_flags[1] = 0u; }  // see fold_rows_kernel
   rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
   out += (long)blockIdx.y * channels * out_stride;
   const u32 f = threadIdx.x & 15u, g = threadIdx.x >> 4;
