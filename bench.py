@@ -3,10 +3,11 @@
 
 Workload: BASELINE.json configs[2] ("C3"): 16384 voices per GPU, chain
 SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, block_size 512, f32, 48 kHz, synthetic
-per-voice parameters (xorshift32).  One *step* = one 512-frame block of every
-voice on every rank.  Blocks are rendered REDUCE_EVERY per launch (knh_bank_process_blocks_device:
-voice state stays in registers across the blocks of a launch; results are bit-identical to one launch
-per block, tests/test_gpu_properties.py).  Voices shard across ranks (one process per GPU); each rank
+per-voice parameters (xorshift32).  One *step* = one pass of the hot path over one
+batch: BLOCKS_PER_STEP (64) consecutive 512-frame blocks of every voice on every rank, rendered in ONE
+launch (knh_bank_process_blocks_device: voice state stays in registers across the blocks of a launch;
+results are bit-identical to one launch per block, tests/test_gpu_properties.py) -- the note cycle of
+SURVEY.md 8(d) (t_restart at block 0, t_release at block 32).  `value` counts every block of every step.  Voices shard across ranks (one process per GPU); each rank
 folds its own voices into stereo blocks and each launch's stereo blocks are sum-reduced to rank 0
 over RCCL in one call (the reduce is latency-bound at 4 KiB per block).
 
@@ -37,14 +38,16 @@ OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per
 SVF_STEP_CYCLES = 44.0
 SHADER_CLOCK_GHZ = 2.4
 PIPE_TILE = 64                 # samples per pipeline step of the shipped C3 kernel (voice_pipe.hpp)
-REDUCE_EVERY = 64              # blocks per RCCL reduce
+BLOCKS_PER_STEP = 64           # blocks per step = per launch = per RCCL reduce (one note cycle)
+REDUCE_EVERY = BLOCKS_PER_STEP
+PREWARM_MS = 150.0             # untimed launches before the warm-up steps: the shader clock needs a few ms of load to come up
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2048)
-    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one 64-block launch per rank")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps before the timed ones")
     ap.add_argument("--voices-per-gpu", type=int, default=16384)
     ap.add_argument("--block-size", type=int, default=512)
     ap.add_argument("--allow-fma", action="store_true", help="non-bit-exact FMA kernels (reported as such)")
@@ -131,22 +134,19 @@ def main():
     launch_no = [0]
 
     def run_steps(first_step: int, n: int):
-        """n steps (blocks), REDUCE_EVERY blocks per launch; one RCCL reduce of each launch's stereo blocks."""
-        done = 0
-        while done < n:
-            k = min(REDUCE_EVERY, n - done)
+        """n steps; one step = one launch of BLOCKS_PER_STEP blocks + one RCCL reduce of its stereo blocks."""
+        for i in range(n):
             half = launch_no[0] & 1
             launch_no[0] += 1
             if pending[half] is not None:  # the reduce that last read this buffer must be done before it is rewritten
                 pending[half].wait()
                 pending[half] = None
-            schedule(first_step + done, k)
-            bank.process_blocks_device(k, rings[half].data_ptr(), stream.cuda_stream)
+            schedule((first_step + i) * BLOCKS_PER_STEP, BLOCKS_PER_STEP)
+            bank.process_blocks_device(BLOCKS_PER_STEP, rings[half].data_ptr(), stream.cuda_stream)
             if world > 1 and not rehearse:
-                pending[half] = dist.reduce(rings[half][:k], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+                pending[half] = dist.reduce(rings[half], dst=0, op=dist.ReduceOp.SUM, async_op=True)
             elif world > 1:  # gloo has no device-tensor reduce
-                pending[half] = dist.all_reduce(rings[half][:k], op=dist.ReduceOp.SUM, async_op=True)
-            done += k
+                pending[half] = dist.all_reduce(rings[half], op=dist.ReduceOp.SUM, async_op=True)
 
     def drain():
         for h in range(2):
@@ -160,6 +160,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed: bring the shader clock up (a kernel of under a few milliseconds right after an idle period runs ~25 % slow)
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while (time.perf_counter() - t_pre) * 1e3 < PREWARM_MS:
+        run_steps(0, 2)
+        drain()
+        torch.cuda.synchronize()
+        n_pre += 2
     run_steps(0, args.warmup)
     fence()
     bank.timing_reset(True)
@@ -169,7 +177,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = bank.timing_read()
     bank.timing_reset(False)
-    blocks_per_launch = args.steps / max(launches, 1)
+    blocks_per_launch = float(BLOCKS_PER_STEP)
+    total_blocks = args.steps * BLOCKS_PER_STEP
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -186,27 +195,33 @@ def main():
     host_rate = None
     if world == 1:
         n_host = 4
-        schedule(args.warmup + args.steps, REDUCE_EVERY)
+        schedule(0, REDUCE_EVERY)
         bank.process_blocks(REDUCE_EVERY)
         t1 = time.perf_counter()
         for i in range(n_host):
-            schedule(args.warmup + args.steps + (i + 1) * REDUCE_EVERY, REDUCE_EVERY)
+            schedule(0, REDUCE_EVERY)
             bank.process_blocks(REDUCE_EVERY)
         host_rate = float(nv) * bs * ugens * REDUCE_EVERY * n_host / (time.perf_counter() - t1)
 
     sane = bool(torch.isfinite(rings[0]).all().item() and torch.isfinite(rings[1]).all().item())
-    traffic = None  # HBM bytes per launch from the committed PMC passes, if they were taken on this launch shape
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            prof = json.load(f)
-        wl = prof.get("workload", {})
-        if (wl.get("voices"), wl.get("block_size"), wl.get("blocks_per_launch")) == (nv, bs, int(round(args.steps / max(launches, 1)))):
-            traffic = prof["voice_pipe_kernel"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM bytes per launch from the committed PMC passes (newest round first), scaled per block: the counters are
+    # per-launch totals of a 64-block launch of the same bank
+    traffic, traffic_src = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+            wl = prof.get("workload", {})
+            if (wl.get("voices"), wl.get("block_size"), wl.get("sample_type", "f32")) == (nv, bs, "f32"):
+                traffic = prof["voice_pipe_kernel"]["hbm_bytes_per_launch"] / float(wl["blocks_per_launch"]) * blocks_per_launch
+                traffic_src = os.path.relpath(path, ROOT)
+                break
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            continue
     if rank == 0:
         total_voices = nv * world
-        ugen_samples = float(total_voices) * bs * ugens * args.steps
+        ugen_samples = float(total_voices) * bs * ugens * total_blocks
         value = ugen_samples / elapsed
         rd, wr = bank.algorithmic_bytes_per_voice_block()
         # 92 B per voice per block (state read once + mutable state written once per block)
@@ -231,6 +246,11 @@ def main():
                 "workload": "C3: SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, stereo mix",
                 "voices_per_gpu": nv, "voices_total": total_voices, "block_size": bs, "sample_rate": 48000,
                 "ugens_per_voice": ugens, "mix": "two-level left fold (deterministic)",
+                "step": f"one launch = {BLOCKS_PER_STEP} consecutive blocks of every voice (one note cycle); "
+                        f"{total_blocks} blocks timed", "blocks_per_step": BLOCKS_PER_STEP, "blocks_timed": total_blocks,
+                "residency": "value is measured with voice state, events and the mixed stereo blocks resident in HBM; the "
+                             "PCIe-inclusive rate of the host-pointer boundary (knh_bank_process_blocks) is host_output",
+                "prewarm": f"{n_pre} untimed launches (>= {PREWARM_MS:.0f} ms) before the warm-up steps, to bring the clock up",
                 "arithmetic": "fma" if args.allow_fma else "exact (bit-identical per voice to the CPU oracle)",
                 "parallelism": f"voices sharded over {world} rank(s); {REDUCE_EVERY} blocks per launch; RCCL sum-reduce of the "
                                f"stereo blocks once per launch",
@@ -239,7 +259,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes)" if traffic else None,
+                "traffic_source": f"{traffic_src} (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes, per launch)" if traffic else None,
                 "kernel": "voice_pipe_kernel<float,false,64,true,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>",
                 "kernel_avg_ms": kernel_avg_ms, "launches": launches, "blocks_per_launch": blocks_per_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,

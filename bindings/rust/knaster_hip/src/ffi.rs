@@ -86,7 +86,8 @@ pub const KNH_STAGE_WHITE_NOISE: u16 = 28;
 pub const KNH_STAGE_PINK_NOISE: u16 = 29;
 pub const KNH_STAGE_BROWN_NOISE: u16 = 30;
 pub const KNH_STAGE_RANDOM_LIN: u16 = 31;
-pub const KNH_STAGE_KIND_COUNT: u16 = 32;
+pub const KNH_STAGE_PAN2: u16 = 32;
+pub const KNH_STAGE_KIND_COUNT: u16 = 33;
 
 // knh_svf_type = SvfFilterType, knaster_core_dsp/src/ugens/svf.rs:19-39
 pub const KNH_SVF_LOW: u32 = 0;

@@ -138,6 +138,13 @@ typedef enum knh_value_kind {
  *     unpinned.
  * KNH_STAGE_SAFETY_LIMITER  x >> g.push(SafetyLimiter::new())   dynamics.rs:9-31     1    (none)
  *     clamp to [-1, 1], NaN -> 0; no parameters, no state
+ * KNH_STAGE_PAN2            x >> g.push(Pan2::new(pan))         pan.rs:12-37         1    pan (-1 .. 1)
+ *     mono -> stereo with the cos/sin pan law: the voice's signal times left_gain goes to graph out 0, times
+ *     right_gain to graph out 1 (`(voice >> pan).to_graph_out()`, knaster/examples/many_sines.rs:51-63).  Must be the
+ *     LAST stage, and the bank must have out_channels = 2; per-voice output (knh_bank_process_block_voices) is then
+ *     [2][n_voices][block_size].  params: 0 pan.  The gains are fastapprox::fast::cos / sin (crate fastapprox 0.3.1,
+ *     not vendored with the reference) of (pan * 0.5 + 0.5) * pi/2, restated from the published algorithm: parity
+ *     unpinned.  Cannot be wrapped in WrPreciseTiming here (delayed_changes_per_block must be 0).
  *     WrMul: params: 0 = the reference's "wr_mul" (index T::Parameters of the
  *     wrapped node, math.rs:69-98).  No other wrapper adds a parameter.  POW_CONST: params: 0 value.
  *     powi is the multiply-by-squaring loop of compiler-builtins (exact, bit-identical to the oracle);
@@ -176,7 +183,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_PINK_NOISE = 29,
   KNH_STAGE_BROWN_NOISE = 30,
   KNH_STAGE_RANDOM_LIN = 31,
-  KNH_STAGE_KIND_COUNT = 32
+  KNH_STAGE_PAN2 = 32,
+  KNH_STAGE_KIND_COUNT = 33
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,
@@ -227,7 +235,8 @@ typedef struct knh_bank_desc {
   uint32_t n_stages;
   const knh_stage_desc* stages;
   /* 1: mono signal -> graph out 0.  2: `.out([0,0]).to_graph_out()`, the same
-   * mono signal additively to out 0 and out 1 (graph_edit.rs:280-292,363-369). */
+   * mono signal additively to out 0 and out 1 (graph_edit.rs:280-292,363-369) -- or, for a
+   * chain that ends in KNH_STAGE_PAN2, the Pan2's left and right outputs to out 0 and out 1. */
   uint32_t out_channels;
   uint32_t mix_mode;     /* knh_mix_mode */
   int32_t device;        /* HIP device ordinal, -1 = current device */
@@ -336,7 +345,8 @@ int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process,
                                       size_t block_start_offset, uint64_t frame_clock,
                                       void* out_device, void* hip_stream);
 /* Parity/debug: also materialise every voice's own signal,
- * voices_out = host [n_voices][block_size] of F.  `out` may be NULL. */
+ * voices_out = host [n_voices][block_size] of F ([2][n_voices][block_size] for a chain that ends in
+ * KNH_STAGE_PAN2: every voice's left signals, then every voice's right signals).  `out` may be NULL. */
 int32_t knh_bank_process_block_voices(knh_bank* bank, size_t frames_to_process,
                                       size_t block_start_offset, uint64_t frame_clock, void* out,
                                       void* voices_out, uint32_t* out_flags);

@@ -25,7 +25,7 @@ VALUE_FLOAT, VALUE_TRIGGER, VALUE_INTEGER, VALUE_BOOL, VALUE_SMOOTHING = 0, 1, 2
  STAGE_MUL_ENV_AR, STAGE_MUL_CONST, STAGE_ADD_CONST, STAGE_SUB_CONST, STAGE_DIV_CONST, STAGE_WR_MUL,
  STAGE_WR_ADD, STAGE_WR_SUB, STAGE_MUL_ENVELOPE, STAGE_WR_VSUB, STAGE_WR_DIV, STAGE_WR_VDIV, STAGE_WR_POWF,
  STAGE_WR_POWI, STAGE_POW_CONST, STAGE_SAMPLE_DELAY, STAGE_PHASOR, STAGE_SAFETY_LIMITER, STAGE_POLYBLEP, STAGE_ALLPASS_DELAY, STAGE_ALLPASS_FB_DELAY, STAGE_BUFFER_READER,
- STAGE_WHITE_NOISE, STAGE_PINK_NOISE, STAGE_BROWN_NOISE, STAGE_RANDOM_LIN) = range(32)
+ STAGE_WHITE_NOISE, STAGE_PINK_NOISE, STAGE_BROWN_NOISE, STAGE_RANDOM_LIN, STAGE_PAN2) = range(33)
 STAGE_FLAG_AR_FREQ = 1
 STAGE_FLAG_SMOOTH_PARAMS = 2
 # knh_svf_type
@@ -40,7 +40,7 @@ STAGE_CTOR_ARGS = {  # STAGE_MUL_ENVELOPE takes 4 + 2 * n_max (variable)
     STAGE_MUL_ENV_ASR: 2, STAGE_MUL_ENV_AR: 2, STAGE_MUL_CONST: 1, STAGE_ADD_CONST: 1, STAGE_SUB_CONST: 1,
     STAGE_DIV_CONST: 1, STAGE_WR_MUL: 1, STAGE_WR_ADD: 1, STAGE_WR_SUB: 1,
     STAGE_WR_VSUB: 1, STAGE_WR_DIV: 1, STAGE_WR_VDIV: 1, STAGE_WR_POWF: 1, STAGE_WR_POWI: 1, STAGE_POW_CONST: 1, STAGE_SAMPLE_DELAY: 1, STAGE_PHASOR: 1, STAGE_SAFETY_LIMITER: 0, STAGE_POLYBLEP: 2, STAGE_ALLPASS_DELAY: 1, STAGE_ALLPASS_FB_DELAY: 1, STAGE_BUFFER_READER: 3,
-    STAGE_WHITE_NOISE: 1, STAGE_PINK_NOISE: 1, STAGE_BROWN_NOISE: 1, STAGE_RANDOM_LIN: 2,
+    STAGE_WHITE_NOISE: 1, STAGE_PINK_NOISE: 1, STAGE_BROWN_NOISE: 1, STAGE_RANDOM_LIN: 2, STAGE_PAN2: 1,
 }
 
 

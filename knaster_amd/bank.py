@@ -181,7 +181,9 @@ class VoiceBank:
     def process_block_voices(self, frames_to_process: Optional[int] = None, block_start_offset: int = 0, frame_clock: int = 0):
         ftp = self.block_size if frames_to_process is None else frames_to_process
         out = np.zeros((self.out_channels, self.block_size), dtype=self.dtype)
-        voices = np.zeros((self.n_voices, self.block_size), dtype=self.dtype)
+        # a chain that ends in Pan2 has a left and a right signal per voice: [2][n_voices][block_size]
+        pan = bool(self.stages) and self.stages[-1].kind == L.STAGE_PAN2
+        voices = np.zeros((2, self.n_voices, self.block_size) if pan else (self.n_voices, self.block_size), dtype=self.dtype)
         flags = C.c_uint32(0)
         self._check(self._lib.knh_bank_process_block_voices(self._h, ftp, block_start_offset, frame_clock,
                                                             out.ctypes.data_as(C.c_void_p),

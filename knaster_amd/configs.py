@@ -77,7 +77,7 @@ def config(name: str, n_voices: int | None = None, block_size: int | None = None
     name = name.upper()
     defaults = {"C1": (1, 64, L.F32), "C2": (1024, 256, L.F32), "C3": (16384, 512, L.F32),
                 "C4": (65536, 512, L.F64), "C5": (4096, 128, L.F32),
-                "D3": (16384, 512, L.F32), "B3": (16384, 512, L.F32)}
+                "D3": (16384, 512, L.F32), "B3": (16384, 512, L.F32), "M1": (600, 64, L.F32), "P3": (16384, 512, L.F32)}
     nv, bs, st = defaults[name]
     nv = n_voices or nv
     bs = block_size or bs
@@ -99,6 +99,22 @@ def config(name: str, n_voices: int | None = None, block_size: int | None = None
                      description="SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr")
         svf = np.stack([np.full(nv, float(L.SVF_LOW)), p["cutoff"], p["q"], np.zeros(nv)], axis=1)
         w.ctor = {0: col(p["freq"]), 1: col(gain), 2: svf, 3: np.stack([p["attack"], p["release"]], axis=1)}
+        w.restart = (3, 3)
+        w.release = (3, 2, 32)
+    elif name == "M1":  # knaster/examples/many_sines.rs:51-63: (EnvAr(0.01, 0.1) * SinWt(f).wr_mul(amp)) >> Pan2(pan), 600 voices
+        w = Workload(name, [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_MUL_ENV_AR), Stage(L.STAGE_PAN2)], nv, bs, st,
+                     description="(EnvAr * SinWt.wr_mul(amp)) >> Pan2(pan) -> graph out (many_sines.rs)")
+        u = (p["q"] - 0.5) / 3.5  # three of the uniform draws, mapped onto the example's ranges
+        w.ctor = {0: col(3000.0 + 7000.0 * (p["cutoff"] - 200.0) / 7800.0), 1: col(0.01 + 0.005 * u),
+                  2: np.tile([0.01, 0.1], (nv, 1)), 3: col(-1.0 + 2.0 * (p["fm_ratio"] - 1.0) / 3.0)}
+        w.restart = (2, 2)
+    elif name == "P3":  # not a BASELINE.json config: the C3 voice panned (Pan2 behind the envelope)
+        w = Workload(name, [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_SVF),
+                            Stage(L.STAGE_MUL_ENV_ASR, delayed_changes_per_block=precise), Stage(L.STAGE_PAN2)], nv, bs, st,
+                     description="SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr -> Pan2")
+        svf = np.stack([np.full(nv, float(L.SVF_LOW)), p["cutoff"], p["q"], np.zeros(nv)], axis=1)
+        w.ctor = {0: col(p["freq"]), 1: col(gain), 2: svf, 3: np.stack([p["attack"], p["release"]], axis=1),
+                  4: col(-1.0 + 2.0 * (p["fm_ratio"] - 1.0) / 3.0)}
         w.restart = (3, 3)
         w.release = (3, 2, 32)
     elif name == "B3":  # not a BASELINE.json config: the C3 voice with a band-limited PolyBlep oscillator; one waveform per

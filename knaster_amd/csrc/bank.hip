@@ -70,6 +70,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* PINK_NOISE  */ {14, 0, 1, 1, 'K', {nullptr}},
     /* BROWN_NOISE */ {3, 0, 1, 1, 'O', {nullptr}},
     /* RANDOM_LIN  */ {6, 1, 2, 1, 'G', {"freq"}},
+    /* PAN2        */ {2, 1, 1, 1, '2', {"pan"}},
 };
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -127,6 +128,39 @@ inline uint32_t sat_u32(double v) {
   if (!(v > 0.0)) return 0u;
   if (v >= 4294967295.0) return 0xFFFFFFFFu;
   return static_cast<uint32_t>(v);
+}
+
+// fastapprox::fast::{sin, cos} (crate fastapprox 0.3.1, Cargo.lock:931 -- a crates.io dependency that is not in the
+// reference tree), called by Pan2::process (pan.rs:34-35).  Restated from the published algorithm (Paul Mineiro's
+// fastapprox, fasttrig.h `fastsin` / `fastcos`, of which the crate is a port): PARITY UNPINNED, DESIGN.md section 2.
+// Every operation is an f32 operation in source order (Rust never contracts a*b+c).
+inline float fastapprox_fast_sin(float x) {
+  const float FOUROVERPI = 1.2732395447351627f, FOUROVERPISQ = 0.40528473456935109f, Q = 0.78444488374548933f;
+  uint32_t p, r, s, vx;
+  const float P = 0.20363937680730309f, R = 0.015124940802184233f, S = -0.0032225901625579573f;
+  std::memcpy(&p, &P, 4); std::memcpy(&r, &R, 4); std::memcpy(&s, &S, 4); std::memcpy(&vx, &x, 4);
+  const uint32_t sign = vx & 0x80000000u;
+  vx &= 0x7FFFFFFFu;
+  float ax;
+  std::memcpy(&ax, &vx, 4);
+  const float qpprox = FOUROVERPI * x - FOUROVERPISQ * x * ax;
+  const float qpproxsq = qpprox * qpprox;
+  p |= sign; r |= sign; s ^= sign;
+  float pf, rf, sf;
+  std::memcpy(&pf, &p, 4); std::memcpy(&rf, &r, 4); std::memcpy(&sf, &s, 4);
+  return Q * qpprox + qpproxsq * (pf + qpproxsq * (rf + qpproxsq * sf));
+}
+inline float fastapprox_fast_cos(float x) {
+  const float HALFPI = 1.5707963267948966f, HALFPIMINUSTWOPI = -4.7123889803846899f;
+  const float offset = x > HALFPI ? HALFPIMINUSTWOPI : HALFPI;
+  return fastapprox_fast_sin(x + offset);
+}
+// Pan2's two gains for a `pan` parameter value (pan.rs:18-23 / :26-29, then :33-35).
+inline void pan2_gains(float pan_param, float* left, float* right) {
+  const float pan = pan_param * 0.5f + 0.5f;
+  const float rad = pan * 1.57079632679489661923132169163975144f;  // core::f32::consts::FRAC_PI_2
+  *left = fastapprox_fast_cos(rad);
+  *right = fastapprox_fast_sin(rad);
 }
 
 template <typename F> struct Consts;
@@ -650,6 +684,12 @@ struct Bank final : knh_bank {
           case KNH_STAGE_WR_POWI:  // WrPowi::new(ugen, value: i32), wrappers_core/math.rs:591-595
             slot(S.slot_base, v) = static_cast<W>(static_cast<uint32_t>(static_cast<int32_t>(a[0])));
             break;
+          case KNH_STAGE_PAN2: {  // Pan2::new(pan: f32), pan.rs:18-23; the gains of process(), :33-35, as F::new(..)
+            float gl, gr;
+            pan2_gains(static_cast<float>(a[0]), &gl, &gr);
+            slot(S.slot_base + 0, v) = fw(static_cast<F>(gl));
+            slot(S.slot_base + 1, v) = fw(static_cast<F>(gr));
+          } break;
           default:  // Constant / wrapper value: util.rs:43-45, wrappers_core/math.rs:21-23
             slot(S.slot_base, v) = fw(static_cast<F>(a[0]));
             break;
@@ -687,7 +727,9 @@ struct Bank final : knh_bank {
       KNH_HIP(hipMemcpy(d_seg_table, seg_rows.data(), seg_rows.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     const size_t n_waves = (nv + 63) / 64;
-    KNH_HIP(hipMalloc(&d_partials, n_waves * bs * sizeof(F)));
+    pan = !signature.empty() && signature.back() == '2';  // a Pan2 ends the chain: every voice has a left and a right signal
+    fold_planes = pan ? 2u : 1u;
+    KNH_HIP(hipMalloc(&d_partials, fold_planes * n_waves * bs * sizeof(F)));
     KNH_HIP(hipMalloc(&d_out, desc.out_channels * bs * sizeof(F)));
     KNH_HIP(hipMemset(d_out, 0, desc.out_channels * bs * sizeof(F)));
     KNH_HIP(hipMalloc(&d_done, static_cast<size_t>(nv) * sizeof(uint32_t)));
@@ -714,9 +756,11 @@ struct Bank final : knh_bank {
     initialised = true;
     return KNH_OK;
   }
+  bool pan = false;          // the chain ends in a Pan2
+  unsigned fold_planes = 1;  // channel planes of the partial rows and of the per-voice output: 2 for a Pan2 chain
   hipError_t ensure_voices() {
     if (d_voices) return hipSuccess;
-    return hipMalloc(&d_voices, static_cast<size_t>(nv) * block_size * sizeof(F));
+    return hipMalloc(&d_voices, static_cast<size_t>(fold_planes) * nv * block_size * sizeof(F));
   }
 
   // ---- parameter changes ----------------------------------------------------------------
@@ -926,6 +970,12 @@ struct Bank final : knh_bank {
         } else {  // Waveform::from(PInteger): out of range -> default (Sawtooth)
           set(3, iv >= 0 && iv < 14 ? static_cast<uint64_t>(iv) : 0u);
         }
+      } break;
+      case KNH_STAGE_PAN2: {  // Pan2::pan(pan: f32), pan.rs:26-29 (the macro hands the PFloat over `as f32`)
+        float gl, gr;
+        pan2_gains(static_cast<float>(f), &gl, &gr);
+        set(0, to_bits(static_cast<F>(gl)));
+        set(1, to_bits(static_cast<F>(gr)));
       } break;
       case KNH_STAGE_RANDOM_LIN: {  // noise.rs:213-221: phase_step = F::new(value) * freq_to_phase_inc
         const F inc = F(1) / static_cast<F>(sample_rate);
@@ -1176,7 +1226,7 @@ struct Bank final : knh_bank {
       KNH_HIP(hipStreamSynchronize(s));
       KNH_HIP(hipFree(d_partials));
       d_partials = nullptr;
-      KNH_HIP(hipMalloc(&d_partials, static_cast<size_t>(n_blocks) * n_waves * block_size * sizeof(F)));
+      KNH_HIP(hipMalloc(&d_partials, static_cast<size_t>(n_blocks) * fold_planes * n_waves * block_size * sizeof(F)));
       partials_blocks = n_blocks;
     }
     if (!out_device && n_blocks > out_blocks) {
@@ -1245,10 +1295,13 @@ struct Bank final : knh_bank {
     }
 
     F* dst = out_device ? static_cast<F*>(out_device) : d_out;
+    // A Pan2 chain's row sets are [block][channel][rows][frame] and its output [block][channel][frame]: the fold sees
+    // twice as many "blocks" of one channel each.
+    const unsigned fold_channels = pan ? 1u : desc.out_channels;
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
-      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), 1, accumulate, flags_next, s));
+      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), fold_planes, accumulate, flags_next, s));
     else
-      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, desc.out_channels, static_cast<unsigned>(block_size), n_blocks, accumulate, flags_next, s));
+      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), n_blocks * fold_planes, accumulate, flags_next, s));
 
     if (!sync) return KNH_OK;
     const size_t blk_elems = desc.out_channels * block_size;
@@ -1257,7 +1310,7 @@ struct Bank final : knh_bank {
     if (out_host) KNH_HIP(hipMemcpyAsync(h_out, dst, out_bytes, hipMemcpyDeviceToHost, s));
     KNH_HIP(hipMemcpyAsync(h_flags, flags_now, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (voices_host)
-      KNH_HIP(hipMemcpyAsync(voices_host, d_voices, static_cast<size_t>(nv) * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
+      KNH_HIP(hipMemcpyAsync(voices_host, d_voices, static_cast<size_t>(fold_planes) * nv * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
     KNH_HIP(hipStreamSynchronize(s));
     if (out_host) {
       if (n_blocks > 1) {
@@ -1378,6 +1431,8 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
       return KNH_ERR_INVALID_ARGUMENT;
     }
     if (st[i].kind == KNH_STAGE_MUL_ENVELOPE && sig->find('V') != std::string::npos) { *why = "at most one Envelope stage per chain"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (st[i].kind == KNH_STAGE_PAN2 && i + 1 != n) { *why = "Pan2 ends the chain: it must be the last stage"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (st[i].kind == KNH_STAGE_PAN2 && st[i].delayed_changes_per_block > 0) { *why = "Pan2 cannot be wrapped in WrPreciseTiming here (its gains change at block boundaries)"; return KNH_ERR_INVALID_ARGUMENT; }
     sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
     have_x = true;
   }
@@ -1520,6 +1575,7 @@ static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh
   std::string sig, why;
   int rc = build_signature(desc->stages, desc->n_stages, &sig, &why);
   if (rc != KNH_OK) { g_create_error = why; return rc; }
+  if (sig.back() == '2' && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
   // a chain without a pre-built kernel is fused at knh_bank_init time (hiprtc); entry == nullptr marks it
   const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
   // the reference's exact mix order (KNH_MIX_LEFT_FOLD) and banks of a single voice group keep one range

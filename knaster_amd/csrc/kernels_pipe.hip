@@ -1,0 +1,64 @@
+// kernels_pipe.hip -- gfx950 instantiations of the wave-specialised (pipelined) voice-bank kernel (voice_pipe.hpp).
+// Built with -ffp-contract=off, as every kernel of the library.
+#include <cstring>
+
+#include "kernel_registry.hpp"
+#include "voice_pipe.hpp"
+
+namespace knh {
+using namespace knh_dev;
+
+// BIG: 64-sample tiles (32 for f64) with the fold done by the last stage group instead of a mixer wavefront
+template <typename F, bool FMA, bool BIG, typename... Gs>
+static hipError_t launch_pipe(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
+  if (n_wavefronts == 0) return hipSuccess;
+  constexpr int T = BIG ? PipeTile<F>::big : PipeTile<F>::value;
+  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, BIG, Gs...>), dim3(n_wavefronts), dim3((sizeof...(Gs) + (BIG ? 0 : 1)) * 64), 0, stream, args);
+  return hipGetLastError();
+}
+#define KNH_PIPE_AS(sig, n, big, ...)                                                               \
+  {sig, n, big, {launch_pipe<float, false, big, __VA_ARGS__>, launch_pipe<float, true, big, __VA_ARGS__>}, \
+   {launch_pipe<double, false, big, __VA_ARGS__>, launch_pipe<double, true, big, __VA_ARGS__>}}
+#define KNH_PIPE(sig, n, ...) KNH_PIPE_AS(sig, n, false, __VA_ARGS__)
+#define KNH_PIPE_BIG(sig, n, ...) KNH_PIPE_AS(sig, n, true, __VA_ARGS__)
+
+typedef Group<SinWt, MulVal> G_Wm;
+typedef Group<SinWt> G_W;
+typedef Group<SinNum> G_N;
+typedef Group<Svf> G_S;
+typedef Group<MulAsr> G_A;
+typedef Group<MulAr> G_E;
+typedef Group<MulAsr, MulVal> G_Am;
+typedef Group<MulVal> G_m;
+typedef Group<SinWt, MulVal, AddVal> G_Wma;
+typedef Group<SinWtAr, MulVal> G_Rm;
+typedef Group<SampleDelay, MulAsr> G_DA;
+typedef Group<PolyBlepOsc, MulVal> G_Bm;
+typedef Group<MulAr, Pan2> G_E2;
+typedef Group<MulAsr, Pan2> G_A2;
+
+static const PipeEntry kPipes[] = {
+    KNH_PIPE_BIG("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope + fold, 64-sample tiles
+    KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),       // the same with 32-sample tiles and a mixer wavefront (KNH_PIPE_BIG=0)
+    KNH_PIPE_BIG("WSAm", 3, G_W, G_S, G_Am),
+    KNH_PIPE("WSAm", 3, G_W, G_S, G_Am),
+    KNH_PIPE_BIG("WSA", 3, G_W, G_S, G_A),
+    KNH_PIPE("WSA", 3, G_W, G_S, G_A),
+    KNH_PIPE("WS", 2, G_W, G_S),
+    KNH_PIPE("WmaRm", 2, G_Wma, G_Rm),     // C5: modulator | carrier
+    KNH_PIPE("Nm", 2, G_N, G_m),           // C2
+    KNH_PIPE("NSAm", 3, G_N, G_S, G_Am),
+    KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA),  // the delay's HBM traffic rides in the envelope wave
+    KNH_PIPE("BmSA", 3, G_Bm, G_S, G_A),
+    KNH_PIPE_BIG("WmE2", 2, G_Wm, G_E2),     // many_sines: oscillator | envelope + pan + fold
+    KNH_PIPE("WmE2", 2, G_Wm, G_E2),
+    KNH_PIPE_BIG("WmSA2", 3, G_Wm, G_S, G_A2),
+    KNH_PIPE("WmSA2", 3, G_Wm, G_S, G_A2),
+};
+const PipeEntry* find_pipe(const char* signature, bool allow_big) {
+  for (const PipeEntry& e : kPipes)
+    if (std::strcmp(e.signature, signature) == 0 && (allow_big || !e.big)) return &e;
+  return nullptr;
+}
+
+}  // namespace knh

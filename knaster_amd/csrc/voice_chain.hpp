@@ -1564,6 +1564,40 @@ struct PowiVal {
   }
 };
 
+// Pan2 -- knaster_core_dsp/src/ugens/pan.rs:12-37: [x * left_gain, x * right_gain] with the two gains a function of the
+// `pan` parameter alone (fastapprox::fast::cos / sin of pan' * pi/2, recomputed by the reference every sample from the
+// stored pan: the same two numbers each time), so they are computed on the host (bank.hip) and live here as two words.
+// The stage is the END of a chain: the running signal passes through unchanged and the two products are formed where a
+// voice's signal leaves the chain, in the per-wave fold (left = ((x0*l0 + x1*l1) + x2*l2) + ..., the reference's
+// Pan2 outputs summed by its chain of Add nodes, one chain per output channel).  Gains change at block boundaries
+// only (the stage cannot be wrapped in WrPreciseTiming here), which are tile boundaries in every kernel form.
+// slots: 0 left_gain  1 right_gain
+struct Pan2 {
+  static constexpr int kSlots = 2;
+  static constexpr u32 kMutableMask = 0u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs { F l, r; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) { r.l = word_to_f<F>(s[0]); r.r = word_to_f<F>(s[st]); }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>&, F x, const Ctx&, u32, u32&) { return x; }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>&, F (&)[T], const Ctx&, u32, u32&) {}
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    const F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel == 0) r.l = v; else r.r = v;
+  }
+};
+template <typename S> struct IsPan { static constexpr bool value = false; };
+template <> struct IsPan<Pan2> { static constexpr bool value = true; };
+
 // ---------------------------------------------------------------------------
 // Chain = compile-time stage list with all registers inline.
 // ---------------------------------------------------------------------------
@@ -1572,6 +1606,8 @@ template <typename F, bool FMA, int BASE>
 struct Chain<F, FMA, BASE> {
   static constexpr int kSlots = BASE;
   static constexpr bool kUsesSine = false;
+  static constexpr bool kPan = false;
+  __device__ __forceinline__ void pan_gains(F&, F&) const {}
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
   template <typename W> __device__ __forceinline__ void store(W*, long) const {}
   __device__ __forceinline__ F tick(F x, const Ctx&, u32) { return x; }
@@ -1586,6 +1622,7 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   typedef Chain<F, FMA, BASE + S0::kSlots, Rest...> RestT;
   static constexpr int kSlots = RestT::kSlots;
   static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
+  static constexpr bool kPan = IsPan<S0>::value || RestT::kPan;  // the chain ends in a Pan2: two output channels per voice
   typename S0::template Regs<F> r;
   // The frame this stage last passed to mark_done (UGenFlags::mark_done, ugen.rs:199-202), 0xFFFFFFFF: never.  The
   // reference hands one UGenFlags to every task of a block in node order (graph_gen.rs:196-200), so the mark a voice
@@ -1611,6 +1648,10 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   __device__ __forceinline__ u32 collect_done(u32 acc) const {
     if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
     return rest.collect_done(acc);
+  }
+  __device__ __forceinline__ void pan_gains(F& l, F& rg) const {
+    if constexpr (IsPan<S0>::value) { l = r.l; rg = r.r; }
+    else rest.pan_gains(l, rg);
   }
   __device__ __forceinline__ void on_event(u32 op, u32 slot, u64 bits, u32 frame) {
     if (slot >= (u32)BASE && slot < (u32)(BASE + S0::kSlots)) S0::template on_event<F>(r, op, slot - BASE, bits, frame);
@@ -1649,7 +1690,8 @@ struct VoiceKernelArgs {
   const u32* ev_start;              // [n_voices + 1] or null when the block has no events
   const Event* events;
   F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its 64 voices
-  F* voices_out;                    // [n_voices][block_size] or null (n_blocks == 1 only)
+                                    // (chains ending in Pan2: [n_blocks][2][n_waves][block_size], left and right)
+  F* voices_out;                    // [n_voices][block_size] or null (n_blocks == 1 only); Pan2 chains: [2][n_voices][block_size]
   u32* done_frames;                 // [n_voices]
   u32* flags;                       // [0] |= any-done, [1] += voices whose last envelope is not Stopped
 };
@@ -1670,6 +1712,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
                                                 // writes (ds_write_b32) and row reads (ds_read_b128)
   __shared__ float sine[ChainT::kUsesSine ? 16384 : 1];
   __shared__ __attribute__((aligned(16))) F tile[WAVES][TN][TS];
+  __shared__ __attribute__((aligned(16))) F pan_gain[ChainT::kPan ? WAVES : 1][2][ChainT::kPan ? 64 : 1];  // [wave][left, right][voice]
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -1755,28 +1798,59 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
       }
       // Transposed reduce: lane j folds frame j over the wave's voices in voice order.
       // (same-wave LDS traffic: program order is enough, no barrier needed)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      if ((u32)lane < len) {
-        F acc;
-        if (nv == 64u) {  // full wavefront: 16 LDS reads in flight ahead of the serial adds
-#pragma unroll
-          for (int vb = 0; vb < 64; vb += 16) {
-            F t[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = my[lane][vb + k];
-            if (vb == 0) acc = t[0];
-#pragma unroll
-            for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
-          }
-        } else {
-          acc = my[lane][0];
-          for (u32 v = 1; v < nv; ++v) acc = acc + my[lane][v];
-        }
-        partial_row[n0 + lane] = acc;
+      if constexpr (ChainT::kPan) {
+        F gl = (F)0, gr = (F)0;
+        chain.pan_gains(gl, gr);
+        pan_gain[wave][0][lane] = gl;
+        pan_gain[wave][1][lane] = gr;
       }
-      if (a.voices_out) {
-        for (u32 v = 0; v < nv; ++v)
-          if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[lane][v];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if constexpr (!ChainT::kPan) {
+        if ((u32)lane < len) {
+          F acc;
+          if (nv == 64u) {  // full wavefront: 16 LDS reads in flight ahead of the serial adds
+#pragma unroll
+            for (int vb = 0; vb < 64; vb += 16) {
+              F t[16];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) t[k] = my[lane][vb + k];
+              if (vb == 0) acc = t[0];
+#pragma unroll
+              for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
+            }
+          } else {
+            acc = my[lane][0];
+            for (u32 v = 1; v < nv; ++v) acc = acc + my[lane][v];
+          }
+          partial_row[n0 + lane] = acc;
+        }
+        if (a.voices_out) {
+          for (u32 v = 0; v < nv; ++v)
+            if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[lane][v];
+        }
+      } else {
+        // Pan2: each voice's sample times its two gains (two roundings, then the adds: pan.rs:36 and the Add chain)
+        if ((u32)lane < len) {
+          const F* gl = pan_gain[wave][0];
+          const F* gr = pan_gain[wave][1];
+          F accl = my[lane][0] * gl[0], accr = my[lane][0] * gr[0];
+          for (u32 v = 1; v < nv; ++v) {
+            const F t = my[lane][v];
+            accl = mad<FMA>(t, gl[v], accl);
+            accr = mad<FMA>(t, gr[v], accr);
+          }
+          F* pl = a.partials + (((long)b * 2 + 0) * n_waves_total + wave_global) * a.block_size;
+          F* pr = a.partials + (((long)b * 2 + 1) * n_waves_total + wave_global) * a.block_size;
+          pl[n0 + lane] = accl;
+          pr[n0 + lane] = accr;
+          if (a.voices_out) {
+            for (u32 v = 0; v < nv; ++v) {
+              const F t = my[lane][v];
+              a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = t * gl[v];
+              a.voices_out[((long)a.n_voices + v0 + v) * a.block_size + n0 + lane] = t * gr[v];
+            }
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }

@@ -21,6 +21,7 @@ template <typename... S> struct GroupInfo<Group<S...>> {
   static constexpr int slots = (0 + ... + S::kSlots);
   static constexpr bool uses_sine = (false || ... || S::kUsesSine);
   static constexpr bool has_env = (false || ... || S::kIsEnv);
+  static constexpr bool pan = (false || ... || IsPan<S>::value);  // the group ends the chain with a Pan2
 };
 template <typename F, bool FMA, int BASE, typename G> struct GroupChain;
 template <typename F, bool FMA, int BASE, typename... S> struct GroupChain<F, FMA, BASE, Group<S...>> {
@@ -50,6 +51,10 @@ template <typename F> struct PipeShared {
   float* sine;
   F* edge;  // [NG][2][64][stride]; edge i carries group i's output, the last one to the mixer (FOLD: one private buffer)
 };
+
+template <typename F, bool FMA, int T, bool PAN>
+__device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 n_waves_total,
+                                               int blk, u32 n0, u32 len, u32 v0, u32 nv);
 
 // One stage group = one wavefront.  I: group index, NG: number of chain groups (mixer excluded),
 // LAST_ENV: index of the group holding the chain's last envelope stage (-1: none).
@@ -168,11 +173,18 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
             out_row[j] = chain.tick(v, ctx, n + j);
           }
         }
+        if constexpr (GroupInfo<G>::pan) {
+          // Pan2: the voice's two gains ride in the padding of its row (elements T, T + 1), beside the samples they scale
+          F gl = (F)0, gr = (F)0;
+          chain.pan_gains(gl, gr);
+          out_row[T] = gl;
+          out_row[T + 1] = gr;
+        }
 #ifdef KNH_DAG_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const u64 tf0 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (FOLDS) pipe_fold_tile<F, T>(out_tile, a, lane, wave_global, n_waves_total, blk, n, m, v0, nv);
+        if constexpr (FOLDS) pipe_fold_tile<F, FMA, T, GroupInfo<G>::pan>(out_tile, a, lane, wave_global, n_waves_total, blk, n, m, v0, nv);
 #ifdef KNH_DAG_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         busy_fold += __builtin_amdgcn_s_memtime() - tf0;
@@ -222,35 +234,72 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
 // Lane j folds frame j of a finished tile over the wave's voices, in voice order (a left fold, like the reference's
 // chain of Add nodes over those voices).  The tile is stored voice-major ([voice][T], the common edge format), so a
 // read of one voice's row by lanes 0..T-1 is conflict-free and the transposition costs nothing.
-template <typename F, int T>
+template <typename F, bool FMA, int T, bool PAN>
 __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 n_waves_total,
                                                int blk, u32 n0, u32 len, u32 v0, u32 nv) {
   constexpr int ST = EdgeLayout<F, T>::stride;
   if ((u32)lane < len) {
     const F* col = tile + lane;
-    F acc;
-    if (nv == 64u) {
-      // all 64 reads go out before the first add: the LDS latency is paid once, not once per group of rows
-      // (the adds are one dependent chain whatever is done, in voice order)
-      F t[64];
+    if constexpr (!PAN) {
+      F acc;
+      if (nv == 64u) {
+        // all 64 reads go out before the first add: the LDS latency is paid once, not once per group of rows
+        // (the adds are one dependent chain whatever is done, in voice order)
+        F t[64];
 #pragma unroll
-      for (int k = 0; k < 64; ++k) t[k] = col[k * ST];
-      acc = t[0];
+        for (int k = 0; k < 64; ++k) t[k] = col[k * ST];
+        acc = t[0];
 #pragma unroll
-      for (int k = 1; k < 64; ++k) acc = acc + t[k];
+        for (int k = 1; k < 64; ++k) acc = acc + t[k];
+      } else {
+        acc = col[0];
+        for (u32 v = 1; v < nv; ++v) acc = acc + col[v * ST];
+      }
+      a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
+      if (a.voices_out) {
+        for (u32 v = 0; v < nv; ++v) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = col[v * ST];
+      }
     } else {
-      acc = col[0];
-      for (u32 v = 1; v < nv; ++v) acc = acc + col[v * ST];
-    }
-    a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
-    if (a.voices_out) {
-      for (u32 v = 0; v < nv; ++v) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = col[v * ST];
+      // Pan2 (pan.rs:31-36): voice v contributes x * left_gain to channel 0 and x * right_gain to channel 1; each
+      // channel is the left fold of those products in voice order (its own chain of Add nodes, graph.rs:850-864).
+      // The gains sit in the padding of the voice's row: every lane reads the same word (a broadcast).
+      const F* gain = tile + T;
+      F accl, accr;
+      if (nv == 64u) {
+        F t[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) t[k] = col[k * ST];
+        accl = t[0] * gain[0];
+        accr = t[0] * gain[1];
+#pragma unroll
+        for (int k = 1; k < 64; ++k) {
+          accl = mad<FMA>(t[k], gain[k * ST], accl);
+          accr = mad<FMA>(t[k], gain[k * ST + 1], accr);
+        }
+      } else {
+        accl = col[0] * gain[0];
+        accr = col[0] * gain[1];
+        for (u32 v = 1; v < nv; ++v) {
+          const F t = col[v * ST];
+          accl = mad<FMA>(t, gain[v * ST], accl);
+          accr = mad<FMA>(t, gain[v * ST + 1], accr);
+        }
+      }
+      a.partials[(((long)blk * 2 + 0) * n_waves_total + wave_global) * a.block_size + n0 + lane] = accl;
+      a.partials[(((long)blk * 2 + 1) * n_waves_total + wave_global) * a.block_size + n0 + lane] = accr;
+      if (a.voices_out) {
+        for (u32 v = 0; v < nv; ++v) {
+          const F t = col[v * ST];
+          a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = t * gain[v * ST];
+          a.voices_out[((long)a.n_voices + v0 + v) * a.block_size + n0 + lane] = t * gain[v * ST + 1];
+        }
+      }
     }
   }
 }
 
 // The mixer wavefront: folds the tile the last chain group finished in the previous step.
-template <typename F, int T, int NG>
+template <typename F, bool FMA, int T, int NG, bool PAN>
 __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global,
                                                u32 v0, u32 nv) {
   const u32 n_frames = a.frame_end - a.frame_begin;
@@ -271,7 +320,7 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
       const u32 rel = (u32)ti * T;
       const u32 len = n_frames - rel < (u32)T ? n_frames - rel : (u32)T;
       const F* tile = sh.edge + (long)((NG - 1) * 2 + (g & 1)) * EdgeLayout<F, T>::tile;
-      pipe_fold_tile<F, T>(tile, a, lane, wave_global, n_waves_total, blk, a.frame_begin + rel, len, v0, nv);
+      pipe_fold_tile<F, FMA, T, PAN>(tile, a, lane, wave_global, n_waves_total, blk, a.frame_begin + rel, len, v0, nv);
       if (++ti == tpb) { ti = 0; ++blk; }
 #ifdef KNH_DAG_STAMPS
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -331,7 +380,8 @@ __global__ void __launch_bounds__((sizeof...(Gs) + (FOLD ? 0 : 1)) * 64) voice_p
   const u32 v0 = wave_global * 64u;
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
   u32 done_frame = 0xFFFFFFFFu;
-  if (wave == NG) pipe_run_mixer<F, T, NG>(sh, a, lane, wave_global, v0, nv);
+  constexpr bool kPan = (false || ... || GroupInfo<Gs>::pan);
+  if (wave == NG) pipe_run_mixer<F, FMA, T, NG, kPan>(sh, a, lane, wave_global, v0, nv);
   else done_frame = pipe_dispatch<F, FMA, T, FOLD, NG, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
   // mark_done of a voice = that of the last node in task order that set one: combine the groups in chain order
   constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);

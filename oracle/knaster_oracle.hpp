@@ -11,6 +11,9 @@
 //     arithmetic, WrPreciseTiming sequences, MathUGen, graph plumbing,
 //     additive outputs, disconnect, bench asserts, Seconds conversions,
 //     the implement_a_gen sine check.
+//   * PARITY UNPINNED for Pan2's gains (fastapprox::fast::cos/sin, an un-vendored
+//     crate, restated from its published algorithm) and for the noise UGens'
+//     generator (fastrand, likewise).
 //   * PARITY UNPINNED for the waveform-level output of SinWt, SinNumeric,
 //     SvfFilter, OnePole*, EnvAsr, EnvAr: no reference test or fixture pins
 //     those numbers and no Rust toolchain exists in the build image, so those
@@ -1337,6 +1340,65 @@ struct SafetyLimiter : UGen<F> {
     out[0] = std::isnan(s) ? F(0) : s;
   }
   void param_apply(AudioCtx&, size_t, ParameterValue) override {}
+};
+
+// ---------------------------------------------------------------------------
+// Pan2 -- knaster_core_dsp/src/ugens/pan.rs:12-37.  One input, two outputs; the gains come from
+// `fastapprox::fast::{cos, sin}` (Cargo.lock:931, fastapprox 0.3.1 -- a crates.io dependency that is NOT in the
+// reference tree).  PARITY UNPINNED: the two functions are restated from the algorithm the crate ports (P. Mineiro's
+// fastapprox, fasttrig.h: `fastsin` is a parabola q = 4/pi x - 4/pi^2 x|x| refined by an odd polynomial in q whose
+// coefficients take the sign of x by bit operations; `fastcos(x) = fastsin(x + pi/2)`, wrapped by -3pi/2 above pi/2);
+// no reference test holds a Pan2 output.  Anchored on the call site: pan stored as pan * 0.5 + 0.5 (:20,:28), the
+// angle pan * FRAC_PI_2 in f32 (:33), gains cast with F::new (:34-35), out = [x * left, x * right] (:36).
+// ---------------------------------------------------------------------------
+namespace fastapprox_fast {
+inline float bits_to_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint32_t f_to_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float sin(float x) {
+  const float fouroverpi = 1.2732395447351627f;
+  const float fouroverpisq = 0.40528473456935109f;
+  const float q = 0.78444488374548933f;
+  uint32_t p = f_to_bits(0.20363937680730309f);
+  uint32_t r = f_to_bits(0.015124940802184233f);
+  uint32_t s = f_to_bits(-0.0032225901625579573f);
+  const uint32_t vx = f_to_bits(x);
+  const uint32_t sign = vx & 0x80000000u;
+  const float abs_x = bits_to_f(vx & 0x7FFFFFFFu);
+  const float qpprox = fouroverpi * x - fouroverpisq * x * abs_x;
+  const float qpproxsq = qpprox * qpprox;
+  p |= sign;
+  r |= sign;
+  s ^= sign;
+  return q * qpprox + qpproxsq * (bits_to_f(p) + qpproxsq * (bits_to_f(r) + qpproxsq * bits_to_f(s)));
+}
+inline float cos(float x) {
+  const float halfpi = 1.5707963267948966f;
+  const float halfpiminustwopi = -4.7123889803846899f;
+  const float offset = (x > halfpi) ? halfpiminustwopi : halfpi;
+  return sin(x + offset);
+}
+}  // namespace fastapprox_fast
+
+template <typename F>
+struct Pan2 : UGen<F> {
+  float pan;
+  explicit Pan2(float p) : pan(p * 0.5f + 0.5f) {}  // :18-23
+  size_t inputs() const override { return 1; }
+  size_t outputs() const override { return 2; }
+  size_t parameters() const override { return 1; }
+  std::vector<std::string> param_descriptions() const override { return {"pan"}; }
+  void process(AudioCtx&, UGenFlags&, const F* in, F* out) override {  // :31-37
+    const F signal = in[0];
+    const float pan_pos_radians = pan * 1.57079632679489661923132169163975144f;
+    const F left_gain = fnew<F>(fastapprox_fast::cos(pan_pos_radians));
+    const F right_gain = fnew<F>(fastapprox_fast::sin(pan_pos_radians));
+    out[0] = signal * left_gain;
+    out[1] = signal * right_gain;
+  }
+  void param_apply(AudioCtx& ctx, size_t index, ParameterValue value) override {
+    if (index == 0) pan = static_cast<float>(value.f) * 0.5f + 0.5f;  // :26-29 (`pan: f32`: the macro casts the PFloat)
+    else ctx.rt_log("Unknown parameter set for Pan2");
+  }
 };
 
 // ---------------------------------------------------------------------------

@@ -30,6 +30,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_BUFFER_READER: return 3;
     case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: return 1;
     case KNH_STAGE_RANDOM_LIN: return 2;
+    case KNH_STAGE_PAN2: return 1;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -86,6 +87,10 @@ struct VoiceChainBuilder {
           core = std::make_unique<PolyBlep<F>>(waveform_from_pinteger(a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u), fnew<F>(a[1]));
           break;
         case KNH_STAGE_SAFETY_LIMITER: core = std::make_unique<SafetyLimiter<F>>(); break;
+        case KNH_STAGE_PAN2:
+          if (s + 1 != stages.size()) throw std::runtime_error("Pan2 must be the last stage");
+          core = std::make_unique<Pan2<F>>(static_cast<float>(a[0]));
+          break;
         case KNH_STAGE_ALLPASS_FB_DELAY: core = std::make_unique<AllpassFeedbackDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_ALLPASS_DELAY: core = std::make_unique<AllpassDelay<F>>(Seconds::from_secs_f64(a[0])); break;
         case KNH_STAGE_SAMPLE_DELAY: core = std::make_unique<SampleDelay<F>>(Seconds::from_secs_f64(a[0])); break;
@@ -215,29 +220,34 @@ struct OracleBank {
       for (uint32_t s = 0; s < n_stages; ++s) ctor[v][s].assign(static_cast<size_t>(std::max(0, stage_n_ctor_args(stages[s].kind))), 0.0);
   }
   std::shared_ptr<Buffer<F>> buffer;
+  // A chain that ends in Pan2: `(voice >> pan).to_graph_out()` (many_sines.rs:59-60) -- the node's outputs 0 and 1
+  // go to graph outputs 0 and 1, and every voice has two signals: voice_block is [2][n_voices][block_size].
+  bool pan() const { return !stages.empty() && stages.back().kind == KNH_STAGE_PAN2; }
   void init(uint32_t sr, size_t bs) {
     sample_rate = sr;
     block_size = bs;
     VoiceChainBuilder<F> b(stages);
     b.buffer = buffer;
+    if (pan() && out_channels != 2) throw std::runtime_error("a chain ending in Pan2 has two output channels");
     if (want_mix) {
       mix_graph = std::make_unique<Graph<F>>(0, out_channels, bs, sr);
       mix_targets.resize(n_voices);
       for (uint32_t v = 0; v < n_voices; ++v) {
         NodeKey x = b.build(*mix_graph, ctor[v], mix_targets[v]);
-        for (uint32_t c = 0; c < out_channels; ++c) mix_graph->connect_to_output(x, 0, static_cast<uint16_t>(c), true);
+        for (uint32_t c = 0; c < out_channels; ++c) mix_graph->connect_to_output(x, pan() ? static_cast<uint16_t>(c) : 0, static_cast<uint16_t>(c), true);
       }
       mix_graph->commit_changes();
     }
     if (want_voices) {
       voice_targets.resize(n_voices);
+      const uint16_t planes = pan() ? 2 : 1;
       for (uint32_t v = 0; v < n_voices; ++v) {
-        voice_graphs.push_back(std::make_unique<Graph<F>>(0, 1, bs, sr));
+        voice_graphs.push_back(std::make_unique<Graph<F>>(0, planes, bs, sr));
         NodeKey x = b.build(*voice_graphs[v], ctor[v], voice_targets[v]);
-        voice_graphs[v]->connect_to_output(x, 0, 0, true);
+        for (uint16_t c = 0; c < planes; ++c) voice_graphs[v]->connect_to_output(x, c, c, true);
         voice_graphs[v]->commit_changes();
       }
-      voice_block.assign(static_cast<size_t>(n_voices) * bs, F(0));
+      voice_block.assign(static_cast<size_t>(planes) * n_voices * bs, F(0));
       done_frames.assign(n_voices, 0xFFFFFFFFu);
     }
   }
@@ -285,8 +295,16 @@ struct OracleBank {
       if (mix_graph->last_flags.done_) flags |= KNH_FLAG_ANY_DONE;
     }
     if (want_voices) {
+      std::vector<F> lr;
+      if (pan()) lr.resize(2 * block_size);
       for (uint32_t v = 0; v < n_voices; ++v) {
-        voice_graphs[v]->run({}, voice_block.data() + static_cast<size_t>(v) * block_size);
+        if (pan()) {  // [left][right] of this voice -> the two planes
+          voice_graphs[v]->run({}, lr.data());
+          std::copy(lr.begin(), lr.begin() + block_size, voice_block.begin() + static_cast<size_t>(v) * block_size);
+          std::copy(lr.begin() + block_size, lr.end(), voice_block.begin() + (static_cast<size_t>(n_voices) + v) * block_size);
+        } else {
+          voice_graphs[v]->run({}, voice_block.data() + static_cast<size_t>(v) * block_size);
+        }
         uint32_t f = 0xFFFFFFFFu;
         done_frames[v] = voice_graphs[v]->last_flags.done(&f) ? f : 0xFFFFFFFFu;
         if (done_frames[v] != 0xFFFFFFFFu) flags |= KNH_FLAG_ANY_DONE;

@@ -164,9 +164,11 @@ class OracleBank:
         self._check(self._lib.kno_bank_schedule(self._h, voice, stage, param, k, f, i, time_mode, seconds, tesimals))
 
     def process_block(self):
-        """-> (out [ch, B], voices [N, B] or None, flags, done_frames or None)"""
+        """-> (out [ch, B], voices [N, B] ([2, N, B] for a chain ending in Pan2) or None, flags, done_frames or None)"""
         out = np.zeros((self.out_channels, self.block_size), dtype=self.dtype)
-        voices = np.zeros((self.n_voices, self.block_size), dtype=self.dtype) if self.want_voices else None
+        pan = bool(self.stages) and self.stages[-1].kind == 32  # KNH_STAGE_PAN2
+        shape = (2, self.n_voices, self.block_size) if pan else (self.n_voices, self.block_size)
+        voices = np.zeros(shape, dtype=self.dtype) if self.want_voices else None
         done = np.zeros(self.n_voices, dtype=np.uint32) if self.want_voices else None
         flags = C.c_uint32(0)
         self._check(self._lib.kno_bank_process_block(

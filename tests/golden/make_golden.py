@@ -28,6 +28,7 @@ CASES = {
     "c3_chain_f32": ("C3", 24, 96, 5),
     "c4_chain_f64": ("C4", 10, 64, 5),
     "c5_fm_events": ("C5", 16, 128, 4),
+    "m1_many_sines_pan2": ("M1", 20, 64, 5),  # voices: [block][2][voice][frame] (left, right)
 }
 
 
@@ -41,6 +42,13 @@ def script(case: str, w, block: int, bank):
             bank.param_apply_many(v[::2], 3, 2, L.VALUE_TRIGGER)
         if block == 3:
             bank.param_apply_many(v, 2, 0, L.VALUE_FLOAT, 300.0 + 50.0 * v)
+    if w.name == "M1":  # many_sines.rs:64-92: new frequencies and envelope restarts while running; here also new pans
+        if block in (0, 3):
+            bank.param_apply_many(v, 2, 2, L.VALUE_TRIGGER)
+        if block == 1:
+            bank.param_apply_many(v[::3], 0, 0, L.VALUE_FLOAT, 110.0 * (1 + v[::3] % 7))
+        if block == 2:
+            bank.param_apply_many(v[1::2], 3, 0, L.VALUE_FLOAT, np.linspace(-1.0, 1.0, len(v[1::2])))
     if w.name == "C5":
         e = configs.c5_events(w, block)
         if e is not None:

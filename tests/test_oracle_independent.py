@@ -356,3 +356,61 @@ def test_noise_generator_is_the_stated_wyrand(oracle):
             old = np.float32(value + width); value, width, phase = old, np.float32(d[k] - old), np.float32(0); k += 1
     assert np.array_equal(got, np.array(ref, dtype=np.float32)) and k > 100
     assert got.min() >= 0.0 and got.max() < 1.0
+
+
+def _fast_sin_np(x):
+    """fastapprox `fastsin` as published (fasttrig.h), in numpy float32 scalars -- an independent restatement."""
+    f = np.float32
+    x = f(x)
+    q = f(1.2732395447351627) * x - f(0.40528473456935109) * x * f(abs(x))
+    q2 = q * q
+    sgn = f(-1.0) if np.signbit(x) else f(1.0)
+    p, r, s = f(0.20363937680730309) * sgn, f(0.015124940802184233) * sgn, f(-0.0032225901625579573) * sgn  # p |= sign, r |= sign, s ^= sign
+    return f(0.78444488374548933) * q + q2 * (p + q2 * (r + q2 * s))
+
+
+def _fast_cos_np(x):
+    f = np.float32
+    x = f(x)
+    off = f(-4.7123889803846899) if x > f(1.5707963267948966) else f(1.5707963267948966)
+    return _fast_sin_np(x + off)
+
+
+def test_pan2_gains_follow_the_stated_fastapprox(oracle):
+    """Pan2 (pan.rs:12-37): out = [x * fast::cos(p), x * fast::sin(p)], p = (pan * 0.5 + 0.5) * FRAC_PI_2.  fastapprox is
+    not vendored with the reference (parity unpinned): this pins the oracle to the algorithm as stated, checks that the
+    stated algorithm is a sine/cosine to its advertised accuracy, and that the pan law has constant power."""
+    pans = np.linspace(-1.0, 1.0, 41)
+    n = len(pans)
+    w = configs.Workload("pan", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_ADD_CONST), Stage(L.STAGE_PAN2)], n, 8, L.F32, 2)
+    w.ctor = {0: np.zeros((n, 1)), 1: np.ones((n, 1)), 2: pans.reshape(n, 1)}  # a constant 1.0 through the panner: the gains themselves
+    o = make_oracle(oracle, w)
+    _, voices, _, _ = o.process_block()
+    assert voices.shape == (2, n, 8)
+    for i, pan in enumerate(pans):
+        p = np.float32(np.float32(pan) * np.float32(0.5) + np.float32(0.5)) * np.float32(np.pi / 2)
+        gl, gr = _fast_cos_np(p), _fast_sin_np(p)
+        assert np.all(voices[0, i] == gl) and np.all(voices[1, i] == gr), (pan, voices[:, i, 0], gl, gr)
+        assert abs(float(gl) - np.cos(float(p))) < 2e-4 and abs(float(gr) - np.sin(float(p))) < 2e-4  # fastapprox's accuracy class
+        assert abs(float(gl) ** 2 + float(gr) ** 2 - 1.0) < 1e-3                                           # cos/sin pan law
+    # the `pan` parameter (index 0) replaces the gains from the next block on
+    o.param_apply(3, 2, 0, 1.0)
+    _, voices, _, _ = o.process_block()
+    p = np.float32(1.0) * np.float32(np.pi / 2)
+    assert np.all(voices[0, 3] == _fast_cos_np(p)) and np.all(voices[1, 3] == _fast_sin_np(p))
+    o.close()
+
+
+def test_pan2_mix_is_one_left_fold_per_channel(oracle):
+    w = configs.config("M1", n_voices=9, block_size=32)
+    o = make_oracle(oracle, w)
+    o.param_apply_many(np.arange(9, dtype=np.uint32), 2, 2, L.VALUE_TRIGGER)
+    for _ in range(2):
+        out, voices, _, _ = o.process_block()
+        for c in range(2):
+            acc = voices[c, 0].copy()
+            for v in range(1, 9):
+                acc = (acc + voices[c, v]).astype(np.float32)
+            assert_bit_equal(out[c], acc, f"channel {c}")
+        assert np.abs(out[0] - out[1]).max() > 0  # a real stereo image
+    o.close()
