@@ -96,6 +96,7 @@ struct UGenSpec {
   bool ar_params_ = false, smooth_params_ = false;
   uint16_t precise_timing_ = 0;
   bool is_constant = false, is_env = false;
+  uint16_t outputs = 1;              // UGen::Outputs (Pan2: 2)
   // wrappers_core.rs:26-111
   UGenSpec wr_mul(double v) && { wrappers.emplace_back(KNH_STAGE_WR_MUL, v); return std::move(*this); }
   UGenSpec wr_add(double v) && { wrappers.emplace_back(KNH_STAGE_WR_ADD, v); return std::move(*this); }
@@ -115,6 +116,8 @@ inline UGenSpec SinNumeric(double freq) { return UGenSpec(KNH_STAGE_SIN_NUMERIC,
 inline UGenSpec PolyBlep(int waveform, double freq) { return UGenSpec(KNH_STAGE_POLYBLEP, {static_cast<double>(waveform), freq}); }
 inline UGenSpec Phasor(double freq) { return UGenSpec(KNH_STAGE_PHASOR, {freq}); }        // osc.rs:172-214
 inline UGenSpec SafetyLimiter() { return UGenSpec(KNH_STAGE_SAFETY_LIMITER, {}); }        // dynamics.rs:9-31
+// Pan2::new(pan) -- pan.rs:18-23: one input, two outputs; `(voice >> pan).to_graph_out()` sends them to graph outputs 0 and 1
+inline UGenSpec Pan2(double pan) { UGenSpec s(KNH_STAGE_PAN2, {pan}); s.outputs = 2; return s; }
 // noise.rs:11-22: every randomness UGen takes its seed from one process-wide counter, in construction order, so a
 // graph built in the same order makes the same noise.  WhiteNoise / PinkNoise / BrownNoise::new() -- noise.rs:33,65,133
 inline uint64_t next_randomness_seed() {
@@ -194,7 +197,8 @@ struct ChainPlan {
 template <typename F>
 class Sig {  // SH / DH of graph_edit.rs:266-277: one or more output channels of nodes
  public:
-  Sig(GraphEdit<F>* g, std::vector<int> nodes) : g_(g), nodes_(std::move(nodes)) {}
+  Sig(GraphEdit<F>* g, std::vector<int> nodes) : g_(g), nodes_(std::move(nodes)), chans_(nodes_.size(), 0) {}
+  Sig(GraphEdit<F>* g, std::vector<int> nodes, std::vector<int> chans) : g_(g), nodes_(std::move(nodes)), chans_(std::move(chans)) {}
   Sig operator*(double c) const { return g_->math_const(*this, KNH_STAGE_MUL_CONST, c); }
   Sig operator+(double c) const { return g_->math_const(*this, KNH_STAGE_ADD_CONST, c); }
   Sig operator-(double c) const { return g_->math_const(*this, KNH_STAGE_SUB_CONST, c); }
@@ -204,16 +208,18 @@ class Sig {  // SH / DH of graph_edit.rs:266-277: one or more output channels of
   Sig operator>>(const Sig& sink) const { return g_->connect(*this, sink); }  // graph_edit.rs:1347-1417
   // .out([0,0]): the same channel twice (graph_edit.rs:280-292)
   Sig out(std::initializer_list<int> channels) const {
-    std::vector<int> n;
+    std::vector<int> n, ch;
     for (int c : channels) {
       if (c < 0 || c >= static_cast<int>(nodes_.size())) throw GraphError("out(): channel out of range");
       n.push_back(nodes_[static_cast<size_t>(c)]);
+      ch.push_back(chans_[static_cast<size_t>(c)]);
     }
-    return Sig(g_, n);
+    return Sig(g_, n, ch);
   }
   void to_graph_out() const { g_->to_graph_out(*this); }  // additive (graph_edit.rs:363-369)
   int node() const { return nodes_.at(0); }
   const std::vector<int>& nodes() const { return nodes_; }
+  const std::vector<int>& channels() const { return chans_; }  // output channel of nodes()[i] that channel i of this handle carries
 
   // node.param("freq") -> Parameter (graph_edit.rs:761, 1700-1886)
   class Parameter {
@@ -240,7 +246,7 @@ class Sig {  // SH / DH of graph_edit.rs:266-277: one or more output channels of
 
  private:
   GraphEdit<F>* g_;
-  std::vector<int> nodes_;
+  std::vector<int> nodes_, chans_;
 };
 
 inline const char* const* stage_param_names(uint16_t kind, int* n) {
@@ -255,6 +261,7 @@ inline const char* const* stage_param_names(uint16_t kind, int* n) {
   static const char* frq[] = {"freq"};
   switch (kind) {
     case KNH_STAGE_PHASOR: case KNH_STAGE_RANDOM_LIN: *n = 1; return frq;
+    case KNH_STAGE_PAN2: { static const char* pan[] = {"pan"}; *n = 1; return pan; }
     case KNH_STAGE_POLYBLEP: { static const char* pb[] = {"freq", "pulse_width", "waveform"}; *n = 3; return pb; }
     case KNH_STAGE_SAFETY_LIMITER: case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: *n = 0; return frq;
     case KNH_STAGE_SAMPLE_DELAY: case KNH_STAGE_ALLPASS_DELAY: *n = 1; return dly;
@@ -368,12 +375,18 @@ class Graph {
     struct Voice { ChainPlan plan; std::vector<int> nodes; };
     std::vector<Voice> voices;
     for (auto& conn : new_outputs_) {
-      // conn = the per-channel nodes of one to_graph_out(); every channel must carry the same signal
-      for (int n : conn)
-        if (n != conn[0]) throw GraphError("different signals per output channel are not a mono voice chain");
+      // conn = the per-channel (node, output channel) of one to_graph_out(): either the same mono signal on every
+      // graph output (`.out([0,0])`), or the two outputs of a Pan2 on the two graph outputs, in order
       if (conn.size() != outputs_) throw GraphError("to_graph_out(): channel count does not match the graph outputs");
+      const NodeRec& last = nodes_[static_cast<size_t>(conn[0].first)];
+      const bool pan = last.type == NodeRec::UGEN && last.spec.kind == KNH_STAGE_PAN2;
+      for (size_t c = 0; c < conn.size(); ++c) {
+        if (conn[c].first != conn[0].first) throw GraphError("different signals per output channel are not a voice chain");
+        if (conn[c].second != (pan ? static_cast<int>(c) : 0)) throw GraphError("a Pan2's outputs go to graph outputs 0 and 1, in order");
+      }
+      if (pan && outputs_ != 2) throw GraphError("a Pan2 voice needs a stereo graph");
       Voice v;
-      trace(conn[0], v.plan, v.nodes);
+      trace(conn[0].first, v.plan, v.nodes);
       voices.push_back(std::move(v));
     }
     new_outputs_.clear();
@@ -439,7 +452,7 @@ class Graph {
   uint32_t outputs_, sample_rate_;
   size_t block_size_;
   std::vector<NodeRec> nodes_;
-  std::vector<std::vector<int>> new_outputs_;
+  std::vector<std::vector<std::pair<int, int>>> new_outputs_;  // per to_graph_out(): (node, output channel) per graph output
   std::vector<Bank> banks_;
   std::vector<SchedulingEvent> events_;  // the rtrb channel of graph.rs:225-230, drained by the processor
 };
@@ -453,8 +466,12 @@ class GraphEdit {
     NodeRec n;
     n.type = NodeRec::UGEN;
     n.spec = std::move(spec);
+    const uint16_t outs = n.spec.outputs;
     graph_->nodes_.push_back(std::move(n));
-    return Sig<F>(this, {static_cast<int>(graph_->nodes_.size()) - 1});
+    const int id = static_cast<int>(graph_->nodes_.size()) - 1;
+    std::vector<int> nodes(outs, id), chans(outs);
+    for (uint16_t c = 0; c < outs; ++c) chans[c] = c;
+    return Sig<F>(this, nodes, chans);
   }
 
  private:
@@ -488,7 +505,11 @@ class GraphEdit {
     n.in0 = src.node();
     return sink;
   }
-  void to_graph_out(const Sig<F>& s) { graph_->new_outputs_.push_back(s.nodes()); }
+  void to_graph_out(const Sig<F>& s) {
+    std::vector<std::pair<int, int>> conn;
+    for (size_t c = 0; c < s.nodes().size(); ++c) conn.emplace_back(s.nodes()[c], s.channels()[c]);
+    graph_->new_outputs_.push_back(std::move(conn));
+  }
   typename Sig<F>::Parameter param(int node, const std::string& name) {
     const NodeRec& n = graph_->nodes_[static_cast<size_t>(node)];
     if (n.type != NodeRec::UGEN) throw GraphError("param(): not a UGen node");

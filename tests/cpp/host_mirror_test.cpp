@@ -102,6 +102,42 @@ static void plan_noise_sources_take_seeds_in_construction_order() {
   CHECK(graph->bank(2).plan.stage_args[0][0] == double(first + 2));
   CHECK(next_randomness_seed() == first + 4);
 }
+// knaster/examples/many_sines.rs:51-63 as written: `((env * sine) >> pan).to_graph_out()` -- the Pan2's two outputs go to
+// graph outputs 0 and 1, and the 600 voices become one bank whose chain ends in KNH_STAGE_PAN2.
+static void plan_many_sines_with_pan2() {
+  auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
+  (void)processor;
+  graph->plan_only = true;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int i = 0; i < 600; ++i) {
+      auto env = g.push(EnvAr(0.01, 0.1));
+      auto sine = g.push(SinWt(3000. + i).wr_mul(0.0125));
+      auto pan = g.push(Pan2(-1.0 + i / 300.0));
+      ((env * sine) >> pan).to_graph_out();
+    }
+  });
+  CHECK(graph->num_banks() == 1 && graph->bank(0).n_voices == 600);
+  const auto& st = graph->bank(0).plan.stages;
+  CHECK(st.size() == 4 && st[0].kind == KNH_STAGE_SIN_WT && st[1].kind == KNH_STAGE_WR_MUL && st[2].kind == KNH_STAGE_MUL_ENV_AR && st[3].kind == KNH_STAGE_PAN2);
+  CHECK(knh_chain_ugen_count(st.data(), 4) == 4);  // SinWt, EnvAr, MathUGen Mul, Pan2
+  // a Pan2 needs a stereo graph, and its outputs go to graph outputs 0 and 1 in that order
+  bool threw = false;
+  try {
+    auto [g1, p1] = AudioProcessor<float>::create(1, {64, 48000});
+    (void)p1;
+    g1->plan_only = true;
+    g1->edit([&](GraphEdit<float>& g) { (g.push(SinWt(440.)) >> g.push(Pan2(0.))).to_graph_out(); });
+  } catch (const GraphError&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try {
+    auto [g2, p2] = AudioProcessor<float>::create(2, {64, 48000});
+    (void)p2;
+    g2->plan_only = true;
+    g2->edit([&](GraphEdit<float>& g) { (g.push(SinWt(440.)) >> g.push(Pan2(0.))).out({1, 0}).to_graph_out(); });
+  } catch (const GraphError&) { threw = true; }
+  CHECK(threw);
+}
 static void plan_rejects_what_is_not_a_voice_chain() {
   auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
   (void)processor;
@@ -458,6 +494,69 @@ static void gpu_polyblep_delay_limiter_voices() {
   CHECK(worst <= 1e-5 && peak > 1e-3);
 }
 
+// many_sines.rs:51-92 end to end: 600 panned voices, envelope restarts and new frequencies while running, against the
+// reference-shaped graph (one node per UGen, an Add chain per output channel) of the oracle.
+static void gpu_many_sines_with_pan2() {
+  const int N = 600, B = 64;
+  kno::XOrShift32Rng rng(0x1234567u);
+  struct V { double freq, amp, pan; };
+  std::vector<V> voices;
+  for (int i = 0; i < N; ++i) {
+    const double a = rng.gen_f32(), b = rng.gen_f32(), c = rng.gen_f32();
+    voices.push_back({3000.0 + 7000.0 * a, 0.01 + 0.005 * b, -1.0 + 2.0 * c});
+  }
+  auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+  std::vector<Sig<float>::Parameter> restart, freq, panp;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (const auto& v : voices) {
+      auto env = g.push(EnvAr(0.01, 0.1));
+      auto sine = g.push(SinWt(v.freq).wr_mul(v.amp));
+      auto pan = g.push(Pan2(v.pan));
+      ((env * sine) >> pan).to_graph_out();
+      restart.push_back(env.param("t_restart"));
+      freq.push_back(sine.param("freq"));
+      panp.push_back(pan.param("pan"));
+    }
+  });
+  CHECK(graph->num_banks() == 1 && graph->bank(0).n_voices == N);
+  kno::Graph<float> ref(0, 2, B, 48000);
+  std::vector<kno::NodeKey> r_env, r_sine, r_pan;
+  for (const auto& v : voices) {
+    auto e = ref.push(std::make_unique<kno::EnvAr<float>>(0.01f, 0.1f));
+    auto s = ref.push(std::make_unique<kno::WrMath<float>>(std::make_unique<kno::SinWt<float>>(float(v.freq)), kno::WrOp::Mul, float(v.amp)));
+    auto p = ref.push(std::make_unique<kno::Pan2<float>>(float(v.pan)));
+    auto m = ref.math_nodes(e, 0, kno::MathOp::Mul, s, 0);
+    ref.connect_to_node(m, 0, 0, p, false);
+    ref.connect_to_output(p, 0, 0, true);
+    ref.connect_to_output(p, 1, 1, true);
+    r_env.push_back(e); r_sine.push_back(s); r_pan.push_back(p);
+  }
+  ref.commit_changes();
+  std::vector<float> want(2 * B);
+  double worst = 0, peak = 0, stereo = 0;
+  const double ratios[7] = {1.0, 9. / 8., 6. / 5., 3. / 2., 8. / 5., 16. / 9., 2.};
+  for (int block = 0; block < 12; ++block) {
+    for (int i = block % 3; i < N; i += 3) {  // many_sines.rs:73-88: a new frequency, then the envelope restarts
+      const double f = 220.0 * ratios[i % 7] * (1 + block % 4);
+      freq[i].set(f); ref.set(r_sine[i], 0, kno::ParameterValue::Flt(f));
+      restart[i].trig(); ref.set(r_env[i], 2, kno::ParameterValue::Trig());
+    }
+    if (block == 5)
+      for (int i = 0; i < N; i += 2) { panp[i].set(-voices[i].pan); ref.set(r_pan[i], 0, kno::ParameterValue::Flt(-voices[i].pan)); }
+    processor->run_without_inputs();
+    ref.run({}, want.data());
+    auto out = processor->output_block();
+    for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < B; ++i) {
+        worst = std::max(worst, std::fabs(double(out.read(c, i)) - double(want[c * B + i])));
+        peak = std::max(peak, std::fabs(double(want[c * B + i])));
+      }
+    for (int i = 0; i < B; ++i) stereo = std::max(stereo, std::fabs(double(out.read(0, i)) - double(out.read(1, i))));
+  }
+  std::printf("  many_sines with Pan2: max |gpu - reference-shaped graph| = %.3g (peak %.3g, max |L - R| %.3g)\n", worst, peak, stereo);
+  CHECK(worst <= 1e-5 && peak > 1e-3 && stereo > 1e-4);
+}
+
 int main(int argc, char** argv) {
   bool plan = false, gpu = false;
   for (int i = 1; i < argc; ++i) {
@@ -470,6 +569,7 @@ int main(int argc, char** argv) {
     RUN(plan_readme_example);
     RUN(plan_groups_voices_by_chain_shape);
     RUN(plan_noise_sources_take_seeds_in_construction_order);
+    RUN(plan_many_sines_with_pan2);
     RUN(plan_rejects_what_is_not_a_voice_chain);
     RUN(time_and_seconds);
   }
@@ -481,6 +581,7 @@ int main(int argc, char** argv) {
     RUN(gpu_heterogeneous_voices_mix_on_device);
     RUN(gpu_segment_envelopes_of_ragged_length);
     RUN(gpu_polyblep_delay_limiter_voices);
+    RUN(gpu_many_sines_with_pan2);
   }
   std::printf("%s (%d failures)\n", g_fail ? "HOST MIRROR FAILED" : "HOST MIRROR PASSED", g_fail);
   return g_fail ? 1 : 0;
