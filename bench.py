@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- UGen-samples/s of the fused voice-bank path on N MI355X (BASELINE.json metric).
 
-Workload: BASELINE.json configs[2] ("C3"): 16384 voices per GPU, chain
-SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, block_size 512, f32, 48 kHz, synthetic
-per-voice parameters (xorshift32).  One *step* = one pass of the hot path over one
-batch: BLOCKS_PER_STEP (64) consecutive 512-frame blocks of every voice on every rank, rendered in ONE
-launch (knh_bank_process_blocks_device: voice state stays in registers across the blocks of a launch;
-results are bit-identical to one launch per block, tests/test_gpu_properties.py) -- the note cycle of
-SURVEY.md 8(d) (t_restart at block 0, t_release at block 32).  `value` counts every block of every step.  Voices shard across ranks (one process per GPU); each rank
-folds its own voices into stereo blocks and each launch's stereo blocks are sum-reduced to rank 0
-over RCCL in one call (the reduce is latency-bound at 4 KiB per block).
+Workload (`value`): BASELINE.json configs[2] ("C3"): 16384 voices per GPU, chain
+SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, block_size 512, f32, 48 kHz, synthetic per-voice parameters
+(xorshift32); weak scaling (voices per GPU fixed).  One *step* = one pass of the hot path over one
+batch: BLOCKS_PER_STEP (64) consecutive 512-frame blocks of every voice on every rank, rendered in ONE launch
+(knh_bank_process_blocks_device: voice state stays in registers across the blocks of a launch; results are
+bit-identical to one launch per block, tests/test_gpu_properties.py) -- the note cycle of SURVEY.md 8(d)
+(t_restart at block 0, t_release at block 32).  `value` counts every block of every step.
+
+Several GPUs: one process per GPU; each rank creates its share of the bank with knh_bank_create_rank (contiguous
+voice ranges, global voice indices) and the LIBRARY sums each launch's stereo blocks to rank 0 with RCCL's ncclReduce
+on a stream of its own, overlapping the next launch (knaster_amd/csrc/comm.hip, rank_bank.hpp).  torch.distributed is
+used for nothing on the data path: it hands the communicator id to the ranks, and provides the barrier and the
+max-over-ranks of the timing.
+
+The same line also carries BASELINE.json configs[3] ("C4": 65536 voices in all, f64, STRONG scaling over the ranks)
+as `c4_strong` (skip with --no-c4; `--config C4` makes it the headline instead).
 
 Launch: `python bench.py` (N=1) or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
@@ -18,6 +25,7 @@ Rank 0 prints ONE JSON line.
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -39,7 +47,6 @@ SVF_STEP_CYCLES = 44.0
 SHADER_CLOCK_GHZ = 2.4
 PIPE_TILE = 64                 # samples per pipeline step of the shipped C3 kernel (voice_pipe.hpp)
 BLOCKS_PER_STEP = 64           # blocks per step = per launch = per RCCL reduce (one note cycle)
-REDUCE_EVERY = BLOCKS_PER_STEP
 PREWARM_MS = 150.0             # untimed launches before the warm-up steps: the shader clock needs a few ms of load to come up
 
 
@@ -48,10 +55,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one 64-block launch per rank")
     ap.add_argument("--warmup", type=int, default=4, help="untimed steps before the timed ones")
-    ap.add_argument("--voices-per-gpu", type=int, default=16384)
+    ap.add_argument("--config", choices=["C3", "C4"], default="C3", help="headline workload: C3 weak scaling (default) or C4 strong scaling")
+    ap.add_argument("--voices-per-gpu", type=int, default=16384, help="C3: voices per GPU (weak scaling)")
+    ap.add_argument("--c4-voices", type=int, default=65536, help="C4: voices in all (strong scaling)")
     ap.add_argument("--block-size", type=int, default=512)
     ap.add_argument("--allow-fma", action="store_true", help="non-bit-exact FMA kernels (reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the secondary C4 strong-scaling measurement")
     ap.add_argument("--cpu-baseline-blocks", type=int, default=0, help="0 = auto (about 10-20 s)")
     return ap.parse_args()
 
@@ -68,231 +78,296 @@ def cpu_baseline(w, cores: int, blocks: int):
     return secs, wall
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
+class Env:
+    """The process's place in the job: rank, device, and the little torch.distributed is used for."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
 
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.rank == 0:
+                print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; launch with torch.distributed.run", file=sys.stderr)
+            sys.exit(2)
+        if not torch.cuda.is_available():
+            print("bench.py: no GPU visible; the voice-bank path has no CPU fallback", file=sys.stderr)
+            sys.exit(3)
+        # KNH_BENCH_REHEARSE=1: several ranks share the visible GPUs (RCCL refuses two ranks on one GPU, so the sum goes
+        # through a host-side gloo reduce handed to the library as its reduce function): rehearses the N > 1 control flow
+        # on a one-GPU box (tests/test_gpu_multi.py).  Never set for a measurement: the line then says "rehearsal".
+        self.rehearse = os.environ.get("KNH_BENCH_REHEARSE") == "1"
+        if self.rehearse:
+            self.local_rank %= torch.cuda.device_count()
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+        self.stream = torch.cuda.current_stream()
+
+    def comm_id(self):
+        """rank 0 makes the RCCL id (through the library); the host hands it round."""
+        import knaster_amd
+
+        if self.world == 1 or self.rehearse:
+            return None
+        box = [knaster_amd.comm_unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def gloo_reduce_fn(self):
+        """knh_reduce_fn for the rehearsal: device -> host, gloo reduce, host -> device on the root."""
+        import ctypes as C
+
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        torch, dist, rank = self.torch, self.dist, self.rank
+
+        def fn(_user, buf, count, sample_type, root, stream):
+            host = np.empty(count, dtype=np.float64 if sample_type == 1 else np.float32)
+            if hip.hipStreamSynchronize(stream) != 0 or hip.hipMemcpy(host.ctypes.data, buf, host.nbytes, 2) != 0:
+                return 4
+            t = torch.from_numpy(host)
+            dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
+            if rank == root and hip.hipMemcpy(buf, host.ctypes.data, host.nbytes, 1) != 0:
+                return 4
+            return 0
+        return fn
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.rehearse else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, warmup: int):
+    """One workload on the job's ranks: returns a dict of raw measurements (every rank), or exits on failure."""
     import knaster_amd
     from knaster_amd import _lib as L
     from knaster_amd import configs
 
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the voice-bank path has no CPU fallback", file=sys.stderr)
-        sys.exit(3)
-    # KNH_BENCH_REHEARSE=1: several ranks share the visible GPUs and talk over gloo, to rehearse the N>1 control
-    # flow on a one-GPU box.  Never set for a measurement: the reported line then says "rehearsal".
-    rehearse = os.environ.get("KNH_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    nv, bs = args.voices_per_gpu, args.block_size
-    # every rank owns a contiguous range of the global voice list: parameters are drawn for the whole
-    # list (one xorshift stream, voices in index order) and sliced
-    w_all = configs.config("C3", n_voices=nv * world, block_size=bs)
-    lo, hi = rank * nv, (rank + 1) * nv
-    bank = knaster_amd.VoiceBank(w_all.stages, nv, w_all.sample_type, w_all.out_channels, L.MIX_TREE, local_rank, args.allow_fma)
+    torch = env.torch
+    w_all = configs.config(name, n_voices=total_voices, block_size=bs)
+    lo, cnt = knaster_amd.shard_voice_range(total_voices, env.rank, env.world)
+    kwargs = dict(rank=env.rank, world=env.world)
+    if env.world > 1 and env.rehearse:
+        kwargs["reduce_fn"] = env.gloo_reduce_fn()
+    else:
+        kwargs["comm_id"] = env.comm_id()
+    bank = knaster_amd.VoiceBank(w_all.stages, total_voices, w_all.sample_type, w_all.out_channels, L.MIX_TREE, env.local_rank,
+                                 args.allow_fma, **kwargs)
     for s, a in w_all.ctor.items():
-        bank.set_ctor_args(s, a[lo:hi])
+        bank.set_ctor_args(s, a)  # every rank hands over the whole list; the library keeps its range
     bank.init(configs.SAMPLE_RATE, bs)
     ugens = knaster_amd.chain_ugen_count(w_all.stages)
-    voices = np.arange(nv, dtype=np.uint32)
-
-    stream = torch.cuda.current_stream()
-    # the mixed stereo blocks of a launch: [REDUCE_EVERY][channels][block_size], resident in HBM; two of them so
-    # that the RCCL reduce of one launch overlaps the next launch's kernels
-    rings = [torch.zeros((REDUCE_EVERY, w_all.out_channels, bs), dtype=torch.float32, device=dev) for _ in range(2)]
-    ring = rings[0]
-    pending = [None, None]
-    CYCLE = 64  # the note cycle of SURVEY.md 8(d): t_restart at block 0, t_release at block 32 of every 64 blocks
-
-    def schedule(first_step: int, n: int):
-        """Queue the parameter events of steps [first_step, first_step + n) for the next launch."""
-        for i in range(n):
-            phase = (first_step + i) % CYCLE
-            if phase == 0:
-                bank.param_apply_many(voices, w_all.restart[0], w_all.restart[1], L.VALUE_TRIGGER, block_offset=i)
-            elif phase == CYCLE // 2:
-                bank.param_apply_many(voices, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER, block_offset=i)
-
+    mine = np.arange(lo, lo + cnt, dtype=np.uint32)  # global indices of this rank's voices
+    restart = bank.prepare_many(mine, w_all.restart[0], w_all.restart[1], L.VALUE_TRIGGER)
+    release = bank.prepare_many(mine, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER)
+    tdtype = torch.float64 if w_all.sample_type == L.F64 else torch.float32
+    # the mixed stereo blocks of a launch: [BLOCKS_PER_STEP][channels][block_size], resident in HBM; two of them, used
+    # alternately, so that the library's reduce of one launch overlaps the next launch's kernels
+    rings = [torch.zeros((BLOCKS_PER_STEP, w_all.out_channels, bs), dtype=tdtype, device=env.dev) for _ in range(2)]
     launch_no = [0]
 
-    def run_steps(first_step: int, n: int):
-        """n steps; one step = one launch of BLOCKS_PER_STEP blocks + one RCCL reduce of its stereo blocks."""
-        for i in range(n):
+    def schedule():
+        """The parameter events of one step (a 64-block note cycle): t_restart at block 0, t_release at block 32."""
+        if cnt:
+            bank.param_apply_prepared(restart, 0)
+            bank.param_apply_prepared(release, BLOCKS_PER_STEP // 2)
+
+    def run_steps(n: int):
+        for _ in range(n):
             half = launch_no[0] & 1
             launch_no[0] += 1
-            if pending[half] is not None:  # the reduce that last read this buffer must be done before it is rewritten
-                pending[half].wait()
-                pending[half] = None
-            schedule((first_step + i) * BLOCKS_PER_STEP, BLOCKS_PER_STEP)
-            bank.process_blocks_device(BLOCKS_PER_STEP, rings[half].data_ptr(), stream.cuda_stream)
-            if world > 1 and not rehearse:
-                pending[half] = dist.reduce(rings[half], dst=0, op=dist.ReduceOp.SUM, async_op=True)
-            elif world > 1:  # gloo has no device-tensor reduce
-                pending[half] = dist.all_reduce(rings[half], op=dist.ReduceOp.SUM, async_op=True)
-
-    def drain():
-        for h in range(2):
-            if pending[h] is not None:
-                pending[h].wait()
-                pending[h] = None
+            schedule()
+            bank.process_blocks_device(BLOCKS_PER_STEP, rings[half].data_ptr(), env.stream.cuda_stream)
 
     def fence():
-        drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        bank.synchronize()  # this rank's kernels and reduces
+        env.barrier()
 
     # untimed: bring the shader clock up (a kernel of under a few milliseconds right after an idle period runs ~25 % slow)
-    t_pre = time.perf_counter()
-    n_pre = 0
-    while (time.perf_counter() - t_pre) * 1e3 < PREWARM_MS:
-        run_steps(0, 2)
-        drain()
-        torch.cuda.synchronize()
+    # (every rank runs the same number of launches -- each launch holds a collective: the ranks agree after every pair)
+    t_pre, n_pre = time.perf_counter(), 0
+    while True:
+        run_steps(2)
+        bank.synchronize()
         n_pre += 2
-    run_steps(0, args.warmup)
+        if env.max_over_ranks((time.perf_counter() - t_pre) * 1e3) >= PREWARM_MS:
+            break
+    run_steps(warmup)
     fence()
     bank.timing_reset(True)
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
+    run_steps(steps)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = bank.timing_read()
     bank.timing_reset(False)
-    blocks_per_launch = float(BLOCKS_PER_STEP)
-    total_blocks = args.steps * BLOCKS_PER_STEP
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_avg_ms = float(k.item())
-    else:
-        kernel_avg_ms = kernel_ms / max(launches, 1)
+    elapsed = env.max_over_ranks(elapsed)
+    kernel_avg_ms = env.max_over_ranks(kernel_ms / max(launches, 1))
 
     # The same path when the boundary hands the blocks to the HOST (knh_bank_process_blocks: D2H copy of
     # every launch's stereo blocks over PCIe + stream sync).  Reported beside `value`, never as `value`.
     host_rate = None
-    if world == 1:
+    if env.world == 1:
         n_host = 4
-        schedule(0, REDUCE_EVERY)
-        bank.process_blocks(REDUCE_EVERY)
+        schedule()
+        bank.process_blocks(BLOCKS_PER_STEP)
         t1 = time.perf_counter()
-        for i in range(n_host):
-            schedule(0, REDUCE_EVERY)
-            bank.process_blocks(REDUCE_EVERY)
-        host_rate = float(nv) * bs * ugens * REDUCE_EVERY * n_host / (time.perf_counter() - t1)
-
+        for _ in range(n_host):
+            schedule()
+            bank.process_blocks(BLOCKS_PER_STEP)
+        host_rate = float(total_voices) * bs * ugens * BLOCKS_PER_STEP * n_host / (time.perf_counter() - t1)
     sane = bool(torch.isfinite(rings[0]).all().item() and torch.isfinite(rings[1]).all().item())
-    # HBM bytes per launch from the committed PMC passes (newest round first), scaled per block: the counters are
-    # per-launch totals of a 64-block launch of the same bank
-    traffic, traffic_src = None, None
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+    peak = float(max(rings[0].abs().max().item(), rings[1].abs().max().item()))
+    rd, wr = bank.algorithmic_bytes_per_voice_block()
+    out = dict(workload=w_all, ugens=ugens, elapsed=elapsed, kernel_avg_ms=kernel_avg_ms, launches=launches, host_rate=host_rate,
+               sane=sane, peak=peak, bytes_per_voice_block=rd + wr, n_pre=n_pre, voices_rank0=cnt if env.rank == 0 else None,
+               ranks_seen=bank.ranks(), total_voices=total_voices, steps=steps)
+    bank.close()
+    return out
+
+
+def traffic_from_profiles(nv: int, bs: int, sample_type: str, kernel_key: str = "voice_pipe_kernel"):
+    """HBM bytes per 64-block launch from the committed PMC passes (newest round first), scaled per block: the counters
+    are per-launch totals of a launch of the same bank (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 prof = json.load(f)
             wl = prof.get("workload", {})
-            if (wl.get("voices"), wl.get("block_size"), wl.get("sample_type", "f32")) == (nv, bs, "f32"):
-                traffic = prof["voice_pipe_kernel"]["hbm_bytes_per_launch"] / float(wl["blocks_per_launch"]) * blocks_per_launch
-                traffic_src = os.path.relpath(path, ROOT)
-                break
+            if (wl.get("voices"), wl.get("block_size"), wl.get("sample_type", "f32")) == (nv, bs, sample_type):
+                return prof[kernel_key]["hbm_bytes_per_launch"] / float(wl["blocks_per_launch"]) * BLOCKS_PER_STEP, os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
-    if rank == 0:
-        total_voices = nv * world
-        ugen_samples = float(total_voices) * bs * ugens * total_blocks
-        value = ugen_samples / elapsed
-        rd, wr = bank.algorithmic_bytes_per_voice_block()
-        # SURVEY.md 8(d): 92 B per voice per block (state read once + mutable state written once per block)
-        # x the voice-blocks one launch processes
-        alg_bytes_per_launch = float(rd + wr) * nv * blocks_per_launch
+    return None, None
+
+
+def main():
+    args = parse()
+    env = Env(args)
+    from knaster_amd import _lib as L
+
+    bs, world = args.block_size, env.world
+    headline = args.config
+    if headline == "C3":
+        m = measure(env, args, "C3", args.voices_per_gpu * world, bs, args.steps, args.warmup)
+        secondary = None if args.no_c4 else measure(env, args, "C4", args.c4_voices, bs, max(4, args.steps // 2), max(1, args.warmup // 2))
+    else:
+        m = measure(env, args, "C4", args.c4_voices, bs, args.steps, args.warmup)
+        secondary = None
+    if env.rank == 0:
+        w_all, ugens, total_voices = m["workload"], m["ugens"], m["total_voices"]
+        f64 = w_all.sample_type == L.F64
+        nv_rank = m["voices_rank0"]
+        total_blocks = m["steps"] * BLOCKS_PER_STEP
+        value = float(total_voices) * bs * ugens * total_blocks / m["elapsed"]
+        kernel_avg_ms = m["kernel_avg_ms"]
+        # SURVEY.md 8(d): 92 B per voice per block for C3 (state read once + mutable state written once per block; f64: 184 B)
+        # x the voice-blocks one launch of one rank processes
+        alg_bytes_per_launch = float(m["bytes_per_voice_block"]) * nv_rank * BLOCKS_PER_STEP
         achieved_gbs = alg_bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
-        kernel_rate = float(nv) * bs * ugens * blocks_per_launch / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
+        kernel_rate = float(nv_rank) * bs * ugens * BLOCKS_PER_STEP / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
+        traffic, traffic_src = traffic_from_profiles(nv_rank, bs, "f64" if f64 else "f32")
+        ns_per_sample = kernel_avg_ms * 1e6 / (BLOCKS_PER_STEP * bs) if kernel_avg_ms > 0 else None
         line = {
             "metric": "UGen-samples/sec (voices x block_size x UGens / s)",
             "value": value,
             "unit": "UGen-samples/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": m["steps"],
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": m["elapsed"] / m["steps"] * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if headline == "C3" else "strong",
             "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: ranks share GPUs, gloo; not a measurement)",
+            "dtype": "f64" if f64 else "f32",
+            "data": "synthetic" if not env.rehearse else "synthetic (REHEARSAL: ranks share GPUs, host-side gloo reduce; not a measurement)",
             "config": {
-                "workload": "C3: SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, stereo mix",
-                "voices_per_gpu": nv, "voices_total": total_voices, "block_size": bs, "sample_rate": 48000,
-                "ugens_per_voice": ugens, "mix": "two-level left fold (deterministic)",
-                "step": f"one launch = {BLOCKS_PER_STEP} consecutive blocks of every voice (one note cycle); "
+                "workload": ("C3" if headline == "C3" else "C4") + ": SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, stereo mix"
+                            + (", f64 samples" if f64 else ""),
+                "voices_per_gpu": nv_rank, "voices_total": total_voices, "block_size": bs, "sample_rate": 48000,
+                "ugens_per_voice": ugens, "mix": "two-level left fold per GPU (deterministic), RCCL sum across GPUs",
+                "step": f"one launch per rank = {BLOCKS_PER_STEP} consecutive blocks of every voice (one note cycle); "
                         f"{total_blocks} blocks timed", "blocks_per_step": BLOCKS_PER_STEP, "blocks_timed": total_blocks,
                 "residency": "value is measured with voice state, events and the mixed stereo blocks resident in HBM; the "
                              "PCIe-inclusive rate of the host-pointer boundary (knh_bank_process_blocks) is host_output",
-                "prewarm": f"{n_pre} untimed launches (>= {PREWARM_MS:.0f} ms) before the warm-up steps, to bring the clock up",
+                "prewarm": f"{m['n_pre']} untimed launches (>= {PREWARM_MS:.0f} ms) before the warm-up steps, to bring the clock up",
                 "arithmetic": "fma" if args.allow_fma else "exact (bit-identical per voice to the CPU oracle)",
-                "parallelism": f"voices sharded over {world} rank(s); {REDUCE_EVERY} blocks per launch; RCCL sum-reduce of the "
-                               f"stereo blocks once per launch",
+                "parallelism": f"voices sharded over {world} rank(s), one process per GPU (knh_bank_create_rank); "
+                               f"{BLOCKS_PER_STEP} blocks per launch; the library's ncclReduce of the stereo blocks to rank 0 once per "
+                               f"launch, on its own stream",
+                "ranks_seen_by_rccl": m["ranks_seen"],
                 "events": "t_restart on every voice at block 0 and t_release at block 32 of every 64-block cycle",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": f"{traffic_src} (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes, per launch)" if traffic else None,
-                "kernel": "voice_pipe_kernel<float,false,64,true,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>",
-                "kernel_avg_ms": kernel_avg_ms, "launches": launches, "blocks_per_launch": blocks_per_launch,
+                "kernel": ("voice_pipe_kernel<double,false,32,true,...>" if f64 else "voice_pipe_kernel<float,false,64,true,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>")
+                          if nv_rank <= 24576 else "voice_kernel<..., WAVES = 4 or 8, SinWt, MulVal, Svf, MulAsr>",
+                "kernel_avg_ms": kernel_avg_ms, "launches": m["launches"], "blocks_per_launch": float(BLOCKS_PER_STEP),
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "note": "fused kernel moves 92 B per voice per block; it is bound by the instruction issue of its busiest "
-                        "wavefront, not by HBM (see valu and issue)",
+                "note": "fused kernel moves 92 B (f64: 184 B) per voice per block; it is bound by the instruction issue of its "
+                        "busiest wavefront, not by HBM (see valu and issue)",
             },
             "valu": {
                 "achieved_ops_per_s": kernel_rate * OPS_PER_UGEN_SAMPLE, "peak_ops_per_s": VALU_PEAK_OPS,
                 "frac": kernel_rate * OPS_PER_UGEN_SAMPLE / VALU_PEAK_OPS,
                 "ops_per_ugen_sample": OPS_PER_UGEN_SAMPLE, "kernel_only_ugen_samples_per_s": kernel_rate,
             },
+            "output_finite": m["sane"], "output_peak": m["peak"],
+            "host_output": None if m["host_rate"] is None else {
+                "value": m["host_rate"], "unit": "UGen-samples/s",
+                "note": "PCIe-inclusive: each 64-block launch's stereo blocks copied to host memory and synchronised",
+            },
+        }
+        if headline == "C3" and not f64:
             # What actually bounds this kernel at 16 384 voices (one 64-voice group per CU, one wavefront per SIMD): the
             # filter wavefront's instruction stream.
-            "issue": {
+            line["issue"] = {
                 "bound": "instruction issue of the busiest wavefront (SVF), one wavefront per SIMD",
                 "filter_step_cycles_per_sample_alone": SVF_STEP_CYCLES,
                 "floor_ns_per_sample": SVF_STEP_CYCLES / SHADER_CLOCK_GHZ,
-                "kernel_ns_per_sample": kernel_avg_ms * 1e6 / (blocks_per_launch * bs) if kernel_avg_ms > 0 else None,
-                "frac": (SVF_STEP_CYCLES / SHADER_CLOCK_GHZ) / (kernel_avg_ms * 1e6 / (blocks_per_launch * bs))
-                if kernel_avg_ms > 0 and not args.allow_fma else None,
+                "kernel_ns_per_sample": ns_per_sample,
+                "frac": (SVF_STEP_CYCLES / SHADER_CLOCK_GHZ) / ns_per_sample if ns_per_sample and not args.allow_fma else None,
                 "tile_samples": PIPE_TILE,
                 "note": "floor = the ten instructions of one filter step issued by a wavefront alone on its SIMD (44 cycles, "
                         "micro-benchmark) at 2.4 GHz; the rest of the kernel's time per sample is that wavefront's LDS hand-over, "
                         "block/event bookkeeping and barrier once per 64-sample tile, and tiles in which the envelope "
                         "wavefront (which also folds the voices) is the slower one",
-            },
-            "output_finite": sane,
-            "host_output": None if host_rate is None else {
-                "value": host_rate, "unit": "UGen-samples/s",
-                "note": "PCIe-inclusive: each 64-block launch's stereo blocks copied to host memory and synchronised",
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:
+            }
+        if secondary is not None:
+            s = secondary
+            s_blocks = s["steps"] * BLOCKS_PER_STEP
+            s_kernel_rate = float(s["voices_rank0"]) * bs * s["ugens"] * BLOCKS_PER_STEP / (s["kernel_avg_ms"] * 1e-3) if s["kernel_avg_ms"] > 0 else 0.0
+            line["c4_strong"] = {
+                "workload": "C4: the same chain, f64 samples, 65 536 voices IN ALL, split over the ranks (BASELINE.json configs[3])",
+                "value": float(s["total_voices"]) * bs * s["ugens"] * s_blocks / s["elapsed"], "unit": "UGen-samples/s",
+                "scaling": "strong", "dtype": "f64", "n_gpus": world, "voices_total": s["total_voices"], "voices_per_gpu": s["voices_rank0"],
+                "steps": s["steps"], "ms_per_step": s["elapsed"] / s["steps"] * 1e3, "kernel_avg_ms": s["kernel_avg_ms"],
+                "kernel_only_ugen_samples_per_s_per_gpu": s_kernel_rate,
+                "roofline_achieved_gbs": float(s["bytes_per_voice_block"]) * s["voices_rank0"] * BLOCKS_PER_STEP / (s["kernel_avg_ms"] * 1e-3) / 1e9
+                if s["kernel_avg_ms"] > 0 else 0.0,
+                "ranks_seen_by_rccl": s["ranks_seen"], "output_finite": s["sane"],
+            }
+        if not args.no_cpu_baseline and world == 1 and headline == "C3":
             try:
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:
@@ -317,9 +392,8 @@ def main():
                 "kind": "port", "sample": f"{b1} blocks, one sequential scheduler (the reference is single-threaded)",
             }
         print(json.dumps(line), flush=True)
-    bank.close()
     if world > 1:
-        dist.destroy_process_group()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -7,6 +7,14 @@ use core::ffi::{c_char, c_void};
 pub struct knh_bank {
     _private: [u8; 0],
 }
+/// An RCCL communicator wrapped by the library (one process per GPU).
+#[repr(C)]
+pub struct knh_comm {
+    _private: [u8; 0],
+}
+pub const KNH_COMM_ID_BYTES: usize = 128;
+/// The host's own sum-reduce for `knh_bank_create_rank_custom`.
+pub type knh_reduce_fn = Option<unsafe extern "C" fn(user: *mut c_void, device_buf: *mut c_void, count: usize, sample_type: u32, root: u32, hip_stream: *mut c_void) -> i32>;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
@@ -146,4 +154,20 @@ unsafe extern "C" {
     pub fn knh_bank_timing_reset(bank: *mut knh_bank, enable: i32) -> i32;
     pub fn knh_bank_timing_read(bank: *mut knh_bank, kernel_ms: *mut f64, launches: *mut u64) -> i32;
     pub fn knh_bank_algorithmic_bytes_per_voice_block(bank: *const knh_bank, read_bytes: *mut u32, write_bytes: *mut u32) -> i32;
+    // several GPUs of one node: one process owning them all, or one process per GPU with an RCCL reduce
+    pub fn knh_bank_create_multi_device(desc: *const knh_bank_desc, devices: *const i32, n_devices: u32, out_bank: *mut *mut knh_bank) -> i32;
+    pub fn knh_comm_unique_id(id: *mut u8) -> i32;
+    pub fn knh_bank_create_rank(desc: *const knh_bank_desc, rank: u32, world: u32, comm_id: *const u8, out_bank: *mut *mut knh_bank) -> i32;
+    pub fn knh_bank_create_rank_custom(desc: *const knh_bank_desc, rank: u32, world: u32, reduce: knh_reduce_fn, user: *mut c_void, out_bank: *mut *mut knh_bank) -> i32;
+    pub fn knh_shard_voice_range(n_voices: u32, rank: u32, world: u32, first: *mut u32, count: *mut u32) -> i32;
+    pub fn knh_bank_ranks(bank: *const knh_bank) -> u32;
+    pub fn knh_comm_create(rank: u32, world: u32, id: *const u8, device: i32, out_comm: *mut *mut knh_comm) -> i32;
+    pub fn knh_comm_destroy(comm: *mut knh_comm);
+    pub fn knh_comm_last_error(comm: *const knh_comm) -> *const c_char;
+    pub fn knh_comm_world(comm: *const knh_comm) -> u32;
+    pub fn knh_comm_rccl_version() -> i32;
+    pub fn knh_comm_reduce_sum(comm: *mut knh_comm, buf: *mut c_void, count: usize, sample_type: u32, root: u32, after_stream: *mut c_void) -> i32;
+    pub fn knh_comm_wait_buffer(comm: *mut knh_comm, buf: *const c_void, stream: *mut c_void) -> i32;
+    pub fn knh_comm_wait(comm: *mut knh_comm, stream: *mut c_void) -> i32;
+    pub fn knh_comm_synchronize(comm: *mut knh_comm) -> i32;
 }

@@ -400,6 +400,61 @@ int32_t knh_bank_timing_read(knh_bank* bank, double* kernel_ms, uint64_t* launch
 int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_t* read_bytes,
                                                    uint32_t* write_bytes);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Several GPUs of one node.  The voices of a graph are independent -- no voice reads another voice's
+ * state or output (knaster/examples/many_sines.rs:51-63); the only cross-voice operation is the additive graph output
+ * (knaster_graph/src/graph.rs:827-872) -- so a bank shards by contiguous voice ranges of whole 64-voice groups, the
+ * chain and the sine table are replicated, parameter changes are routed on the host by voice index, and the one exchange
+ * is the sum of the GPUs' mixed blocks.  Both forms return an ordinary knh_bank: every entry point above keeps its
+ * meaning and takes GLOBAL voice indices.  KNH_MIX_TREE only (the sum re-associates, like the tree mix); per-voice output
+ * is not available.
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* ONE PROCESS, several GPUs: voice range k lives on devices[k] with a host thread and a stream of its own; each range's
+ * mixed blocks are copied peer-to-peer (xGMI) to devices[0] and summed there in range order -- the one-shot direct sum,
+ * deterministic, no ring.  The mix (out / out_device) belongs to devices[0].  A device may appear more than once.
+ * This is what a Rust host owning all GPUs of the node calls instead of knh_bank_create. */
+int32_t knh_bank_create_multi_device(const knh_bank_desc* desc, const int32_t* devices, uint32_t n_devices, knh_bank** out_bank);
+
+/* ONE PROCESS PER GPU: this process is `rank` of `world` and owns the voices knh_shard_voice_range() gives it, on
+ * desc->device; desc->n_voices is the TOTAL.  A call for a voice of another rank is checked and otherwise ignored, so
+ * every rank may be handed the same parameter stream.  After every launch the ranks' mixed blocks are summed to rank 0
+ * by RCCL (ncclReduce over xGMI) on a stream of the communicator's own: the next launch overlaps it when the host
+ * alternates two out_device buffers.  The mix is on rank 0 (the other ranks' `out` holds their own share of it), once
+ * knh_bank_synchronize (or a blocking process call) has returned.  `comm_id`: KNH_COMM_ID_BYTES made by rank 0 with
+ * knh_comm_unique_id and handed to the other ranks by whatever channel the host has.  world == 1 needs no RCCL. */
+#define KNH_COMM_ID_BYTES 128
+int32_t knh_comm_unique_id(uint8_t* id);
+int32_t knh_bank_create_rank(const knh_bank_desc* desc, uint32_t rank, uint32_t world, const uint8_t* comm_id, knh_bank** out_bank);
+/* The same with the host's own sum-reduce instead of RCCL (another transport; or tests, which run two ranks on one GPU,
+ * where RCCL refuses a second rank): called after every launch as reduce(user, device_buf, count, sample_type, root,
+ * hip_stream); on return the sum over all ranks must be in `device_buf` on `root`, in the order of `hip_stream`
+ * (the function may block).  Returns a knh_status. */
+typedef int32_t (*knh_reduce_fn)(void* user, void* device_buf, size_t count, uint32_t sample_type, uint32_t root, void* hip_stream);
+int32_t knh_bank_create_rank_custom(const knh_bank_desc* desc, uint32_t rank, uint32_t world, knh_reduce_fn reduce, void* user,
+                                    knh_bank** out_bank);
+/* Voice range [first, first + count) of `rank`: the 64-voice groups dealt out as evenly as they go.  Never fails for
+ * rank < world (count may be 0); returns KNH_ERR_INVALID_ARGUMENT otherwise. */
+int32_t knh_shard_voice_range(uint32_t n_voices, uint32_t rank, uint32_t world, uint32_t* first, uint32_t* count);
+/* Number of ranks RCCL reports for a bank made by knh_bank_create_rank (ncclCommCount; 1 when world == 1; the number of
+ * voice ranges for a multi-device or host-sharded bank; 1 for any other bank). */
+uint32_t knh_bank_ranks(const knh_bank* bank);
+
+/* The communicator on its own, for hosts that keep their banks separate: sum-reduce `count` samples at `buf` (device
+ * memory, in place on `root`) over all ranks, enqueued on the communicator's stream after everything `after_stream`
+ * holds so far.  knh_comm_wait_buffer / knh_comm_wait make `stream` wait for the last reduce of `buf` / for all of them;
+ * knh_comm_synchronize waits on the host. */
+typedef struct knh_comm knh_comm;
+int32_t knh_comm_create(uint32_t rank, uint32_t world, const uint8_t* id, int32_t device, knh_comm** out_comm);
+void knh_comm_destroy(knh_comm* comm);
+const char* knh_comm_last_error(const knh_comm* comm);
+uint32_t knh_comm_world(const knh_comm* comm);
+int32_t knh_comm_rccl_version(void);
+int32_t knh_comm_reduce_sum(knh_comm* comm, void* buf, size_t count, uint32_t sample_type, uint32_t root, void* after_stream);
+int32_t knh_comm_wait_buffer(knh_comm* comm, const void* buf, void* stream);
+int32_t knh_comm_wait(knh_comm* comm, void* stream);
+int32_t knh_comm_synchronize(knh_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,6 @@ bench.py and the multi-GPU driver.  Importing the package does not load the libr
 the first use of VoiceBank does, and fails loudly if it has not been built.
 """
 from . import _lib as lib  # noqa: F401
-from .bank import TRIGGER, Stage, VoiceBank, chain_ugen_count  # noqa: F401
+from .bank import TRIGGER, Stage, VoiceBank, chain_ugen_count, comm_unique_id, shard_voice_range  # noqa: F401
 
-__all__ = ["lib", "Stage", "VoiceBank", "TRIGGER", "chain_ugen_count"]
+__all__ = ["lib", "Stage", "VoiceBank", "TRIGGER", "chain_ugen_count", "comm_unique_id", "shard_voice_range"]

@@ -96,6 +96,27 @@ PROTOTYPES = {
     "knh_bank_algorithmic_bytes_per_voice_block": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
+COMM_ID_BYTES = 128
+# knh_reduce_fn: int32 (*)(void* user, void* device_buf, size_t count, uint32 sample_type, uint32 root, void* hip_stream)
+REDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
+PROTOTYPES.update({
+    "knh_bank_create_multi_device": (C.c_int32, [C.POINTER(BankDesc), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "knh_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "knh_bank_create_rank": (C.c_int32, [C.POINTER(BankDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "knh_bank_create_rank_custom": (C.c_int32, [C.POINTER(BankDesc), C.c_uint32, C.c_uint32, REDUCE_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "knh_shard_voice_range": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "knh_bank_ranks": (C.c_uint32, [C.c_void_p]),
+    "knh_comm_create": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "knh_comm_destroy": (None, [C.c_void_p]),
+    "knh_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "knh_comm_world": (C.c_uint32, [C.c_void_p]),
+    "knh_comm_rccl_version": (C.c_int32, []),
+    "knh_comm_reduce_sum": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "knh_comm_wait_buffer": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "knh_comm_wait": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "knh_comm_synchronize": (C.c_int32, [C.c_void_p]),
+})
+
 _lib = None
 
 

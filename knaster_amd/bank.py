@@ -37,9 +37,33 @@ def chain_ugen_count(stages: Sequence[Stage]) -> int:
     return int(L.load().knh_chain_ugen_count(_stage_array(stages), len(stages)))
 
 
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: rank 0 makes it, the host hands it to the other ranks."""
+    lib = L.load()
+    buf = C.create_string_buffer(L.COMM_ID_BYTES)
+    rc = lib.knh_comm_unique_id(buf)
+    if rc != L.OK:
+        raise L.KnasterHipError(rc, (lib.knh_comm_last_error(None) or b"").decode())
+    return buf.raw
+
+
+def shard_voice_range(n_voices: int, rank: int, world: int):
+    """(first, count) of `rank`'s voices: knh_shard_voice_range."""
+    lib = L.load()
+    first, count = C.c_uint32(0), C.c_uint32(0)
+    if lib.knh_shard_voice_range(n_voices, rank, world, C.byref(first), C.byref(count)) != L.OK:
+        raise ValueError("rank out of range")
+    return int(first.value), int(count.value)
+
+
 class VoiceBank:
     def __init__(self, stages: Sequence[Stage], n_voices: int, sample_type: int = L.F32, out_channels: int = 2,
-                 mix_mode: int = L.MIX_TREE, device: int = -1, allow_fma: bool = False, host_threads: int = 0):
+                 mix_mode: int = L.MIX_TREE, device: int = -1, allow_fma: bool = False, host_threads: int = 0,
+                 devices: Optional[Sequence[int]] = None, rank: Optional[int] = None, world: int = 1,
+                 comm_id: Optional[bytes] = None, reduce_fn=None):
+        """devices=[..]: one process, voice ranges on several GPUs (knh_bank_create_multi_device).
+        rank/world (+ comm_id from comm_unique_id(), or reduce_fn): one process per GPU, n_voices is the TOTAL
+        (knh_bank_create_rank / _custom).  Voice indices are global in both."""
         self._lib = L.load()
         self.stages = list(stages)
         self.n_voices = int(n_voices)
@@ -50,7 +74,17 @@ class VoiceBank:
         desc = L.BankDesc(L.KNH_ABI_VERSION, self.n_voices, sample_type, len(self.stages), self._stage_arr,
                           out_channels, mix_mode, device, 1 if allow_fma else 0)
         h = C.c_void_p()
-        if host_threads >= 2:  # host work (change queues, event lists) on several threads: knh_bank_create_sharded
+        self._keep = None
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = self._lib.knh_bank_create_multi_device(C.byref(desc), arr, len(devices), C.byref(h))
+        elif rank is not None and reduce_fn is not None:
+            self._keep = L.REDUCE_FN(reduce_fn)  # the callback must outlive the bank
+            rc = self._lib.knh_bank_create_rank_custom(C.byref(desc), int(rank), int(world), self._keep, None, C.byref(h))
+        elif rank is not None:
+            self._keep = C.create_string_buffer(bytes(comm_id), L.COMM_ID_BYTES) if comm_id is not None else None
+            rc = self._lib.knh_bank_create_rank(C.byref(desc), int(rank), int(world), self._keep, C.byref(h))
+        elif host_threads >= 2:  # host work (change queues, event lists) on several threads: knh_bank_create_sharded
             rc = self._lib.knh_bank_create_sharded(C.byref(desc), int(host_threads), C.byref(h))
         else:
             rc = self._lib.knh_bank_create(C.byref(desc), C.byref(h))
@@ -219,6 +253,10 @@ class VoiceBank:
 
     def synchronize(self):
         self._check(self._lib.knh_bank_synchronize(self._h))
+
+    def ranks(self) -> int:
+        """Ranks RCCL reports (rank banks), voice ranges (multi-device / host-sharded banks), else 1."""
+        return int(self._lib.knh_bank_ranks(self._h))
 
     def timing_reset(self, enable: bool = True):
         self._check(self._lib.knh_bank_timing_reset(self._h, 1 if enable else 0))

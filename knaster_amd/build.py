@@ -14,8 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libknaster_hip.so")
-SOURCES = ["kernels_pipe.hip", "kernels_single.hip", "kernels_wide.hip", "kernels_fold.hip", "bank.hip", "jit.hip"]
-HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
+SOURCES = ["kernels_pipe.hip", "kernels_single.hip", "kernels_wide.hip", "kernels_fold.hip", "bank.hip", "jit.hip", "comm.hip"]
+HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", "rank_bank.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
            os.path.join("..", "build.py")]
 FLAGS = [
     "--offload-arch=gfx950",

@@ -273,6 +273,7 @@ struct knh_bank {
   virtual int debug_read(uint32_t* out16) = 0;
   virtual int timing_reset(int enable) = 0;
   virtual int timing_read(double* ms, uint64_t* launches) = 0;
+  virtual uint32_t ranks() const { return 1; }
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -1494,11 +1495,14 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
 }  // namespace
 
 #include "host_shards.hpp"
+#include "rank_bank.hpp"
 
 namespace {
 // K host threads: the bank is cut into K voice ranges of whole 64-voice groups (fewer when there are fewer groups).
+// devices (or null): range k lives on devices[k] (knh_bank_create_multi_device); host_threads == the number of devices then
 template <typename F>
-knh_bank* make_sharded(const knh_bank_desc& d, const knh::KernelEntry* entry, const std::string& sig, uint32_t host_threads) {
+knh_bank* make_sharded(const knh_bank_desc& d, const knh::KernelEntry* entry, const std::string& sig, uint32_t host_threads,
+                       const int32_t* devices = nullptr) {
   const uint32_t groups = (d.n_voices + 63u) / 64u;
   const uint32_t k = std::min(host_threads, groups);
   const uint32_t per = ((groups + k - 1) / k) * 64u;
@@ -1509,6 +1513,10 @@ knh_bank* make_sharded(const knh_bank_desc& d, const knh::KernelEntry* entry, co
   for (uint32_t v = 0; v < d.n_voices; v += per) {
     knh_bank_desc dk = d;
     dk.n_voices = std::min(per, d.n_voices - v);
+    if (devices) {
+      dk.device = devices[b->shard.size()];
+      b->shard_device.push_back(dk.device);
+    }
     b->base.push_back(v);
     b->shard.emplace_back(make_bank<F>(dk, entry, sig));
   }
@@ -1516,6 +1524,37 @@ knh_bank* make_sharded(const knh_bank_desc& d, const knh::KernelEntry* entry, co
   b->stages = b->shard[0]->stages;
   b->n_slots = b->shard[0]->n_slots;
   b->n_params_total = b->shard[0]->n_params_total;
+  b->desc.stages = nullptr;
+  return b;
+}
+}  // namespace
+
+namespace {
+template <typename F>
+knh_bank* make_rank_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const std::string& sig, uint32_t rank, uint32_t world,
+                                const uint8_t* comm_id, knh_reduce_fn reduce, void* user) {
+  auto* b = new RankBank<F>();
+  b->desc = d;
+  b->total = d.n_voices;
+  b->rank = rank;
+  b->world = world;
+  uint32_t first = 0, count = 0;
+  shard_voice_range(d.n_voices, rank, world, &first, &count);
+  b->lo = first;
+  b->hi = first + count;
+  if (comm_id) std::memcpy(b->comm_id, comm_id, KNH_COMM_ID_BYTES);
+  b->custom = reduce;
+  b->custom_user = user;
+  // the rank's own voices: an ordinary bank (host-sharded when KNH_HOST_THREADS asks for it) on this rank's device
+  knh_bank_desc dl = d;
+  dl.n_voices = count ? count : 1;
+  const char* env = std::getenv("KNH_HOST_THREADS");
+  const long k = env ? std::strtol(env, nullptr, 10) : 0;
+  std::unique_ptr<knh_bank> proto(k >= 2 && k <= 64 && dl.n_voices > 64 ? make_sharded<F>(dl, entry, sig, static_cast<uint32_t>(k)) : make_bank<F>(dl, entry, sig));
+  b->stages = proto->stages;
+  b->n_slots = proto->n_slots;
+  b->n_params_total = proto->n_params_total;
+  if (count) b->local = std::move(proto);
   b->desc.stages = nullptr;
   return b;
 }
@@ -1562,6 +1601,67 @@ int32_t knh_chain_ugen_count(const knh_stage_desc* stages, uint32_t n_stages) {
     if (stages[i].kind < KNH_STAGE_KIND_COUNT) n += kKinds[stages[i].kind].n_nodes;
   return n;
 }
+
+static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank);
+
+// The checks every way of creating a bank shares; on success *sig is the chain's device signature.
+static int32_t check_desc(const knh_bank_desc* desc, knh_bank** out_bank, std::string* sig) {
+  if (out_bank) *out_bank = nullptr;
+  if (!desc || !out_bank) { g_create_error = "null argument"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->abi_version != KNH_ABI_VERSION) { g_create_error = "ABI version mismatch"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->n_voices == 0 || !desc->stages) { g_create_error = "n_voices must be > 0 and stages non-null"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->sample_type > KNH_F64) { g_create_error = "unknown sample type"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->out_channels < 1 || desc->out_channels > 2) { g_create_error = "out_channels must be 1 or 2"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->mix_mode > KNH_MIX_LEFT_FOLD) { g_create_error = "unknown mix mode"; return KNH_ERR_INVALID_ARGUMENT; }
+  std::string why;
+  int rc = build_signature(desc->stages, desc->n_stages, sig, &why);
+  if (rc != KNH_OK) { g_create_error = why; return rc; }
+  if (sig->back() == '2' && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
+  return KNH_OK;
+}
+
+int32_t knh_bank_create_multi_device(const knh_bank_desc* desc, const int32_t* devices, uint32_t n_devices, knh_bank** out_bank) {
+  std::string sig;
+  int rc = check_desc(desc, out_bank, &sig);
+  if (rc != KNH_OK) return rc;
+  if (!devices || n_devices == 0 || n_devices > 64) { g_create_error = "devices: 1 to 64 device ordinals"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->mix_mode != KNH_MIX_TREE) { g_create_error = "a bank sharded over several GPUs mixes with KNH_MIX_TREE (the sum over GPUs re-associates)"; return KNH_ERR_INVALID_ARGUMENT; }
+  int visible = 0;
+  (void)hipGetDeviceCount(&visible);
+  for (uint32_t k = 0; k < n_devices; ++k)
+    if (devices[k] < 0 || devices[k] >= std::max(visible, 1)) { g_create_error = "devices: ordinal out of range"; return KNH_ERR_INVALID_ARGUMENT; }
+  const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
+  *out_bank = desc->sample_type == KNH_F64 ? make_sharded<double>(*desc, entry, sig, n_devices, devices) : make_sharded<float>(*desc, entry, sig, n_devices, devices);
+  return KNH_OK;
+}
+
+int32_t knh_shard_voice_range(uint32_t n_voices, uint32_t rank, uint32_t world, uint32_t* first, uint32_t* count) {
+  if (world == 0 || rank >= world || !first || !count) return KNH_ERR_INVALID_ARGUMENT;
+  shard_voice_range(n_voices, rank, world, first, count);
+  return KNH_OK;
+}
+
+static int32_t create_rank_bank(const knh_bank_desc* desc, uint32_t rank, uint32_t world, const uint8_t* comm_id, knh_reduce_fn reduce, void* user,
+                                knh_bank** out_bank) {
+  std::string sig;
+  int rc = check_desc(desc, out_bank, &sig);
+  if (rc != KNH_OK) return rc;
+  if (world == 0 || rank >= world) { g_create_error = "rank must be below world"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (world > 1 && !comm_id && !reduce) { g_create_error = "more than one rank needs a communicator id (knh_comm_unique_id) or a reduce function"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->mix_mode != KNH_MIX_TREE) { g_create_error = "a bank sharded over several GPUs mixes with KNH_MIX_TREE (the sum over GPUs re-associates)"; return KNH_ERR_INVALID_ARGUMENT; }
+  const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
+  *out_bank = desc->sample_type == KNH_F64 ? make_rank_bank<double>(*desc, entry, sig, rank, world, comm_id, reduce, user)
+                                          : make_rank_bank<float>(*desc, entry, sig, rank, world, comm_id, reduce, user);
+  return KNH_OK;
+}
+int32_t knh_bank_create_rank(const knh_bank_desc* desc, uint32_t rank, uint32_t world, const uint8_t* comm_id, knh_bank** out_bank) {
+  return create_rank_bank(desc, rank, world, comm_id, nullptr, nullptr, out_bank);
+}
+int32_t knh_bank_create_rank_custom(const knh_bank_desc* desc, uint32_t rank, uint32_t world, knh_reduce_fn reduce, void* user, knh_bank** out_bank) {
+  if (world > 1 && !reduce) { g_create_error = "null reduce function"; if (out_bank) *out_bank = nullptr; return KNH_ERR_INVALID_ARGUMENT; }
+  return create_rank_bank(desc, rank, world, nullptr, reduce, user, out_bank);
+}
+uint32_t knh_bank_ranks(const knh_bank* bank) { return bank ? bank->ranks() : 0; }
 
 static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank) {
   if (out_bank) *out_bank = nullptr;

@@ -9,6 +9,11 @@
 // range's kernel on the range's stream.  The K partial mixes are then summed on the caller's stream in range order
 // (sum_shards_kernel).  Included by bank.hip only; it is not a second engine, every range is a Bank<F>.
 //
+// The ranges may also live on DIFFERENT GPUs of the node (knh_bank_create_multi_device): range k is then a bank on
+// devices[k] with its stream and its worker thread there, its mix is copied peer-to-peer (xGMI) into slot k of the
+// staging buffer on devices[0], and the sum on devices[0] runs as before, in range order -- the one-shot direct sum of
+// deterministic, one 4..8 KiB-per-block copy per GPU per launch, no ring.
+//
 // Only for KNH_MIX_TREE banks: the tree mix is already "deterministic, within 1e-5 of the left fold", and a sum of K
 // range mixes is one more such grouping; KNH_MIX_LEFT_FOLD (the reference's exact order) keeps one range.
 #pragma once
@@ -23,6 +28,8 @@ struct ShardedBank final : knh_bank {
   uint32_t per_shard = 0;        // voices per shard (a multiple of 64; the last one may hold fewer)
   uint32_t nv = 0;
   std::unique_ptr<ShardWorkers> workers;
+  std::vector<int> shard_device;  // device of each range; empty: all on the bank's device
+  std::vector<F*> d_local;        // multi-device: a range's mix on its own device, before the peer copy
   std::vector<hipStream_t> streams;
   std::vector<hipEvent_t> shard_done;
   hipEvent_t sum_done = nullptr;
@@ -39,9 +46,16 @@ struct ShardedBank final : knh_bank {
     workers.reset();
     if (device >= 0 && initialised) (void)hipSetDevice(device);
     if (initialised) (void)hipDeviceSynchronize();
+    if (initialised && multi_device())
+      for (int k = 0; k < n(); ++k) { (void)hipSetDevice(dev_of(k)); (void)hipDeviceSynchronize(); }
     shard.clear();
-    for (hipStream_t s : streams) if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : shard_done) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < static_cast<int>(streams.size()); ++k) {
+      if (multi_device()) (void)hipSetDevice(dev_of(k));
+      if (streams[k]) (void)hipStreamDestroy(streams[k]);
+      if (k < static_cast<int>(shard_done.size()) && shard_done[k]) (void)hipEventDestroy(shard_done[k]);
+      if (k < static_cast<int>(d_local.size()) && d_local[k]) (void)hipFree(d_local[k]);
+    }
+    if (device >= 0 && initialised) (void)hipSetDevice(device);
     if (sum_done) (void)hipEventDestroy(sum_done);
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (d_parts) (void)hipFree(d_parts);
@@ -49,6 +63,9 @@ struct ShardedBank final : knh_bank {
     if (h_out) (void)hipHostFree(h_out);
   }
   int n() const { return static_cast<int>(shard.size()); }
+  uint32_t ranks() const override { return static_cast<uint32_t>(shard.size()); }
+  bool multi_device() const { return !shard_device.empty(); }
+  int dev_of(int k) const { return multi_device() ? shard_device[static_cast<size_t>(k)] : device; }
   int adopt(int k, int rc) {  // a shard's error becomes the bank's
     if (rc != KNH_OK) err = shard[k]->err;
     return rc;
@@ -84,14 +101,16 @@ struct ShardedBank final : knh_bank {
     device = shard[0]->device;
     sample_rate = sr;
     block_size = bs;
-    KNH_HIP(hipSetDevice(device));
-    KNH_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
     streams.assign(n(), nullptr);
     shard_done.assign(n(), nullptr);
+    d_local.assign(n(), nullptr);
     for (int k = 0; k < n(); ++k) {
+      KNH_HIP(hipSetDevice(dev_of(k)));
       KNH_HIP(hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking));
       KNH_HIP(hipEventCreateWithFlags(&shard_done[k], hipEventDisableTiming));
     }
+    KNH_HIP(hipSetDevice(device));
+    KNH_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
     KNH_HIP(hipEventCreateWithFlags(&sum_done, hipEventDisableTiming));
     workers.reset(new ShardWorkers(n()));
     rcs.assign(n(), KNH_OK);
@@ -203,6 +222,16 @@ struct ShardedBank final : knh_bank {
       d_parts = nullptr;
       KNH_HIP(hipMalloc(&d_parts, elems * n() * sizeof(F)));
       KNH_HIP(hipMemsetAsync(d_parts, 0, elems * n() * sizeof(F), s));
+      for (int k = 0; k < n() && multi_device(); ++k) {  // a range on another GPU renders into memory of its own device
+        if (dev_of(k) == device) continue;
+        KNH_HIP(hipSetDevice(dev_of(k)));
+        KNH_HIP(hipDeviceSynchronize());
+        if (d_local[k]) KNH_HIP(hipFree(d_local[k]));
+        d_local[k] = nullptr;
+        KNH_HIP(hipMalloc(&d_local[k], elems * sizeof(F)));
+        KNH_HIP(hipMemset(d_local[k], 0, elems * sizeof(F)));
+      }
+      KNH_HIP(hipSetDevice(device));
       if (d_out) { KNH_HIP(hipFree(d_out)); d_out = nullptr; }
       if (h_out) { KNH_HIP(hipHostFree(h_out)); h_out = nullptr; }
       cap_blocks = cap;
@@ -230,17 +259,24 @@ struct ShardedBank final : knh_bank {
     if (rc != KNH_OK) return rc;
     const size_t elems = static_cast<size_t>(cap_blocks) * desc.out_channels * block_size;  // per shard
     const bool pending = sum_pending;
+    const size_t n_out_elems = static_cast<size_t>(n_blocks) * desc.out_channels * block_size;
     workers->run([&](int k) {
-      if (hipSetDevice(device) != hipSuccess) { rcs[k] = KNH_ERR_DEVICE; return; }
+      if (hipSetDevice(dev_of(k)) != hipSuccess) { rcs[k] = KNH_ERR_DEVICE; return; }
       apply_deferred(k);
       // the previous launch's sum must be done with this shard's mix before the shard overwrites it
       if (pending && hipStreamWaitEvent(streams[k], sum_done, 0) != hipSuccess) { rcs[k] = KNH_ERR_DEVICE; return; }
       void* vh = voices_host ? static_cast<void*>(static_cast<F*>(voices_host) + static_cast<size_t>(base[k]) * block_size) : nullptr;
       // with a host destination the shard also waits for its stream (per-voice rows, flags); its mix stays on the device
       shard_flags[k] = 0;
-      rcs[k] = shard[k]->process(n_blocks, ftp, offset, clock, nullptr, d_parts + k * elems, vh, &shard_flags[k], streams[k], sync, false);
+      F* slot = d_parts + k * elems;                     // on the bank's (first) device
+      F* mix = d_local[k] ? d_local[k] : slot;           // where this range's kernels write
+      rcs[k] = shard[k]->process(n_blocks, ftp, offset, clock, nullptr, mix, vh, &shard_flags[k], streams[k], sync, false);
+      // a range on another GPU: its blocks cross to the first device in one peer-to-peer copy (xGMI), in the range's stream
+      if (rcs[k] == KNH_OK && mix != slot &&
+          hipMemcpyPeerAsync(slot, device, mix, dev_of(k), n_out_elems * sizeof(F), streams[k]) != hipSuccess) rcs[k] = KNH_ERR_DEVICE;
       if (rcs[k] == KNH_OK && hipEventRecord(shard_done[k], streams[k]) != hipSuccess) rcs[k] = KNH_ERR_DEVICE;
     });
+    KNH_HIP(hipSetDevice(device));
     n_deferred = 0;
     for (int k = 0; k < n(); ++k) {
       if (rcs[k] == KNH_ERR_DEVICE && shard[k]->err.empty()) return fail(KNH_ERR_DEVICE, "HIP error in a shard worker");
@@ -281,16 +317,22 @@ struct ShardedBank final : knh_bank {
   int read_done_frames(uint32_t* out) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
     if (!out) return fail(KNH_ERR_INVALID_ARGUMENT, "null output");
-    KNH_HIP(hipSetDevice(device));
-    KNH_HIP(hipDeviceSynchronize());
+    int rcs_ = synchronize();
+    if (rcs_ != KNH_OK) return rcs_;
     for (int k = 0; k < n(); ++k) {
       int rc = shard[k]->read_done_frames(out + base[k]);
       if (rc != KNH_OK) return adopt(k, rc);
     }
+    KNH_HIP(hipSetDevice(device));
     return KNH_OK;
   }
   int synchronize() override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    for (int k = 0; k < n() && multi_device(); ++k) {
+      if (dev_of(k) == device) continue;
+      KNH_HIP(hipSetDevice(dev_of(k)));
+      KNH_HIP(hipDeviceSynchronize());
+    }
     KNH_HIP(hipSetDevice(device));
     KNH_HIP(hipDeviceSynchronize());
     return KNH_OK;

@@ -1,9 +1,11 @@
-"""Voice banks sharded over the GPUs of one node: one process per GPU, contiguous voice ranges,
-no data-path collective except the sum of the per-rank stereo blocks.
+"""The sharding arithmetic of a voice bank spread over the GPUs of one node, restated in Python for hosts and tests.
 
-The collective is torch.distributed's reduce (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests).  A stereo block is 4 KiB, so the reduce is latency-bound: it is issued
-once per multi-block launch on the whole [n_blocks][channels][block_size] batch, never per block.
+The product's multi-GPU path lives in the library: knh_bank_create_rank (one process per GPU, RCCL ncclReduce of
+each launch's stereo blocks, knaster_amd/csrc/rank_bank.hpp + comm.hip) and knh_bank_create_multi_device (one
+process, peer-to-peer copies + a sum in range order, host_shards.hpp); bench.py runs the former.  This module holds
+`shard_range` / `owner_of` -- the same voice ranges as knh_shard_voice_range, checked against it by
+tests/test_sharded_gloo.py -- and `ShardedBank`, the same control flow (route by voice, process, sum-reduce) over any
+object with a bank's surface, which the CPU tests drive with world_size 2 over gloo and a CPU stand-in as the local bank.
 """
 from __future__ import annotations
 
@@ -14,18 +16,20 @@ import numpy as np
 
 
 def shard_range(n_voices: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous voice range [lo, hi) owned by `rank`: rank r of R owns [r*N/R, (r+1)*N/R)."""
+    """Contiguous voice range [lo, hi) owned by `rank`: the 64-voice groups (one wavefront each) are dealt out as evenly
+    as they go -- rank r of R owns groups [r*G/R, (r+1)*G/R).  For N a multiple of 64*R this is [r*N/R, (r+1)*N/R).
+    Mirrors knh_shard_voice_range (rank_bank.hpp)."""
     if not (0 <= rank < world):
         raise ValueError("rank out of range")
-    return (n_voices * rank) // world, (n_voices * (rank + 1)) // world
+    groups = (n_voices + 63) // 64
+    return min(groups * rank // world * 64, n_voices), min(groups * (rank + 1) // world * 64, n_voices)
 
 
 def owner_of(voice: int, n_voices: int, world: int) -> Tuple[int, int]:
     """(rank, local voice index) of a global voice: parameter/event routing on the host."""
     if not (0 <= voice < n_voices):
         raise IndexError("voice out of range")
-    # smallest r with (n*(r+1))//world > voice
-    r = min(world - 1, (voice * world) // n_voices)
+    r = min(world - 1, (voice * world) // max(n_voices, 1))
     while shard_range(n_voices, r, world)[1] <= voice:
         r += 1
     while shard_range(n_voices, r, world)[0] > voice:

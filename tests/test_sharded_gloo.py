@@ -29,6 +29,25 @@ def test_shard_ranges_partition_the_voices():
     assert shard_range(65536, 3, 8) == (24576, 32768)  # C4: 8192 voices per GPU
 
 
+def test_shard_ranges_are_the_library_s(knh):
+    """knaster_amd.sharded.shard_range restates knh_shard_voice_range (the ranges knh_bank_create_rank uses): whole
+    64-voice groups, as even as they go.  Needs the library, not a GPU."""
+    from knaster_amd import shard_voice_range
+    from knaster_amd.sharded import shard_range
+
+    for n in (1, 63, 64, 65, 130, 1000, 16384, 65536, 100000):
+        for world in (1, 2, 3, 4, 8):
+            nxt = 0
+            for r in range(world):
+                first, count = shard_voice_range(n, r, world)
+                assert (first, first + count) == shard_range(n, r, world)
+                assert first == nxt and (first % 64 == 0 or count == 0)
+                nxt = first + count
+            assert nxt == n
+    with pytest.raises(ValueError):
+        shard_voice_range(10, 2, 2)
+
+
 class _OracleLocal:
     """An object with VoiceBank's multi-block surface, computed by the oracle (tests only)."""
 
