@@ -739,7 +739,7 @@ struct Bank final : knh_bank {
     KNH_HIP(hipMalloc(&d_flags, 32 * sizeof(uint32_t)));
     KNH_HIP(hipMemset(d_flags, 0, 32 * sizeof(uint32_t)));
     for (int b = 0; b < 2; ++b) {
-      KNH_HIP(hipHostMalloc(&h_ev_start2[b], (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
+      KNH_HIP(hipHostMalloc(&h_ev_start2[b], (static_cast<size_t>(nv) + 2) * sizeof(uint32_t)));
       KNH_HIP(hipEventCreateWithFlags(&list_done[b], hipEventDisableTiming));
     }
     KNH_HIP(hipHostMalloc(&h_out, desc.out_channels * bs * sizeof(F) + 2 * sizeof(uint32_t)));
@@ -884,10 +884,64 @@ struct Bank final : knh_bank {
     return KNH_OK;
   }
 
+  // A parameter whose device patches depend on the new value alone (no shadow of an earlier value is read, and no other
+  // parameter's patches touch the same words): a call for a later block of the launch can be turned into its patches
+  // at once, instead of being kept and replayed when that block is assembled.  Stages wrapped in WrPreciseTiming or
+  // WrSmoothParams keep state on the host per call and always take the general path.
+  bool direct_ok(const StageInfo& S, uint32_t param) const {
+    if (S.dcpb > 0 || (S.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS)) return false;
+    switch (S.kind) {
+      case KNH_STAGE_SVF: return false;             // every setter recomputes from the three shadows
+      case KNH_STAGE_BUFFER_READER: return false;   // start / duration / rate shadows
+      case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: return param >= 2;  // the times skip when unchanged (shadow); the triggers do not
+      default: return true;
+    }
+  }
+  // knh_bank_param_apply_many[_at]: runs of calls to the same (stage, parameter, kind) -- how a host sends "this parameter
+  // of these voices" -- are checked once and turned into patches in one pass; anything else goes call by call.
+  int apply_many(uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stgs, const uint32_t* params,
+                 const uint32_t* kinds, const double* fvalues, const int64_t* ivalues, const uint16_t* delays) override {
+    if (!initialised || count < 16 || block_offset >= 65536) return knh_bank::apply_many(block_offset, count, voices, stgs, params, kinds, fvalues, ivalues, delays);
+    int rc = KNH_OK;
+    size_t k = 0;
+    while (k < count) {
+      size_t e = k + 1;
+      while (e < count && stgs[e] == stgs[k] && params[e] == params[k] && kinds[e] == kinds[k]) ++e;
+      bool direct = e - k >= 16 && stgs[k] < stages.size() && params[k] < static_cast<uint32_t>(stages[stgs[k]].n_params) &&
+                    kind_ok(stages[stgs[k]], params[k], kinds[k]) && direct_ok(stages[stgs[k]], params[k]);
+      if (direct && delays)
+        for (size_t q = k; q < e && direct; ++q) direct = delays[q] == 0;  // an armed delay on an unwrapped stage: the warning path
+      if (direct) {
+        const uint32_t stage = stgs[k], param = params[k];
+        const uint32_t frame = block_offset * static_cast<uint32_t>(block_size);
+        pending.reserve(pending.size() + (e - k) * 2);
+        for (size_t q = k; q < e; ++q) {
+          const uint32_t v = voices[q];
+          if (v >= nv) { rc = fail(KNH_ERR_OUT_OF_RANGE, "voice out of range"); continue; }
+          apply_now(v, stage, param, fvalues ? fvalues[q] : 0.0, ivalues ? ivalues[q] : 0, frame, pending);
+        }
+      } else {
+        int r = knh_bank::apply_many(block_offset, e - k, voices + k, stgs + k, params + k, kinds + k, fvalues ? fvalues + k : nullptr,
+                                     ivalues ? ivalues + k : nullptr, delays ? delays + k : nullptr);
+        if (r != KNH_OK) rc = r;
+      }
+      k = e;
+    }
+    return rc;
+  }
+
   // The parameter setters of each UGen, restated as "new shadow value -> device patches".
+  // Events reach `pending` in application order; a voice's list must also be in frame order.  As long as every new event's
+  // frame is at least the largest one seen, both hold by construction and the per-voice sort of upload_events is skipped.
+  uint32_t pending_max_frame = 0;
+  void note_frame(uint32_t frame) {
+    if (frame < pending_max_frame) pending_needs_sort = true;
+    else pending_max_frame = frame;
+  }
   void apply_now(uint32_t v, uint32_t stage, uint32_t param, double f, int64_t iv, uint32_t frame, std::vector<HostEvent>& out) {
     const StageInfo& S = stages[stage];
     Shadow& sh = shadow[stage];
+    note_frame(frame);
     auto set = [&](int rel, uint64_t bits) { out.push_back(HostEvent{v, frame, knh_dev::EV_SET, static_cast<uint32_t>(S.slot_base + rel), bits}); };
     const F sr_as_f32 = static_cast<F>(static_cast<float>(sample_rate));
     switch (S.kind) {
@@ -1131,10 +1185,33 @@ struct Bank final : knh_bank {
   }
 
   // ---- processing ---------------------------------------------------------------------------
-  int upload_events(hipStream_t s, bool* have_events) {
+  // Events addressed past the blocks of this launch (a call for block k of a later launch, turned into patches at once):
+  // they stay in `pending`, k launches' worth of blocks earlier, for the next launch.
+  std::vector<HostEvent> later;
+  int upload_events(hipStream_t s, bool* have_events, uint32_t n_blocks) {
     *have_events = false;
+    later.clear();
+    const uint64_t horizon = static_cast<uint64_t>(n_blocks) * block_size;
+    if (pending_max_frame >= horizon && !pending.empty()) {
+      size_t w = 0;
+      for (const HostEvent& e : pending) {
+        if (e.frame >= horizon) { later.push_back(e); later.back().frame -= static_cast<uint32_t>(horizon); }
+        else pending[w++] = e;
+      }
+      pending.resize(w);
+    }
     const size_t total = pending.size();
-    if (total == 0) return KNH_OK;
+    auto finish = [&] {
+      pending.clear();
+      pending_needs_sort = false;
+      pending_max_frame = 0;
+      if (!later.empty()) {
+        pending.swap(later);
+        pending_needs_sort = true;  // conservatively: their order among what arrives next is not tracked
+        for (const HostEvent& e : pending) pending_max_frame = std::max(pending_max_frame, e.frame);
+      }
+    };
+    if (total == 0) { finish(); return KNH_OK; }
     const unsigned lb = list_parity;
     list_parity ^= 1u;
     if (list_busy[lb]) {  // the kernel that read this buffer two launches ago must be done with it
@@ -1151,18 +1228,19 @@ struct Bank final : knh_bank {
     h_ev_start = h_ev_start2[lb];
     h_events = h_events2[lb];
     list_in_use = static_cast<int>(lb);
-    // counting sort by voice (stable: keeps application order), then each voice's few events by frame (stable)
-    std::fill(h_ev_start, h_ev_start + nv + 1, 0u);
-    for (const HostEvent& e : pending) h_ev_start[e.voice + 1]++;
-    for (uint32_t v = 0; v < nv; ++v) h_ev_start[v + 1] += h_ev_start[v];
-    cursor.assign(h_ev_start, h_ev_start + nv);
+    // counting sort by voice (stable: keeps application order): counts two places up, so that after the prefix sum
+    // start[v + 1] is where voice v's events begin, and after the scatter (which advances it) where voice v + 1's do
+    uint32_t* start = h_ev_start;  // nv + 2 words
+    std::fill(start, start + nv + 2, 0u);
+    for (const HostEvent& e : pending) start[e.voice + 2]++;
+    for (uint32_t v = 0; v < nv; ++v) start[v + 2] += start[v + 1];
     for (const HostEvent& e : pending) {
-      Event& d = h_events[cursor[e.voice]++];
+      Event& d = h_events[start[e.voice + 1]++];
       d.frame = e.frame;
       d.slot_op = (e.slot & 0xFFFFFFu) | (e.op << 24);
       d.bits = e.bits;
     }
-    if (pending_needs_sort) {
+    if (pending_needs_sort) {  // then each voice's few events by frame (stable)
       for (uint32_t v = 0; v < nv; ++v) {
         Event* b = h_events + h_ev_start[v];
         Event* e = h_events + h_ev_start[v + 1];
@@ -1171,12 +1249,10 @@ struct Bank final : knh_bank {
       }
     }
     (void)s;
-    pending.clear();
-    pending_needs_sort = false;
+    finish();
     *have_events = true;
     return KNH_OK;
   }
-  std::vector<uint32_t> cursor;
 
   int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t /*clock*/, void* out_host, void* out_device, void* voices_host,
               uint32_t* out_flags, void* stream, bool sync, bool accumulate) override {
@@ -1197,13 +1273,12 @@ struct Bank final : knh_bank {
           if (c.is_delay) set_delay(c.voice, c.stage, c.param, c.delay);
           else param_apply(c.voice, c.stage, c.param, c.kind, c.f, c.i);
         }
-        if (!future[b].empty()) pending_needs_sort = pending_needs_sort || n_blocks > 1;
       }
       resolve_queues(fb, fe);
     }
     frame_base = 0;
     bool have_events = false;
-    int rc = upload_events(s, &have_events);
+    int rc = upload_events(s, &have_events, n_blocks);
     if (rc != KNH_OK) return rc;
     if (!future.empty()) {  // calls addressed beyond this launch move up; those now due for the next
                             // block are applied right away, ahead of anything that arrives later

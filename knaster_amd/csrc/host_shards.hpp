@@ -113,6 +113,7 @@ struct ShardedBank final : knh_bank {
     KNH_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
     KNH_HIP(hipEventCreateWithFlags(&sum_done, hipEventDisableTiming));
     workers.reset(new ShardWorkers(n()));
+    scratch.assign(static_cast<size_t>(n()), Scratch{});
     rcs.assign(n(), KNH_OK);
     shard_flags.assign(n(), 0u);
     initialised = true;
@@ -132,17 +133,31 @@ struct ShardedBank final : knh_bank {
   std::vector<Batch> deferred;
   size_t n_deferred = 0;  // batches in use (the vectors keep their capacity)
 
+  struct Scratch {  // a batch's calls for one range, with the range's own voice indices
+    std::vector<uint32_t> voices, stgs, params, kinds;
+    std::vector<double> f;
+    std::vector<int64_t> i;
+    std::vector<uint16_t> d;
+  };
+  std::vector<Scratch> scratch;
   void apply_deferred(int k) {  // on worker k
     knh_bank* b = shard[k].get();
     const uint32_t lo = base[k], hi = base[k + 1];
+    Scratch& S = scratch[static_cast<size_t>(k)];
     for (size_t q = 0; q < n_deferred; ++q) {
       const Batch& B = deferred[q];
+      S.voices.clear(); S.stgs.clear(); S.params.clear(); S.kinds.clear(); S.f.clear(); S.i.clear(); S.d.clear();
       for (size_t i = 0; i < B.count; ++i) {
         const uint32_t v = B.voices[i];
         if (v < lo || v >= hi) continue;
-        if (B.has_d && B.d[i] > 0) (void)b->call_at(B.block_offset, true, v - lo, B.stgs[i], B.params[i], 0, 0.0, 0, B.d[i]);
-        (void)b->call_at(B.block_offset, false, v - lo, B.stgs[i], B.params[i], B.kinds[i], B.has_f ? B.f[i] : 0.0, B.has_i ? B.i[i] : 0, 0);
+        S.voices.push_back(v - lo); S.stgs.push_back(B.stgs[i]); S.params.push_back(B.params[i]); S.kinds.push_back(B.kinds[i]);
+        if (B.has_f) S.f.push_back(B.f[i]);
+        if (B.has_i) S.i.push_back(B.i[i]);
+        if (B.has_d) S.d.push_back(B.d[i]);
       }
+      if (!S.voices.empty())  // the range's bank turns runs of one (stage, parameter, kind) into patches in one pass
+        (void)b->apply_many(B.block_offset, S.voices.size(), S.voices.data(), S.stgs.data(), S.params.data(), S.kinds.data(),
+                            B.has_f ? S.f.data() : nullptr, B.has_i ? S.i.data() : nullptr, B.has_d ? S.d.data() : nullptr);
     }
   }
   void flush_deferred() {

@@ -402,3 +402,55 @@ def test_host_sharded_bank_equals_single_bank(knh, name, n_voices, block_size, t
     with pytest.raises(L.KnasterHipError) as e:
         b.param_apply(n_voices - 1, 99, 0, 1.0)
     assert e.value.status == L.ERR_OUT_OF_RANGE
+
+
+@pytest.mark.parametrize("host_threads", [0, 3])
+def test_batched_calls_for_later_blocks_in_any_order(knh, host_threads):
+    """knh_bank_param_apply_many_at batches addressed to blocks of this launch and of later launches, submitted in scrambled
+    block order, mixing parameters whose patches are made at once (triggers, SinWt freq, wr_mul) with parameters replayed
+    when their block is assembled (every SvfFilter setter, the envelope times): same samples as the same calls made block
+    by block, each block's calls in their submission order (GraphGen applies a block's events in arrival order,
+    graph_gen.rs:110-166)."""
+    n, bs, n_blocks = 300, 64, 10
+    w = configs.config("C3", n_voices=n, block_size=bs)
+    v = np.arange(n, dtype=np.uint32)
+    F, T = L.VALUE_FLOAT, L.VALUE_TRIGGER
+    calls = [  # (block, voices, stage, param, kind, values)
+        (5, v, 3, 3, T, None),                          # t_restart again
+        (2, v[::2], 2, 0, F, 400.0 + 3.0 * v[::2]),     # SVF cutoff (shadowed)
+        (2, v, 0, 0, F, 110.0 + v),                     # SinWt freq
+        (0, v, 3, 3, T, None),                          # t_restart
+        (7, v[::3], 3, 2, T, None),                     # t_release
+        (5, v, 3, 0, F, 0.001 + 1e-5 * v),              # attack_time (skip-if-unchanged shadow)
+        (2, v[1::2], 2, 1, F, 0.7 + 0.01 * v[1::2]),    # SVF q, other voices
+        (2, v[::2], 2, 1, F, 1.5 + 0.0 * v[::2]),       # SVF q after the cutoff of the same voices, same block
+        (9, v, 1, 0, F, 0.5 / n + 0.0 * v),             # wr_mul
+        (3, v[::5], 2, 3, L.VALUE_INTEGER, 2 + 0 * v[::5]),  # SVF filter type
+        (8, v, 3, 2, T, None),
+        (6, v, 0, 1, F, 1000.0 + v),                    # phase_offset
+    ]
+
+    def send(bank, c, offset):
+        _, vs, stage, param, kind, vals = c
+        iv = vals.astype(np.int64) if kind == L.VALUE_INTEGER else None
+        fv = vals if kind == F else None
+        bank.param_apply_many(vs, stage, param, kind, fv, iv, None, block_offset=offset)
+    a = make_gpu(knh, w)
+    single = []
+    for block in range(n_blocks):
+        for c in calls:
+            if c[0] == block:
+                send(a, c, 0)
+        single.append(a.process_block()[0])
+    for split in ([10], [4, 6], [3, 3, 4], [1, 1, 1, 1, 1, 1, 1, 1, 1, 1]):
+        b = make_gpu(knh, w, host_threads=host_threads)
+        for c in calls:
+            send(b, c, c[0])
+        got = np.concatenate([b.process_blocks(k)[0] for k in split])
+        if host_threads:
+            assert np.max(np.abs(got.astype(np.float64) - np.stack(single))) <= 1e-5
+        else:
+            for block in range(n_blocks):
+                assert_bit_equal(got[block], single[block], f"split {split} block {block}")
+        b.close()
+    a.close()
