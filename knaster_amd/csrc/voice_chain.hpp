@@ -47,12 +47,24 @@ template <bool FMA> __device__ __forceinline__ double mad(double a, double b, do
   else return a * b + c;
 }
 
-// Rust `as u32` from f64: NaN -> 0, negative -> 0, too large -> u32::MAX (osc.rs:129).
+// Rust `as u32` from f64: NaN -> 0, negative -> 0, too large -> u32::MAX (osc.rs:129).  That is what the hardware
+// conversion does by itself (v_cvt_u32_f64: out-of-range values saturate, NaN gives 0); spelled as compares in C++ it
+// becomes two branches per sample (an out-of-range cast is undefined there, so the compiler guards the instruction).
 __device__ __forceinline__ u32 sat_u32(double v) {
-  if (!(v > 0.0)) return 0u;
-  if (v >= 4294967295.0) return 0xFFFFFFFFu;
-  return (u32)v;
+  u32 r;
+  asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
+  return r;
 }
+
+// What a stage is unless it says otherwise: none of its slots can be switched in the middle of a tile (see take_params).
+struct StageDefaults {
+  // Slots (bit k = the stage's slot k) that are PARAMETERS: read by tick, never written by it, so that a sample-accurate
+  // change of one is "use the new value from frame f on" and nothing else.  A tile in which voices have such changes
+  // runs stage by stage like any other tile, each sample taking over the new parameter values at its voice's frame
+  // (take_params, one compare and one select per parameter and sample) instead of dropping to the per-sample path.
+  static constexpr u32 kParamMask = 0u;
+  template <typename R> static __device__ __forceinline__ void take_params(R&, const R&, bool) {}
+};
 
 // Event opcodes (host -> device state patches, applied at an in-block frame).
 enum { EV_SET = 0, EV_ENV_ASR_RELEASE = 1, EV_NOP = 2, EV_SEGENV_STOP = 3, EV_ALLPASS_DELAY = 4, EV_SPLIT = 0x80 /* flag: change came out of a WrPreciseTiming queue */ };
@@ -84,7 +96,7 @@ struct Ctx {
 // SinWt -- knaster_core_dsp/src/ugens/osc.rs:97-168, wavetable.rs:21-60,322-324
 // slots: 0 phase, 1 phase_offset, 2 phase_increment
 template <bool AR_FREQ>
-struct SinWtT {
+struct SinWtT : StageDefaults {
   static constexpr int kSlots = 3;
   static constexpr u32 kMutableMask = AR_FREQ ? 0b101u : 0b001u;
   static constexpr bool kUsesSine = true;
@@ -92,6 +104,11 @@ struct SinWtT {
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { u32 phase, off, inc; };
+  static constexpr u32 kParamMask = AR_FREQ ? 0b010u : 0b110u;  // phase_offset, and the increment unless the signal drives it
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) {
+    r.off = c ? n.off : r.off;
+    if (!AR_FREQ) r.inc = c ? n.inc : r.inc;
+  }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
     r.phase = (u32)s[0]; r.off = (u32)s[stride]; r.inc = (u32)s[2 * stride];
@@ -129,7 +146,7 @@ typedef SinWtT<true> SinWtAr;
 
 // Phasor -- osc.rs:172-214: out = phase; phase += step; while phase >= 1 { phase -= 1 }.  Phase and step are f64 for
 // any F.  slots: 0,1 phase (low, high word)  2,3 step
-struct Phasor {
+struct Phasor : StageDefaults {
   static constexpr int kSlots = 4;
   static constexpr u32 kMutableMask = 0b0011u;
   static constexpr bool kUsesSine = false;
@@ -206,7 +223,7 @@ struct NoiseRng {
   }
 };
 // slots: 0,1 rng state (low, high word)
-struct WhiteNoise {
+struct WhiteNoise : StageDefaults {
   static constexpr int kSlots = 2;
   static constexpr u32 kMutableMask = 0b11u;
   static constexpr bool kUsesSine = false;
@@ -229,7 +246,7 @@ struct WhiteNoise {
   }
 };
 // BrownNoise -- noise.rs:119-156: last += white * 0.1; clamp to [-1, 1].  slots: 0,1 rng  2 last_output
-struct BrownNoise {
+struct BrownNoise : StageDefaults {
   static constexpr int kSlots = 3;
   static constexpr u32 kMutableMask = 0b111u;
   static constexpr bool kUsesSine = false;
@@ -269,7 +286,7 @@ struct BrownNoise {
 };
 // RandomLin -- noise.rs:158-230: random values in 0..1, a new one whenever the phase reaches 1, straight lines between.
 // slots: 0,1 rng  2 current_value  3 current_change_width  4 phase  5 phase_step (= freq / sample_rate, host side)
-struct RandomLin {
+struct RandomLin : StageDefaults {
   static constexpr int kSlots = 6;
   static constexpr u32 kMutableMask = 0b011111u;
   static constexpr bool kUsesSine = false;
@@ -315,7 +332,7 @@ struct RandomLin {
 // PinkNoise -- noise.rs:49-111 (Voss-McCartney, nine octaves).  slots: 0,1 rng  2 counter  3 pink  4 always_on
 // 5..13 white_noises[0..8].  The nine rows live in registers; the row to replace (counter.trailing_zeros()) is picked
 // with selects, not with an indexed access.
-struct PinkNoise {
+struct PinkNoise : StageDefaults {
   static constexpr int kSlots = 14;
   static constexpr u32 kMutableMask = 0x3FFFu;
   static constexpr bool kUsesSine = false;
@@ -377,7 +394,7 @@ struct PinkNoise {
 };
 
 // SafetyLimiter -- dynamics.rs:9-31: clamp to [-1, 1] (a NaN passes the clamp), then NaN -> 0.  No state.
-struct SafetyLimiter {
+struct SafetyLimiter : StageDefaults {
   static constexpr int kSlots = 0;
   static constexpr u32 kMutableMask = 0u;
   static constexpr bool kUsesSine = false;
@@ -406,7 +423,7 @@ struct SafetyLimiter {
 // (blamp).  Every waveform is + - * / and comparisons in the reference's order, except the four that call sin
 // (Sine, Cosine, Half/FullWaveRectifiedSine, and every waveform above sample_rate / 4): device libm, tolerance only.
 // slots: 0 t (phase 0..1)  1 dt = freq / sample_rate  2 pulse_width  3 waveform (u32)  4 dt * sample_rate >= sample_rate / 4
-struct PolyBlepOsc {
+struct PolyBlepOsc : StageDefaults {
   static constexpr int kSlots = 5;
   static constexpr u32 kMutableMask = 0b00001u;
   static constexpr bool kUsesSine = false;
@@ -604,7 +621,7 @@ struct PolyBlepOsc {
 // linear interpolation (Buffer::get_linear_interp_f64, :100-110), per-voice rate, start and end, looping or one-shot
 // (mark_done(i + 1) at the frame after the last one, then silence).  All positions are f64 for any F.
 // slots: 0,1 read_pointer  2,3 step (= base_rate * rate)  4,5 start_frame  6,7 end_frame  8 finished  9 looping
-struct BufferReader {
+struct BufferReader : StageDefaults {
   static constexpr int kSlots = 10;
   static constexpr u32 kMutableMask = 0b0100000011u;
   static constexpr bool kUsesSine = false;
@@ -676,7 +693,7 @@ struct BufferReader {
 };
 
 // SinNumeric -- osc.rs:222-271.  slots: 0 phase, 1 phase_offset, 2 phase_increment
-struct SinNum {
+struct SinNum : StageDefaults {
   static constexpr int kSlots = 3;
   static constexpr u32 kMutableMask = 0b001u;
   static constexpr bool kUsesSine = false;
@@ -684,6 +701,11 @@ struct SinNum {
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F phase, off, inc; };
+  static constexpr u32 kParamMask = 0b110u;
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) {
+    r.off = c ? n.off : r.off;
+    r.inc = c ? n.inc : r.inc;
+  }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
     r.phase = word_to_f<F>(s[0]); r.off = word_to_f<F>(s[stride]); r.inc = word_to_f<F>(s[2 * stride]);
@@ -717,7 +739,7 @@ struct SinNum {
 
 // SvfFilter tick -- svf.rs:272-278.  slots: 0 ic1eq, 1 ic2eq, 2 a1, 3 a2, 4 a3, 5 m0, 6 m1, 7 m2
 // All nine filter types share this tick; the type only changes the coefficients (host side).
-struct Svf {
+struct Svf : StageDefaults {
   static constexpr int kSlots = 8;
   static constexpr u32 kMutableMask = 0b11u;
   static constexpr bool kUsesSine = false;
@@ -725,6 +747,11 @@ struct Svf {
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m0, m1, m2; };
+  static constexpr u32 kParamMask = 0b11111100u;  // the six coefficients (every setter recomputes them on the host)
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) {
+    r.a1 = c ? n.a1 : r.a1; r.a2 = c ? n.a2 : r.a2; r.a3 = c ? n.a3 : r.a3;
+    r.m0 = c ? n.m0 : r.m0; r.m1 = c ? n.m1 : r.m1; r.m2 = c ? n.m2 : r.m2;
+  }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
     r.ic1 = word_to_f<F>(s[0]); r.ic2 = word_to_f<F>(s[st]); r.a1 = word_to_f<F>(s[2 * st]);
@@ -831,7 +858,7 @@ struct Svf {
 
 // OnePoleLpf / OnePoleHpf tick -- onepole.rs:64-92.  slots: 0 last_output, 1 a0, 2 b1
 template <bool HIGHPASS>
-struct OnePoleT {
+struct OnePoleT : StageDefaults {
   static constexpr int kSlots = 3;
   static constexpr u32 kMutableMask = 0b1u;
   static constexpr bool kUsesSine = false;
@@ -839,6 +866,11 @@ struct OnePoleT {
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F y, a0, b1; };
+  static constexpr u32 kParamMask = 0b110u;
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) {
+    r.a0 = c ? n.a0 : r.a0;
+    r.b1 = c ? n.b1 : r.b1;
+  }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
     r.y = word_to_f<F>(s[0]); r.a0 = word_to_f<F>(s[st]); r.b1 = word_to_f<F>(s[2 * st]);
@@ -870,7 +902,7 @@ typedef OnePoleT<true> OnePoleHp;
 // slots: 0 state, 1 t, 2 attack_rate, 3 release_rate, 4 release_scale
 // state: 0 Stopped, 1 Attacking, 2 Sustaining, 3 Releasing
 template <bool AR>
-struct MulEnvT {
+struct MulEnvT : StageDefaults {
   static constexpr int kSlots = 5;
   static constexpr u32 kMutableMask = 0b10011u;
   static constexpr bool kUsesSine = false;
@@ -878,6 +910,14 @@ struct MulEnvT {
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = true;  // r.seg: start of the (partial) block, for mark_done
   template <typename F> struct Regs { u32 state; F t, ar, rr, scale; u32 seg; };
+  // the two rates; `seg` (where the node's partial block began, set by any change that came out of a WrPreciseTiming
+  // queue) moves with them
+  static constexpr u32 kParamMask = 0b01100u;
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) {
+    r.ar = c ? n.ar : r.ar;
+    r.rr = c ? n.rr : r.rr;
+    r.seg = c ? n.seg : r.seg;
+  }
   template <typename F> static __device__ __forceinline__ bool is_stopped(const Regs<F>& r) { return r.state == 0u; }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -1142,7 +1182,7 @@ typedef MulEnvT<true> MulAr;
 // slots (one word each; doubles take two, low word first):
 //   0 running  1 current_segment  2,3 current_time  4,5 from_value  6,7 dt (= time_scale * base_scale)
 //   8 n_segments  9 looping  10 row of this voice in the segment table
-struct MulSegEnv {
+struct MulSegEnv : StageDefaults {
   static constexpr int kSlots = 11;
   static constexpr u32 kMutableMask = 0b111111u;
   static constexpr bool kUsesSine = false;
@@ -1258,7 +1298,7 @@ struct MulSegEnv {
 // (0..len), 2 len, 3 the voice's ring row.  A tile whose reads cannot meet its own writes (delay >= T) and that does not
 // cross the end of the ring moves its T samples with 16-byte loads, then 16-byte stores; any other tile runs sample by
 // sample in the reference's order (store, then load).
-struct SampleDelay {
+struct SampleDelay : StageDefaults {
   static constexpr int kSlots = 4;
   static constexpr u32 kMutableMask = 0b1u;
   static constexpr bool kUsesSine = false;
@@ -1382,7 +1422,7 @@ struct SampleDelay {
 // FB = true: AllpassFeedbackDelay, the Schroeder allpass around it (delay.rs:210-306): d = read(); w = d * feedback + x;
 // write(w); out = d - feedback * w.
 template <bool FB>
-struct AllpassDelayT {
+struct AllpassDelayT : StageDefaults {
   static constexpr int kSlots = FB ? 8 : 7;
   static constexpr u32 kMutableMask = 0b1100011u;
   static constexpr bool kUsesSine = false;
@@ -1487,7 +1527,7 @@ typedef AllpassDelayT<true> AllpassFbDelay;
 static __device__ __forceinline__ float dev_pow(float a, float b) { return __ocml_pow_f32(a, b); }
 static __device__ __forceinline__ double dev_pow(double a, double b) { return __ocml_pow_f64(a, b); }
 template <int OP>
-struct ValT {
+struct ValT : StageDefaults {
   static constexpr int kSlots = 1;
   static constexpr u32 kMutableMask = 0u;
   static constexpr bool kUsesSine = false;
@@ -1495,6 +1535,8 @@ struct ValT {
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { F v; };
+  static constexpr u32 kParamMask = 0b1u;
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) { r.v = c ? n.v : r.v; }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.v = word_to_f<F>(s[0]); }
   template <typename F, typename W>
@@ -1529,7 +1571,7 @@ typedef ValT<6> PowVal;
 
 // x.powi(n): WrPowi (wrappers_core/math.rs:587-661).  f32::powi / f64::powi with a run-time exponent lower to
 // compiler-builtins' __powisf2 / __powidf2: multiply by squaring, reciprocal at the end for n < 0.  slot 0: n (i32)
-struct PowiVal {
+struct PowiVal : StageDefaults {
   static constexpr int kSlots = 1;
   static constexpr u32 kMutableMask = 0u;
   static constexpr bool kUsesSine = false;
@@ -1537,6 +1579,8 @@ struct PowiVal {
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = false;
   template <typename F> struct Regs { int n; };
+  static constexpr u32 kParamMask = 0b1u;
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) { r.n = c ? n.n : r.n; }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.n = (int)(u32)s[0]; }
   template <typename F, typename W>
@@ -1572,7 +1616,7 @@ struct PowiVal {
 // Pan2 outputs summed by its chain of Add nodes, one chain per output channel).  Gains change at block boundaries
 // only (the stage cannot be wrapped in WrPreciseTiming here), which are tile boundaries in every kernel form.
 // slots: 0 left_gain  1 right_gain
-struct Pan2 {
+struct Pan2 : StageDefaults {
   static constexpr int kSlots = 2;
   static constexpr u32 kMutableMask = 0u;
   static constexpr bool kUsesSine = false;
@@ -1607,6 +1651,8 @@ struct Chain<F, FMA, BASE> {
   static constexpr int kSlots = BASE;
   static constexpr bool kUsesSine = false;
   static constexpr bool kPan = false;
+  static constexpr u64 kParamBits = 0ull, kNopOkBits = 0ull;
+  template <int T> __device__ __forceinline__ void tick_tile_sw(const Chain&, u32, u64, F (&)[T], const Ctx&, u32) {}
   __device__ __forceinline__ void pan_gains(F&, F&) const {}
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
   template <typename W> __device__ __forceinline__ void store(W*, long) const {}
@@ -1623,6 +1669,12 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   static constexpr int kSlots = RestT::kSlots;
   static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
   static constexpr bool kPan = IsPan<S0>::value || RestT::kPan;  // the chain ends in a Pan2: two output channels per voice
+  // Absolute slots (bit = slot index, chains of up to 64 slots) that are parameters in the sense of
+  // StageDefaults::kParamMask, and stage base slots to which a split mark without a change (EV_NOP) may be addressed
+  // in the middle of a tile (the stage either carries its partial-block origin along in take_params or has none).
+  static constexpr u64 kStageBits = BASE + S0::kSlots <= 64 ? (((u64)1 << S0::kSlots) - 1) << (BASE < 64 ? BASE : 0) : 0ull;
+  static constexpr u64 kParamBits = (BASE + S0::kSlots <= 64 ? (u64)S0::kParamMask << (BASE < 64 ? BASE : 0) : 0ull) | RestT::kParamBits;
+  static constexpr u64 kNopOkBits = ((S0::kParamMask != 0u || !S0::kHasSeg) && BASE < 64 ? (u64)1 << (BASE < 64 ? BASE : 0) : 0ull) | RestT::kNopOkBits;
   typename S0::template Regs<F> r;
   // The frame this stage last passed to mark_done (UGenFlags::mark_done, ugen.rs:199-202), 0xFFFFFFFF: never.  The
   // reference hands one UGenFlags to every task of a block in node order (graph_gen.rs:196-200), so the mark a voice
@@ -1644,6 +1696,23 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   template <int T> __device__ __forceinline__ void tick_tile(F (&x)[T], const Ctx& c, u32 frame0) {
     S0::template tick_tile<F, FMA, T>(r, x, c, frame0, mark);
     rest.template tick_tile<T>(x, c, frame0);
+  }
+  // A tile in which voices change parameters at frames of their own: `cn` holds each voice's registers with its changes
+  // applied, `sw` the tile-relative frame at which the voice takes them over (T: never), `touched` the slots its changes
+  // address.  A stage none of whose slots is touched in the whole wave runs its ordinary tile code.
+  template <int T> __device__ __forceinline__ void tick_tile_sw(const Chain& cn, u32 sw, u64 touched, F (&x)[T], const Ctx& c, u32 frame0) {
+    bool hit = false;
+    if constexpr (S0::kParamMask != 0u) hit = __builtin_amdgcn_ballot_w64((touched & kStageBits) != 0ull) != 0;
+    if (hit) {
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        S0::take_params(r, cn.r, (u32)j == sw);
+        x[j] = S0::template tick<F, FMA>(r, x[j], c, frame0 + j, mark);
+      }
+    } else {
+      S0::template tick_tile<F, FMA, T>(r, x, c, frame0, mark);
+    }
+    rest.template tick_tile_sw<T>(cn.rest, sw, touched, x, c, frame0);
   }
   __device__ __forceinline__ u32 collect_done(u32 acc) const {
     if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
@@ -1749,22 +1818,24 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ChainT chain;
   chain.load(a.state + voice, a.stride);
 
+  // the voice's next event waits in registers, whole: one 16-byte read per event (voice_pipe.hpp)
   u32 ev_i = 0, ev_end = 0;
   if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
-  u32 next_frame = 0xFFFFFFFFu;
-  if (ev_i < ev_end) next_frame = a.events[ev_i].frame;
+  Event nxt;
+  nxt.frame = 0xFFFFFFFFu; nxt.slot_op = 0u; nxt.bits = 0ull;
+  if (ev_i < ev_end) nxt = a.events[ev_i];
   u32 base = 0;  // absolute frame of the current block's frame 0
 
   auto apply_events_upto = [&](u32 n_abs) {
-    while (next_frame <= n_abs) {
-      Event e = a.events[ev_i];
-      const u32 op = e.slot_op >> 24, slot = e.slot_op & 0xFFFFFFu;
-      chain.on_event(op, slot, e.bits, e.frame - base);
+    while (nxt.frame <= n_abs) {
+      const u32 op = nxt.slot_op >> 24, slot = nxt.slot_op & 0xFFFFFFu;
+      chain.on_event(op, slot, nxt.bits, nxt.frame - base);
       // a patched coefficient slot is not part of the end-of-launch write-back: persist it now
       // (mutable slots are overwritten by their evolved value at the end)
-      if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)e.bits;
+      if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)nxt.bits;
       ++ev_i;
-      next_frame = ev_i < ev_end ? a.events[ev_i].frame : 0xFFFFFFFFu;
+      if (ev_i < ev_end) nxt = a.events[ev_i];
+      else nxt.frame = 0xFFFFFFFFu;
     }
   };
 
@@ -1779,7 +1850,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
         const u32 n = n0 + j0;
         apply_events_upto(base + n);
         const bool full = j0 + kTile <= len;
-        const bool ev_inside = next_frame < base + n + kTile;
+        const bool ev_inside = nxt.frame < base + n + kTile;
         if (full && !__builtin_amdgcn_ballot_w64(ev_inside)) {
           // fast path: kTile samples, stage by stage, fully unrolled
           F x[kTile];

@@ -50,6 +50,11 @@ template <typename F, int TILE> struct EdgeLayout {
 template <typename F> struct PipeShared {
   float* sine;
   F* edge;  // [NG][2][64][stride]; edge i carries group i's output, the last one to the mixer (FOLD: one private buffer)
+  // The workgroup's piece of the launch's event list (contiguous: the list is sorted by voice), copied into spare LDS at
+  // kernel start when it fits: applying an event is then an LDS read, not a round trip to pinned host memory (~1 us,
+  // during which the wave -- and at the next barrier its whole pipeline -- stands still).  ev_lds_n == 0: read in place.
+  const Event* ev_lds;
+  u32 ev_lds_first, ev_lds_n;
 };
 
 template <typename F, bool FMA, int T, bool PAN>
@@ -81,21 +86,35 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   ChainT chain;
   chain.load(a.state + voice, a.stride);
 
+  // The voice's next event waits in registers, whole: one 16-byte read per event (the list may sit in pinned host
+  // memory, a PCIe round trip away), issued as soon as the event before it has been applied.
   u32 ev_i = 0, ev_end = 0;
   if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
-  u32 next_frame = 0xFFFFFFFFu;
-  if (ev_i < ev_end) next_frame = a.events[ev_i].frame;
+  Event nxt;
+  nxt.frame = 0xFFFFFFFFu; nxt.slot_op = 0u; nxt.bits = 0ull;
+  const bool ev_staged = sh.ev_lds_n != 0u;  // uniform: two plain loads (LDS / global, spelled with their address spaces), never a flat one
+  typedef __attribute__((address_space(3))) const Event* lds_ev_t;
+  typedef __attribute__((address_space(1))) const Event* glb_ev_t;
+  const lds_ev_t ev_l = (lds_ev_t)sh.ev_lds;
+  const glb_ev_t ev_g = (glb_ev_t)a.events;
+  auto fetch = [&](u32 i) -> Event {
+    Event e;
+    if (ev_staged) { e.frame = ev_l[i - sh.ev_lds_first].frame; e.slot_op = ev_l[i - sh.ev_lds_first].slot_op; e.bits = ev_l[i - sh.ev_lds_first].bits; }
+    else { e.frame = ev_g[i].frame; e.slot_op = ev_g[i].slot_op; e.bits = ev_g[i].bits; }
+    return e;
+  };
+  if (ev_i < ev_end) nxt = fetch(ev_i);
   u32 base = 0;  // absolute frame of the current block's frame 0
   auto apply_events_upto = [&](u32 n_abs) {
-    while (next_frame <= n_abs) {
-      Event e = a.events[ev_i];
-      const u32 op = e.slot_op >> 24, slot = e.slot_op & 0xFFFFFFu;
+    while (nxt.frame <= n_abs) {
+      const u32 op = nxt.slot_op >> 24, slot = nxt.slot_op & 0xFFFFFFu;
       if (slot >= SLOT_LO && slot < SLOT_HI) {  // every group scans the list, the owner applies
-        chain.on_event(op, slot, e.bits, e.frame - base);
-        if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)e.bits;
+        chain.on_event(op, slot, nxt.bits, nxt.frame - base);
+        if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)nxt.bits;
       }
       ++ev_i;
-      next_frame = ev_i < ev_end ? a.events[ev_i].frame : 0xFFFFFFFFu;
+      if (ev_i < ev_end) nxt = fetch(ev_i);
+      else nxt.frame = 0xFFFFFFFFu;
     }
   };
 
@@ -136,7 +155,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       const u32 n = a.frame_begin + (u32)ti * T;
       const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
       apply_events_upto(base + n);
-      const bool ev_inside = next_frame < base + n + T;
+      const bool ev_inside = nxt.frame < base + n + T;
 #if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -163,14 +182,109 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
             for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
             out[j] = v;
           }
-        } else {
-          // sample by sample, each sample straight from the input row to the output row in LDS: the register tile is
-          // never indexed by a run-time value (that would put all of it, the fast path's too, in scratch memory)
+        } else if (m == (u32)T && [&]() -> bool {
+          // Voices of the wave change PARAMETERS inside this tile (sample-accurate changes out of a WrPreciseTiming queue:
+          // a new frequency, gain, filter coefficient set ..), each at one frame of its own.  The changes are applied to a
+          // copy of the voice's registers in one pass, and the tile then runs stage by stage as usual, every sample taking
+          // over its voice's new parameter values at that voice's frame (Chain::tick_tile_sw).  Anything else inside the tile
+          // -- a trigger, a phase reset, two changes of one voice at different frames -- leaves everything as it was and
+          // takes the general path below.
+          ChainT cn = chain;
+          const u32 sv_i = ev_i;
+          const Event sv_nxt = nxt;
+          const u32 tile_end = base + n + (u32)T;
+          u32 sw = (u32)T;
+          u64 touched = 0ull;
+          bool bad = false;
+          while (nxt.frame < tile_end) {
+            const u32 op = nxt.slot_op >> 24, slot = nxt.slot_op & 0xFFFFFFu, code = op & 0x7Fu;
+            if (slot >= SLOT_LO && slot < SLOT_HI) {
+              const u32 rel = nxt.frame - (base + n);
+              if (sw == (u32)T) sw = rel;
+              bad = bad || sw != rel || slot >= 64u ||
+                    !((code == EV_SET && ((ChainT::kParamBits >> (slot & 63u)) & 1ull)) || (code == EV_NOP && ((ChainT::kNopOkBits >> (slot & 63u)) & 1ull)));
+              if (!bad) {
+                cn.on_event(op, slot, nxt.bits, nxt.frame - base);
+                touched |= 1ull << (slot & 63u);
+                if (live && code == EV_SET) a.state[(long)slot * a.stride + voice] = (W)nxt.bits;
+              }
+            }
+            ++ev_i;
+            if (ev_i < ev_end) nxt = fetch(ev_i);
+            else nxt.frame = 0xFFFFFFFFu;
+          }
+          if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+            ev_i = sv_i;
+            nxt = sv_nxt;
+            return false;
+          }
+          // eight samples at a time, row to row in LDS (a run-time loop, like the general path: keeps this rare path small
+          // and the register tile of the fast path out of it)
           const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride;
-          for (u32 j = 0; j < m; ++j) {
-            apply_events_upto(base + n + j);
-            const F v = I > 0 ? in_row[j] : (F)0;
-            out_row[j] = chain.tick(v, ctx, n + j);
+          for (u32 j0 = 0; j0 < (u32)T; j0 += 8u) {
+            F sub[8];
+            if (I > 0) {
+#pragma unroll
+              for (int q = 0; q < 8 / VW; ++q) {
+                const Vec v = reinterpret_cast<const Vec*>(in_row + j0)[q];
+#pragma unroll
+                for (int k = 0; k < VW; ++k) sub[q * VW + k] = v[k];
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) sub[k] = (F)0;
+            }
+            chain.template tick_tile_sw<8>(cn, sw - j0, touched, sub, ctx, n + j0);  // sw - j0 outside 0..7: no switch in this run
+#pragma unroll
+            for (int q = 0; q < 8 / VW; ++q) {
+              Vec v;
+#pragma unroll
+              for (int k = 0; k < VW; ++k) v[k] = sub[q * VW + k];
+              reinterpret_cast<Vec*>(out_row + j0)[q] = v;
+            }
+          }
+          return true;
+        }()) {
+        } else {
+          // Some voice of the wave has a change inside this tile (sample-accurate parameter changes, WrPreciseTiming), or
+          // the tile is a partial one at the end of a block: it is walked eight samples at a time, row to row in LDS (a
+          // run-time loop: the register tile above is never indexed by a run-time value, which would put all of it, the
+          // fast path's too, in scratch memory).  Eight samples in which no voice has a change run as a small tile, any
+          // others sample by sample with the changes applied in front of their frame.
+          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride;
+          for (u32 j0 = 0; j0 < m; j0 += 8u) {
+            const u32 cnt = m - j0 < 8u ? m - j0 : 8u;
+            F sub[8];
+            if (I > 0) {
+#pragma unroll
+              for (int q = 0; q < 8 / VW; ++q) {
+                const Vec v = reinterpret_cast<const Vec*>(in_row + j0)[q];
+#pragma unroll
+                for (int k = 0; k < VW; ++k) sub[q * VW + k] = v[k];
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) sub[k] = (F)0;
+            }
+            const bool ev_sub = nxt.frame < base + n + j0 + 8u;
+            if (cnt == 8u && !__builtin_amdgcn_ballot_w64(ev_sub)) {
+              chain.template tick_tile<8>(sub, ctx, n + j0);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                if ((u32)k < cnt) {
+                  apply_events_upto(base + n + j0 + (u32)k);
+                  sub[k] = chain.tick(sub[k], ctx, n + j0 + (u32)k);
+                }
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8 / VW; ++q) {
+              Vec v;
+#pragma unroll
+              for (int k = 0; k < VW; ++k) v[k] = sub[q * VW + k];
+              reinterpret_cast<Vec*>(out_row + j0)[q] = v;  // a partial run stores its unused tail too: the row is T (+ padding) long
+            }
           }
         }
         if constexpr (GroupInfo<G>::pan) {
@@ -359,9 +473,22 @@ __global__ void __launch_bounds__((sizeof...(Gs) + (FOLD ? 0 : 1)) * 64) voice_p
   __shared__ float sine[kSine ? 16384 : 1];
   // the last edge feeds the mixer; with FOLD it is one buffer private to the last group
   __shared__ __attribute__((aligned(16))) F edge[(NG * 2 - (FOLD ? 1 : 0)) * EdgeLayout<F, T>::tile];
+  // what is left of the CU's 160 KiB holds the workgroup's events (16 bytes each), up to 2 048 of them
+  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 1) - (long)sizeof(F) * (NG * 2 - (FOLD ? 1 : 0)) * EdgeLayout<F, T>::tile;
+  constexpr int kEvCap = kLdsFree < 16 ? 0 : (kLdsFree / 16 > 2048 ? 2048 : (int)(kLdsFree / 16));
+  __shared__ __attribute__((aligned(16))) Event ev_stage[kEvCap > 0 ? kEvCap : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  u32 ev_first = 0, ev_count = 0;
+  if (kEvCap > 0 && a.ev_start) {
+    const u32 gv0 = blockIdx.x * 64u;
+    const u32 gnv = a.n_voices - gv0 < 64u ? a.n_voices - gv0 : 64u;
+    ev_first = a.ev_start[gv0];
+    ev_count = a.ev_start[gv0 + gnv] - ev_first;
+    if (ev_count > (u32)kEvCap) ev_count = 0u;  // does not fit: the groups read the list where it is
+    for (u32 i = threadIdx.x; i < ev_count; i += WAVES * 64) ev_stage[i] = a.events[ev_first + i];
+  }
   if (kSine) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -376,6 +503,9 @@ __global__ void __launch_bounds__((sizeof...(Gs) + (FOLD ? 0 : 1)) * 64) voice_p
   PipeShared<F> sh;
   sh.sine = sine;
   sh.edge = edge;
+  sh.ev_lds = ev_stage;
+  sh.ev_lds_first = ev_first;
+  sh.ev_lds_n = ev_count;
   const u32 wave_global = blockIdx.x;  // one 64-voice wavefront-group per workgroup
   const u32 v0 = wave_global * 64u;
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;

@@ -76,6 +76,11 @@ if __name__ == "__main__":
         run("D3")
         run("D3", n_voices=65536)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "only":  # tools/bench_configs.py only C5 C3 C2:1024 ...
+        for spec in sys.argv[2:]:
+            name, _, nv = spec.partition(":")
+            run(name, n_voices=int(nv) if nv else None)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c5":  # the host-bound config against the number of host threads
         for k in (0, 2, 4, 8, 12):
             run("C5", host_threads=k, launches=16)
