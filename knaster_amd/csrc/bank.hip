@@ -347,6 +347,27 @@ struct Bank final : knh_bank {
   // param_apply / set_delay calls addressed to later blocks of the next multi-block launch
   struct Call { uint8_t is_delay; uint16_t delay; uint32_t voice, stage, param, kind; double f; int64_t i; };
   std::vector<std::vector<Call>> future;  // [block_offset]
+  // Calls to a node wrapped in WrPreciseTiming (and in nothing that keeps host state of its own): one compact record per
+  // call, per block in arrival order.  When the block is assembled a single pass replays them against the armed delays
+  // and each node's queue state (precise_timing.rs:65-135) and writes the device events; no queue is ever materialised.
+  struct QRec {
+    uint32_t voice;
+    uint16_t delay;     // set_delay_within_block_for_param value, when `arm` is set
+    uint8_t stage, param, kind;
+    uint8_t arm : 1, has_value : 1;
+    union { double f; int64_t i; } v;
+  };
+  static_assert(sizeof(QRec) == 24, "QRec is 24 bytes");
+  std::vector<std::vector<QRec>> qfuture;  // [block_offset]
+  struct NodeQ { uint32_t epoch; uint16_t at; uint16_t taken : 15, blocked : 1; };  // a node's queue during the block `epoch`
+  std::vector<NodeQ> node_q;               // [voice * n_wrapped + wrapped index of the stage]
+  std::vector<int> wrapped_index;          // [stage] -> index among the stages of this kind, or -1
+  uint32_t n_wrapped = 0, q_epoch = 0;
+  bool fastq(const StageInfo& S) const { return S.dcpb > 0 && !(S.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS); }
+  std::vector<QRec>& qblock(uint32_t block_offset) {
+    if (qfuture.size() <= block_offset) qfuture.resize(block_offset + 1);
+    return qfuture[block_offset];
+  }
 
   // device
   hipStream_t own_stream = nullptr;
@@ -747,6 +768,11 @@ struct Bank final : knh_bank {
     bool any_wrapped = false;
     for (auto& S : stages) any_wrapped = any_wrapped || S.dcpb > 0;
     if (any_wrapped) next_delay.assign(static_cast<size_t>(n_params_total) * nv, 0);
+    wrapped_index.assign(stages.size(), -1);
+    n_wrapped = 0;
+    for (size_t si = 0; si < stages.size(); ++si)
+      if (fastq(stages[si])) wrapped_index[si] = static_cast<int>(n_wrapped++);
+    node_q.assign(static_cast<size_t>(nv) * n_wrapped, NodeQ{0u, 0, 0, 0});
     smooth.assign(stages.size(), {});
     smooth_mark.assign(stages.size(), {});
     for (size_t si = 0; si < stages.size(); ++si)
@@ -780,6 +806,12 @@ struct Bank final : knh_bank {
       warn("Parameter delay set, but the stage is not wrapped in WrPreciseTiming; no effect");
       return KNH_OK;
     }
+    if (fastq(S)) {
+      QRec r{};
+      r.voice = voice; r.delay = delay; r.stage = static_cast<uint8_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
+      qblock(0).push_back(r);
+      return KNH_OK;
+    }
     next_delay[static_cast<size_t>(S.param_base + param) * nv + voice] = delay;  // precise_timing.rs:146-148
     return KNH_OK;
   }
@@ -788,6 +820,10 @@ struct Bank final : knh_bank {
     if (rc != KNH_OK) return rc;
     const StageInfo& S = stages[stage];
     if (!kind_ok(S, param, kind)) return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
+    if (fastq(S) && frame_base == 0) {  // (frame_base != 0: a replay inside process, which has its own order)
+      qblock(0).push_back(make_qrec(voice, stage, param, kind, f, i, 0, false));
+      return KNH_OK;
+    }
     if (S.dcpb > 0) {  // WrPreciseTiming::param_apply, precise_timing.rs:126-135
       uint16_t d = next_delay[static_cast<size_t>(S.param_base + param) * nv + voice];
       if (d != 0) {  // capacity (DELAYED_CHANGES_PER_BLOCK) is enforced per node when the block is assembled
@@ -797,6 +833,13 @@ struct Bank final : knh_bank {
     }
     deliver(voice, stage, param, kind, f, i, frame_base);
     return KNH_OK;
+  }
+  static QRec make_qrec(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i, uint16_t delay, bool arm) {
+    QRec r{};
+    r.voice = voice; r.delay = delay; r.stage = static_cast<uint8_t>(stage); r.param = static_cast<uint8_t>(param);
+    r.kind = static_cast<uint8_t>(kind); r.arm = arm ? 1 : 0; r.has_value = 1;
+    if (kind == KNH_VALUE_FLOAT) r.v.f = f; else r.v.i = i;
+    return r;
   }
   static bool kind_ok(const StageInfo& S, uint32_t param, uint32_t kind) {
     const int want = expected_value_kind(S.kind, param);
@@ -879,6 +922,16 @@ struct Bank final : knh_bank {
     if (block_offset >= 65536) return fail(KNH_ERR_OUT_OF_RANGE, "block_offset too large");
     if (!is_delay && !kind_ok(stages[stage], param, kind))
       return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
+    if (fastq(stages[stage])) {
+      if (is_delay) {
+        QRec r{};
+        r.voice = voice; r.delay = delay; r.stage = static_cast<uint8_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
+        qblock(block_offset).push_back(r);
+      } else {
+        qblock(block_offset).push_back(make_qrec(voice, stage, param, kind, f, i, 0, false));
+      }
+      return KNH_OK;
+    }
     if (future.size() <= block_offset) future.resize(block_offset + 1);
     future[block_offset].push_back(Call{static_cast<uint8_t>(is_delay), delay, voice, stage, param, kind, f, i});
     return KNH_OK;
@@ -911,7 +964,20 @@ struct Bank final : knh_bank {
                     kind_ok(stages[stgs[k]], params[k], kinds[k]) && direct_ok(stages[stgs[k]], params[k]);
       if (direct && delays)
         for (size_t q = k; q < e && direct; ++q) direct = delays[q] == 0;  // an armed delay on an unwrapped stage: the warning path
-      if (direct) {
+      // (runs of any length: a host that addresses two parameters of alternate voices sends runs of one)
+      const bool queued_run = !direct && stgs[k] < stages.size() && stages.size() <= 255 && params[k] < static_cast<uint32_t>(stages[stgs[k]].n_params) &&
+                              fastq(stages[stgs[k]]) && kind_ok(stages[stgs[k]], params[k], kinds[k]) && kinds[k] != KNH_VALUE_SMOOTHING;
+      if (queued_run) {  // calls to a WrPreciseTiming-wrapped node: one record each (arm the delay, then the value)
+        std::vector<QRec>& q = qblock(block_offset);
+        if (q.capacity() < q.size() + (e - k)) q.reserve(std::max(q.size() + (count - k), q.capacity() * 2));
+        const uint32_t stage = stgs[k], param = params[k], kind = kinds[k];
+        for (size_t p = k; p < e; ++p) {
+          const uint32_t v = voices[p];
+          if (v >= nv) { rc = fail(KNH_ERR_OUT_OF_RANGE, "voice out of range"); continue; }
+          const uint16_t d = delays ? delays[p] : 0;
+          q.push_back(make_qrec(v, stage, param, kind, fvalues ? fvalues[p] : 0.0, ivalues ? ivalues[p] : 0, d, d > 0));
+        }
+      } else if (direct) {
         const uint32_t stage = stgs[k], param = params[k];
         const uint32_t frame = block_offset * static_cast<uint32_t>(block_size);
         pending.reserve(pending.size() + (e - k) * 2);
@@ -1104,6 +1170,54 @@ struct Bank final : knh_bank {
     }
   }
 
+  // The records of one block, in arrival order: set_delay_within_block_for_param arms (precise_timing.rs:146-148),
+  // param_apply queues when a delay is armed (:126-135, capacity DELAYED_CHANGES_PER_BLOCK) and applies at once otherwise,
+  // and process_block's change loop (:65-114) applies a node's queued changes first in, first out, each at
+  // max(its delay, where the node's block has got to) -- a change behind one that is not due inside the processed range
+  // is never reached.  A node's events come out in frame order by construction.
+  void resolve_qrecs(std::vector<QRec>& recs, uint32_t frame_begin, uint32_t frame_end) {
+    if (recs.empty()) return;
+    q_epoch += 1;
+    if (q_epoch == 0) {  // wrapped around: no stale state may look current
+      std::fill(node_q.begin(), node_q.end(), NodeQ{0u, 0, 0, 0});
+      q_epoch = 1;
+    }
+    pending.reserve(pending.size() + recs.size());
+    for (const QRec& r : recs) {
+      const StageInfo& S = stages[r.stage];
+      uint16_t& armed = next_delay[static_cast<size_t>(S.param_base + r.param) * nv + r.voice];
+      if (r.arm) armed = r.delay;
+      if (!r.has_value) continue;
+      const double f = r.kind == KNH_VALUE_FLOAT ? r.v.f : 0.0;
+      const int64_t iv = r.kind == KNH_VALUE_FLOAT ? 0 : r.v.i;
+      if (armed == 0) {  // no delay armed: straight through, before the block
+        apply_now(r.voice, r.stage, r.param, f, iv, frame_base, pending);
+        continue;
+      }
+      NodeQ& q = node_q[static_cast<size_t>(r.voice) * n_wrapped + static_cast<uint32_t>(wrapped_index[r.stage])];
+      if (q.epoch != q_epoch) q = NodeQ{q_epoch, static_cast<uint16_t>(frame_begin), 0, 0};
+      if (q.taken >= S.dcpb) {  // precise_timing.rs:129-134: the queue was full when this change arrived
+        if (q.taken == S.dcpb) { warn("Not enough space for scheduled changes in WrPreciseTiming, change ignored"); q.taken = static_cast<uint16_t>(std::min<uint32_t>(S.dcpb + 1u, 32767u)); }
+        continue;
+      }
+      q.taken = static_cast<uint16_t>(q.taken + 1);
+      if (q.blocked) continue;  // behind a change that is not due in this block: never reached
+      const uint32_t due = std::max<uint32_t>(armed, q.at);
+      if (due > frame_end) { q.blocked = 1; continue; }
+      q.at = static_cast<uint16_t>(due);
+      const size_t first_ev = pending.size();
+      apply_now(r.voice, r.stage, r.param, f, iv, frame_base + due, pending);
+      if (due > frame_begin) {  // a split point: the node's block restarts here (precise_timing.rs:104-110)
+        if (pending.size() == first_ev) {
+          note_frame(frame_base + due);
+          pending.push_back(HostEvent{r.voice, frame_base + due, knh_dev::EV_NOP, static_cast<uint32_t>(S.slot_base), 0});
+        }
+        for (size_t e = first_ev; e < pending.size(); ++e) pending[e].op |= knh_dev::EV_SPLIT;
+      }
+    }
+    recs.clear();
+  }
+
   // WrPreciseTiming::process_block's change loop (precise_timing.rs:65-114) for every wrapped node
   // with queued changes: FIFO with head-of-line blocking, changes past the processed range are lost.
   void resolve_queues(uint32_t frame_begin, uint32_t frame_end) {  // block-relative range; events get frame_base added
@@ -1274,9 +1388,18 @@ struct Bank final : knh_bank {
           else param_apply(c.voice, c.stage, c.param, c.kind, c.f, c.i);
         }
       }
+      if (b < qfuture.size()) resolve_qrecs(qfuture[b], fb, fe);
       resolve_queues(fb, fe);
     }
     frame_base = 0;
+    if (!qfuture.empty()) {  // records addressed beyond this launch move up (their vectors keep their capacity)
+      if (qfuture.size() <= n_blocks) {
+        for (auto& q : qfuture) q.clear();
+      } else {
+        std::rotate(qfuture.begin(), qfuture.begin() + n_blocks, qfuture.end());
+        for (size_t k = qfuture.size() - n_blocks; k < qfuture.size(); ++k) qfuture[k].clear();
+      }
+    }
     bool have_events = false;
     int rc = upload_events(s, &have_events, n_blocks);
     if (rc != KNH_OK) return rc;
