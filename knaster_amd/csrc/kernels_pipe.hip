@@ -13,9 +13,21 @@ template <typename F, bool FMA, bool BIG, typename... Gs>
 static hipError_t launch_pipe(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
   if (n_wavefronts == 0) return hipSuccess;
   constexpr int T = BIG ? PipeTile<F>::big : PipeTile<F>::value;
-  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, BIG, Gs...>), dim3(n_wavefronts), dim3((sizeof...(Gs) + (BIG ? 0 : 1)) * 64), 0, stream, args);
+  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, BIG, Gs...>), dim3(n_wavefronts), dim3(PipeWaves<T, BIG, Gs...>::value * 64), 0, stream, args);
   return hipGetLastError();
 }
+// 64-sample tiles (32 for f64) WITH a mixer wavefront: for pipelines with a Fan group (the fold costs the same per
+// tile whatever the tile length, and a Fan group's windows are whole runs of eight samples)
+template <typename F, bool FMA, typename... Gs>
+static hipError_t launch_pipe_wide_tile(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
+  if (n_wavefronts == 0) return hipSuccess;
+  constexpr int T = PipeTile<F>::big;
+  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, false, Gs...>), dim3(n_wavefronts), dim3(PipeWaves<T, false, Gs...>::value * 64), 0, stream, args);
+  return hipGetLastError();
+}
+#define KNH_PIPE_FAN(sig, n, ...)                                                                                       \
+  {sig, n, false, {launch_pipe_wide_tile<float, false, __VA_ARGS__>, launch_pipe_wide_tile<float, true, __VA_ARGS__>}, \
+   {launch_pipe_wide_tile<double, false, __VA_ARGS__>, launch_pipe_wide_tile<double, true, __VA_ARGS__>}}
 #define KNH_PIPE_AS(sig, n, big, ...)                                                               \
   {sig, n, big, {launch_pipe<float, false, big, __VA_ARGS__>, launch_pipe<float, true, big, __VA_ARGS__>}, \
    {launch_pipe<double, false, big, __VA_ARGS__>, launch_pipe<double, true, big, __VA_ARGS__>}}
@@ -25,6 +37,9 @@ static hipError_t launch_pipe(const VoiceKernelArgs<F>& args, unsigned n_wavefro
 typedef Group<SinWt, MulVal> G_Wm;
 typedef Group<SinWt> G_W;
 typedef Group<SinNum> G_N;
+typedef Group<SinPhase> G_Np;                 // SinNumeric's phase accumulator ...
+typedef Fan<8, SinMap, MulVal> F_Nm;          // ... and its sin (with the gain), over eight wavefronts: C2
+typedef Fan<8, SinMap> F_N;
 typedef Group<Svf> G_S;
 typedef Group<MulAsr> G_A;
 typedef Group<MulAr> G_E;
@@ -46,7 +61,8 @@ static const PipeEntry kPipes[] = {
     KNH_PIPE("WSA", 3, G_W, G_S, G_A),
     KNH_PIPE("WS", 2, G_W, G_S),
     KNH_PIPE("WmaRm", 2, G_Wma, G_Rm),     // C5: modulator | carrier
-    KNH_PIPE("Nm", 2, G_N, G_m),           // C2
+    KNH_PIPE_FAN("Nm", 2, G_Np, F_Nm),     // C2: phase | sin * gain on eight wavefronts | mixer
+    KNH_PIPE_FAN("N", 2, G_Np, F_N),
     KNH_PIPE("NSAm", 3, G_N, G_S, G_Am),
     KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA),  // the delay's HBM traffic rides in the envelope wave
     KNH_PIPE("BmSA", 3, G_Bm, G_S, G_A),

@@ -737,6 +737,75 @@ struct SinNum : StageDefaults {
   }
 };
 
+// SinNumeric cut in two for the pipeline kernels (voice_pipe.hpp): the SERIAL part -- the phase accumulator, three
+// instructions per sample -- and the part that is a pure function of one sample, sin(p * TAU), some forty instructions.
+// SinPhase hands on p = phase + phase_offset (the reference's first operation on it, osc.rs:264), SinMap finishes
+// ((p) * TAU).sin(): the same operations in the same order as SinNum::tick, so the same bits.  SinMap has no state and
+// can therefore be spread over several wavefronts, each taking a slice of every tile (Fan groups).
+// SinPhase slots: 0 phase, 1 phase_offset, 2 phase_increment (= SinNum's); SinMap: none
+struct SinPhase : StageDefaults {
+  static constexpr int kSlots = 3;
+  static constexpr u32 kMutableMask = 0b001u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs { F phase, off, inc; };
+  static constexpr u32 kParamMask = 0b110u;
+  template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) {
+    r.off = c ? n.off : r.off;
+    r.inc = c ? n.inc : r.inc;
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long stride) {
+    r.phase = word_to_f<F>(s[0]); r.off = word_to_f<F>(s[stride]); r.inc = word_to_f<F>(s[2 * stride]);
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = f_to_word(r.phase); }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
+    const F p = r.phase + r.off;
+    r.phase += r.inc;
+    if (r.phase > (F)1) r.phase -= (F)1;
+    return p;
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel == 0) r.phase = v;
+    else if (rel == 1) r.off = v;
+    else r.inc = v;
+  }
+};
+struct SinMap : StageDefaults {
+  static constexpr int kSlots = 0;
+  static constexpr u32 kMutableMask = 0u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs {};
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>&, const W*, long) {}
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>&, F p, const Ctx&, u32, u32&) {
+    const F TAU = (F)6.28318530717958647692;
+    return SinNum::sin_f(p * TAU);
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F> static __device__ __forceinline__ void on_event(Regs<F>&, u32, u32, u64, u32) {}
+};
+
 // SvfFilter tick -- svf.rs:272-278.  slots: 0 ic1eq, 1 ic2eq, 2 a1, 3 a2, 4 a3, 5 m0, 6 m1, 7 m2
 // All nine filter types share this tick; the type only changes the coefficients (host side).
 struct Svf : StageDefaults {

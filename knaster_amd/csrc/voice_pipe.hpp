@@ -15,6 +15,12 @@
 namespace knh_dev {
 
 template <typename... S> struct Group {};
+// A stage group whose stages keep no state from one sample to the next (nothing but parameters: sin(p * TAU), x * c,
+// x.powi(n) ..): K wavefronts run it side by side, wavefront k taking samples [k * T / K, (k + 1) * T / K) of every tile.
+// That is how the expensive, per-sample-independent part of a chain (SinNumeric's sin) is spread over the SIMDs of the
+// CU while the serial part (its phase accumulator) stays in one wavefront.  Every wavefront of the group holds the
+// group's parameters and applies the parameter changes addressed to them.
+template <int K, typename... S> struct Fan {};
 
 template <typename G> struct GroupInfo;
 template <typename... S> struct GroupInfo<Group<S...>> {
@@ -22,9 +28,23 @@ template <typename... S> struct GroupInfo<Group<S...>> {
   static constexpr bool uses_sine = (false || ... || S::kUsesSine);
   static constexpr bool has_env = (false || ... || S::kIsEnv);
   static constexpr bool pan = (false || ... || IsPan<S>::value);  // the group ends the chain with a Pan2
+  static constexpr int fan_for(int) { return 1; }
+};
+template <int K, typename... S> struct GroupInfo<Fan<K, S...>> {
+  static constexpr int slots = (0 + ... + S::kSlots);
+  static constexpr bool uses_sine = (false || ... || S::kUsesSine);
+  static constexpr bool has_env = false;
+  static constexpr bool pan = false;
+  // wavefronts for tiles of T samples: K, or as many as leave every one a window of eight samples (f64 tiles are shorter)
+  static constexpr int fan_for(int T) { return K * 8 <= T ? K : (T >= 8 ? T / 8 : 1); }
+  static_assert(((S::kMutableMask == 0u) && ...), "a Fan group's stages keep no state");
+  static_assert((!S::kIsEnv && ...) && (!S::kNeedsBind && ...), "a Fan group's stages keep no state");
 };
 template <typename F, bool FMA, int BASE, typename G> struct GroupChain;
 template <typename F, bool FMA, int BASE, typename... S> struct GroupChain<F, FMA, BASE, Group<S...>> {
+  typedef Chain<F, FMA, BASE, S...> type;
+};
+template <typename F, bool FMA, int BASE, int K, typename... S> struct GroupChain<F, FMA, BASE, Fan<K, S...>> {
   typedef Chain<F, FMA, BASE, S...> type;
 };
 
@@ -66,10 +86,17 @@ __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelA
 // FOLD: the last group also folds its tile over the voices (what pipe_run_mixer does in a wavefront of its own
 // otherwise): it stores the tile in a buffer no other wavefront touches and reads it back column-wise.
 template <typename F, bool FMA, int T, bool FOLD, int NG, int I, int BASE, int LAST_ENV, typename G>
-__device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv) {
+__device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv, int fan_i) {
   typedef typename GroupChain<F, FMA, BASE, G>::type ChainT;
   typedef typename WordOf<F>::type W;
   constexpr bool FOLDS = FOLD && I == NG - 1;
+  // A Fan group's wavefront works on a WINDOW of every tile: TW samples starting fo samples into it (an ordinary group's
+  // window is the tile).  Everything below -- the register tile, the event paths, the LDS rows -- is per window.
+  constexpr int KF = GroupInfo<G>::fan_for(T);
+  constexpr int TW = T / KF;
+  static_assert(T % KF == 0 && TW % 8 == 0, "a window is whole runs of eight samples");
+  static_assert(!(FOLDS && KF > 1), "the folding group is not a Fan group");
+  const u32 fo = KF > 1 ? (u32)fan_i * (u32)TW : 0u;
   constexpr u32 SLOT_LO = (u32)BASE, SLOT_HI = (u32)(BASE + GroupInfo<G>::slots);
 
   Ctx ctx;
@@ -135,27 +162,29 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       const u64 t0 = __builtin_amdgcn_s_memtime();
 #endif
       // the tile's LDS reads go out first, so that their latency runs under the block/event bookkeeping below
-      F x[T];
+      F x[TW];
       if (I > 0) {
         typedef typename EdgeLayout<F, T>::Vec Vec;
         constexpr int VW = EdgeLayout<F, T>::VW;
         const Vec* in = reinterpret_cast<const Vec*>(sh.edge + (long)((I - 1) * 2 + (g & 1)) * EdgeLayout<F, T>::tile +
-                                                     (long)lane * EdgeLayout<F, T>::stride);
+                                                     (long)lane * EdgeLayout<F, T>::stride + fo);
 #pragma unroll
-        for (int j = 0; j < T / VW; ++j) {
+        for (int j = 0; j < TW / VW; ++j) {
           const Vec v = in[j];
 #pragma unroll
           for (int k = 0; k < VW; ++k) x[j * VW + k] = v[k];
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < T; ++j) x[j] = (F)0;
+        for (int j = 0; j < TW; ++j) x[j] = (F)0;
       }
       if (ti == 0) chain.begin_block(a.frame_begin, ctx);
-      const u32 n = a.frame_begin + (u32)ti * T;
-      const u32 m = a.frame_end - n < (u32)T ? a.frame_end - n : (u32)T;
-      apply_events_upto(base + n);
-      const bool ev_inside = nxt.frame < base + n + T;
+      const u32 n_tile = a.frame_begin + (u32)ti * T;
+      const u32 m_tile = a.frame_end - n_tile < (u32)T ? a.frame_end - n_tile : (u32)T;
+      const u32 n = n_tile + fo;                                                            // the window's first frame
+      const u32 m = m_tile > fo ? (m_tile - fo < (u32)TW ? m_tile - fo : (u32)TW) : 0u;     // frames of it inside the block
+      apply_events_upto(base + n);  // (a Fan wavefront: also the changes inside the part of the tile before its window)
+      const bool ev_inside = nxt.frame < base + n + TW;
 #if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -167,22 +196,22 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
         typedef typename EdgeLayout<F, T>::Vec Vec;
         constexpr int VW = EdgeLayout<F, T>::VW;
         F* out_tile = sh.edge + (long)(I * 2 + (FOLDS ? 0 : (g & 1))) * EdgeLayout<F, T>::tile;
-        F* out_row = out_tile + (long)lane * EdgeLayout<F, T>::stride;
-        if (m == (u32)T && !__builtin_amdgcn_ballot_w64(ev_inside)) {
-          chain.template tick_tile<T>(x, ctx, n);
+        F* out_row = out_tile + (long)lane * EdgeLayout<F, T>::stride + fo;
+        if (m == (u32)TW && !__builtin_amdgcn_ballot_w64(ev_inside)) {
+          chain.template tick_tile<TW>(x, ctx, n);
 #ifdef KNH_DAG_STAMPS
           asm volatile("" ::: "memory");
           busy_tick += __builtin_amdgcn_s_memtime() - t1;
 #endif
           Vec* out = reinterpret_cast<Vec*>(out_row);  // 16-byte LDS stores
 #pragma unroll
-          for (int j = 0; j < T / VW; ++j) {
+          for (int j = 0; j < TW / VW; ++j) {
             Vec v;
 #pragma unroll
             for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
             out[j] = v;
           }
-        } else if (m == (u32)T && [&]() -> bool {
+        } else if (m == (u32)TW && [&]() -> bool {
           // Voices of the wave change PARAMETERS inside this tile (sample-accurate changes out of a WrPreciseTiming queue:
           // a new frequency, gain, filter coefficient set ..), each at one frame of its own.  The changes are applied to a
           // copy of the voice's registers in one pass, and the tile then runs stage by stage as usual, every sample taking
@@ -192,15 +221,15 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
           ChainT cn = chain;
           const u32 sv_i = ev_i;
           const Event sv_nxt = nxt;
-          const u32 tile_end = base + n + (u32)T;
-          u32 sw = (u32)T;
+          const u32 tile_end = base + n + (u32)TW;
+          u32 sw = (u32)TW;
           u64 touched = 0ull;
           bool bad = false;
           while (nxt.frame < tile_end) {
             const u32 op = nxt.slot_op >> 24, slot = nxt.slot_op & 0xFFFFFFu, code = op & 0x7Fu;
             if (slot >= SLOT_LO && slot < SLOT_HI) {
               const u32 rel = nxt.frame - (base + n);
-              if (sw == (u32)T) sw = rel;
+              if (sw == (u32)TW) sw = rel;
               bad = bad || sw != rel || slot >= 64u ||
                     !((code == EV_SET && ((ChainT::kParamBits >> (slot & 63u)) & 1ull)) || (code == EV_NOP && ((ChainT::kNopOkBits >> (slot & 63u)) & 1ull)));
               if (!bad) {
@@ -220,8 +249,8 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
           }
           // eight samples at a time, row to row in LDS (a run-time loop, like the general path: keeps this rare path small
           // and the register tile of the fast path out of it)
-          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride;
-          for (u32 j0 = 0; j0 < (u32)T; j0 += 8u) {
+          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride + fo;
+          for (u32 j0 = 0; j0 < (u32)TW; j0 += 8u) {
             F sub[8];
             if (I > 0) {
 #pragma unroll
@@ -251,7 +280,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
           // run-time loop: the register tile above is never indexed by a run-time value, which would put all of it, the
           // fast path's too, in scratch memory).  Eight samples in which no voice has a change run as a small tile, any
           // others sample by sample with the changes applied in front of their frame.
-          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride;
+          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride + fo;
           for (u32 j0 = 0; j0 < m; j0 += 8u) {
             const u32 cnt = m - j0 < 8u ? m - j0 : 8u;
             F sub[8];
@@ -298,7 +327,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const u64 tf0 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (FOLDS) pipe_fold_tile<F, FMA, T, GroupInfo<G>::pan>(out_tile, a, lane, wave_global, n_waves_total, blk, n, m, v0, nv);
+        if constexpr (FOLDS) pipe_fold_tile<F, FMA, T, GroupInfo<G>::pan>(out_tile, a, lane, wave_global, n_waves_total, blk, n_tile, m_tile, v0, nv);
 #ifdef KNH_DAG_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         busy_fold += __builtin_amdgcn_s_memtime() - tf0;
@@ -448,13 +477,20 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
 #endif
 }
 
-template <typename F, bool FMA, int T, bool FOLD, int NG, int I, int BASE, int LAST_ENV, typename G, typename... Rest>
+// W0: the first wavefront of group I (a Fan group takes several)
+template <typename F, bool FMA, int T, bool FOLD, int NG, int I, int BASE, int W0, int LAST_ENV, typename G, typename... Rest>
 __device__ __forceinline__ u32 pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv) {
-  if (wave == I) return pipe_run_group<F, FMA, T, FOLD, NG, I, BASE, LAST_ENV, G>(sh, a, lane, wave_global, v0, nv);
+  constexpr int KF = GroupInfo<G>::fan_for(T);
+  if (wave >= W0 && wave < W0 + KF) return pipe_run_group<F, FMA, T, FOLD, NG, I, BASE, LAST_ENV, G>(sh, a, lane, wave_global, v0, nv, wave - W0);
   if constexpr (sizeof...(Rest) > 0)
-    return pipe_dispatch<F, FMA, T, FOLD, NG, I + 1, BASE + GroupInfo<G>::slots, LAST_ENV, Rest...>(wave, sh, a, lane, wave_global, v0, nv);
+    return pipe_dispatch<F, FMA, T, FOLD, NG, I + 1, BASE + GroupInfo<G>::slots, W0 + KF, LAST_ENV, Rest...>(wave, sh, a, lane, wave_global, v0, nv);
   return 0xFFFFFFFFu;
 }
+// wavefronts of a pipeline: one per group (K per Fan group), plus the mixer unless the last group folds
+template <int T, bool FOLD, typename... Gs> struct PipeWaves {
+  static constexpr int chain = (0 + ... + GroupInfo<Gs>::fan_for(T));
+  static constexpr int value = chain + (FOLD ? 0 : 1);
+};
 
 template <int I, typename... Gs> struct LastEnv;
 template <int I> struct LastEnv<I> { static constexpr int value = -1; };
@@ -463,11 +499,12 @@ template <int I, typename G, typename... Rest> struct LastEnv<I, G, Rest...> {
   static constexpr int value = later >= 0 ? later : (GroupInfo<G>::has_env ? I : -1);
 };
 
-// One workgroup = 64 voices = (number of groups + 1) wavefronts, or (number of groups) with FOLD.
+// One workgroup = 64 voices = one wavefront per stage group (K for a Fan group) + the mixer, or without it with FOLD.
 template <typename F, bool FMA, int T, bool FOLD, typename... Gs>
-__global__ void __launch_bounds__((sizeof...(Gs) + (FOLD ? 0 : 1)) * 64) voice_pipe_kernel(VoiceKernelArgs<F> a) {
+__global__ void __launch_bounds__((PipeWaves<T, FOLD, Gs...>::value * 64)) voice_pipe_kernel(VoiceKernelArgs<F> a) {
   constexpr int NG = (int)sizeof...(Gs);
-  constexpr int WAVES = NG + (FOLD ? 0 : 1);
+  constexpr int CHAINW = PipeWaves<T, FOLD, Gs...>::chain;  // wavefronts that run stage groups
+  constexpr int WAVES = PipeWaves<T, FOLD, Gs...>::value;
   static_assert(T <= 64 && T % 8 == 0, "a tile column per lane of the folding wavefront");
   constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
   __shared__ float sine[kSine ? 16384 : 1];
@@ -511,19 +548,19 @@ __global__ void __launch_bounds__((sizeof...(Gs) + (FOLD ? 0 : 1)) * 64) voice_p
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
   u32 done_frame = 0xFFFFFFFFu;
   constexpr bool kPan = (false || ... || GroupInfo<Gs>::pan);
-  if (wave == NG) pipe_run_mixer<F, FMA, T, NG, kPan>(sh, a, lane, wave_global, v0, nv);
-  else done_frame = pipe_dispatch<F, FMA, T, FOLD, NG, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
+  if (wave == CHAINW) pipe_run_mixer<F, FMA, T, NG, kPan>(sh, a, lane, wave_global, v0, nv);
+  else done_frame = pipe_dispatch<F, FMA, T, FOLD, NG, 0, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
   // mark_done of a voice = that of the last node in task order that set one: combine the groups in chain order
   constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);
   if constexpr (kAnyEnv) {
     u32* marks = reinterpret_cast<u32*>(edge);  // the tiles are dead: every wavefront is past its last barrier-separated read
     __syncthreads();
-    if (wave < NG) marks[wave * 64 + lane] = done_frame;
+    if (wave < CHAINW) marks[wave * 64 + lane] = done_frame;
     __syncthreads();
     if (wave == 0) {
       u32 d = 0xFFFFFFFFu;
 #pragma unroll
-      for (int g = 0; g < NG; ++g) d = marks[g * 64 + lane] != 0xFFFFFFFFu ? marks[g * 64 + lane] : d;
+      for (int g = 0; g < CHAINW; ++g) d = marks[g * 64 + lane] != 0xFFFFFFFFu ? marks[g * 64 + lane] : d;
       const bool live = (u32)lane < nv;
       if (live) a.done_frames[v0 + lane] = d;
       const u64 bd = __builtin_amdgcn_ballot_w64(live && d != 0xFFFFFFFFu);
