@@ -1721,6 +1721,7 @@ struct Chain<F, FMA, BASE> {
   static constexpr bool kUsesSine = false;
   static constexpr bool kPan = false;
   static constexpr u64 kParamBits = 0ull, kNopOkBits = 0ull;
+  static constexpr bool kBinds = false;
   template <int T> __device__ __forceinline__ void tick_tile_sw(const Chain&, u32, u64, F (&)[T], const Ctx&, u32) {}
   __device__ __forceinline__ void pan_gains(F&, F&) const {}
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
@@ -1744,6 +1745,7 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   static constexpr u64 kStageBits = BASE + S0::kSlots <= 64 ? (((u64)1 << S0::kSlots) - 1) << (BASE < 64 ? BASE : 0) : 0ull;
   static constexpr u64 kParamBits = (BASE + S0::kSlots <= 64 ? (u64)S0::kParamMask << (BASE < 64 ? BASE : 0) : 0ull) | RestT::kParamBits;
   static constexpr u64 kNopOkBits = ((S0::kParamMask != 0u || !S0::kHasSeg) && BASE < 64 ? (u64)1 << (BASE < 64 ? BASE : 0) : 0ull) | RestT::kNopOkBits;
+  static constexpr bool kBinds = S0::kNeedsBind || RestT::kBinds;  // a stage with memory behind it (delay ring, segment table, buffer)
   typename S0::template Regs<F> r;
   // The frame this stage last passed to mark_done (UGenFlags::mark_done, ugen.rs:199-202), 0xFFFFFFFF: never.  The
   // reference hands one UGenFlags to every task of a block in node order (graph_gen.rs:196-200), so the mark a voice

@@ -211,7 +211,9 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
             for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
             out[j] = v;
           }
-        } else if (m == (u32)TW && [&]() -> bool {
+        } else if (m == (u32)TW && ChainT::kParamBits != 0ull && !ChainT::kBinds && [&]() -> bool {
+          // (groups that hold a delay line, a segment table or a buffer reader keep to the general path: their registers --
+          // a prefetched tile of the ring among them -- are not worth copying for this)
           // Voices of the wave change PARAMETERS inside this tile (sample-accurate changes out of a WrPreciseTiming queue:
           // a new frequency, gain, filter coefficient set ..), each at one frame of its own.  The changes are applied to a
           // copy of the voice's registers in one pass, and the tile then runs stage by stage as usual, every sample taking
@@ -512,7 +514,10 @@ __global__ void __launch_bounds__((PipeWaves<T, FOLD, Gs...>::value * 64)) voice
   __shared__ __attribute__((aligned(16))) F edge[(NG * 2 - (FOLD ? 1 : 0)) * EdgeLayout<F, T>::tile];
   // what is left of the CU's 160 KiB holds the workgroup's events (16 bytes each), up to 2 048 of them
   constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 1) - (long)sizeof(F) * (NG * 2 - (FOLD ? 1 : 0)) * EdgeLayout<F, T>::tile;
-  constexpr int kEvCap = kLdsFree < 16 ? 0 : (kLdsFree / 16 > 2048 ? 2048 : (int)(kLdsFree / 16));
+#ifndef KNH_EVCAP_MAX
+#define KNH_EVCAP_MAX 2048
+#endif
+  constexpr int kEvCap = kLdsFree < 16 ? 0 : (kLdsFree / 16 > KNH_EVCAP_MAX ? KNH_EVCAP_MAX : (int)(kLdsFree / 16));
   __shared__ __attribute__((aligned(16))) Event ev_stage[kEvCap > 0 ? kEvCap : 1];
 
   const int lane = threadIdx.x & 63;

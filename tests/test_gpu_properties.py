@@ -454,3 +454,47 @@ def test_batched_calls_for_later_blocks_in_any_order(knh, host_threads):
                 assert_bit_equal(got[block], single[block], f"split {split} block {block}")
         b.close()
     a.close()
+
+
+def test_fan_pipeline_with_sample_accurate_changes_equals_single_wave_kernel(knh, monkeypatch):
+    """SinNumeric * gain as the Fan pipeline runs it (phase accumulator in one wavefront, sin * gain on eight, each taking a
+    window of every 64-sample tile) against the single-wave kernel, bit for bit, with sample-accurate changes landing in
+    every part of a tile: new frequencies and phase offsets (the serial wavefront's parameters), new gains (parameters every
+    one of the eight wavefronts holds), phase resets (state: the general path), on whole and ragged blocks."""
+    from knaster_amd.bank import Stage, TRIGGER
+    for block_size in (256, 200):
+        n = 300
+        w = configs.Workload("fan", [Stage(L.STAGE_SIN_NUMERIC, delayed_changes_per_block=4), Stage(L.STAGE_MUL_CONST, delayed_changes_per_block=4)],
+                             n, block_size, L.F32, 2)
+        p = configs.voice_parameters(n)
+        w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 1.0 / n)}
+        rng = np.random.default_rng(11)
+        script = []
+        for block in range(6):
+            ops = []
+            for _ in range(int(rng.integers(20, 200))):
+                voice = int(rng.integers(0, n))
+                stage = int(rng.integers(0, 2))
+                if stage == 0:
+                    param = int(rng.integers(0, 3))
+                    value = [float(rng.uniform(50, 5000)), float(rng.uniform(0, 1)), None][param]
+                else:
+                    param, value = 0, float(rng.uniform(0.0, 2.0 / n))
+                ops.append((voice, stage, param, value, int(rng.integers(0, block_size + 8))))
+            script.append(ops)
+        outs = {}
+        for pipeline in ("0", "1"):
+            monkeypatch.setenv("KNH_PIPELINE", pipeline)
+            g = make_gpu(knh, w)
+            res = []
+            for block in range(6):
+                for voice, stage, param, value, delay in script[block]:
+                    g.set_delay_within_block_for_param(voice, stage, param, delay)
+                    g.param_apply(voice, stage, param, TRIGGER if value is None else value)
+                res.append(g.process_block_voices()[:2])
+            outs[pipeline] = res
+            g.close()
+        for (o0, v0), (o1, v1) in zip(outs["0"], outs["1"]):
+            assert_bit_equal(v0, v1, f"block_size {block_size}: per-voice")
+            assert_bit_equal(o0, o1, f"block_size {block_size}: mix")
+        assert np.abs(outs["1"][-1][0]).max() > 0
