@@ -130,18 +130,23 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
     else { e.frame = ev_g[i].frame; e.slot_op = ev_g[i].slot_op; e.bits = ev_g[i].bits; }
     return e;
   };
-  if (ev_i < ev_end) nxt = fetch(ev_i);
+  // The frame of the next event in a register of its own, written by an instruction and not by a load: the per-tile
+  // checks below then never wait for memory (the event may have been read from LDS, whose counter also covers the
+  // tile reads that were just issued; the wait belongs where the event is fetched, not where its frame is looked at).
+  u32 next_frame = 0xFFFFFFFFu;
+  auto note_next = [&]() { asm volatile("v_mov_b32 %0, %1" : "=v"(next_frame) : "v"(nxt.frame)); };
+  if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
   u32 base = 0;  // absolute frame of the current block's frame 0
   auto apply_events_upto = [&](u32 n_abs) {
-    while (nxt.frame <= n_abs) {
+    while (next_frame <= n_abs) {
       const u32 op = nxt.slot_op >> 24, slot = nxt.slot_op & 0xFFFFFFu;
       if (slot >= SLOT_LO && slot < SLOT_HI) {  // every group scans the list, the owner applies
         chain.on_event(op, slot, nxt.bits, nxt.frame - base);
         if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)nxt.bits;
       }
       ++ev_i;
-      if (ev_i < ev_end) nxt = fetch(ev_i);
-      else nxt.frame = 0xFFFFFFFFu;
+      if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
+      else { nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu; }
     }
   };
 
@@ -184,7 +189,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       const u32 n = n_tile + fo;                                                            // the window's first frame
       const u32 m = m_tile > fo ? (m_tile - fo < (u32)TW ? m_tile - fo : (u32)TW) : 0u;     // frames of it inside the block
       apply_events_upto(base + n);  // (a Fan wavefront: also the changes inside the part of the tile before its window)
-      const bool ev_inside = nxt.frame < base + n + TW;
+      const bool ev_inside = next_frame < base + n + TW;
 #if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -223,11 +228,12 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
           ChainT cn = chain;
           const u32 sv_i = ev_i;
           const Event sv_nxt = nxt;
+          const u32 sv_next_frame = next_frame;
           const u32 tile_end = base + n + (u32)TW;
           u32 sw = (u32)TW;
           u64 touched = 0ull;
           bool bad = false;
-          while (nxt.frame < tile_end) {
+          while (next_frame < tile_end) {
             const u32 op = nxt.slot_op >> 24, slot = nxt.slot_op & 0xFFFFFFu, code = op & 0x7Fu;
             if (slot >= SLOT_LO && slot < SLOT_HI) {
               const u32 rel = nxt.frame - (base + n);
@@ -241,12 +247,13 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
               }
             }
             ++ev_i;
-            if (ev_i < ev_end) nxt = fetch(ev_i);
-            else nxt.frame = 0xFFFFFFFFu;
+            if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
+            else { nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu; }
           }
           if (__builtin_amdgcn_ballot_w64(bad) != 0) {
             ev_i = sv_i;
             nxt = sv_nxt;
+            next_frame = sv_next_frame;
             return false;
           }
           // eight samples at a time, row to row in LDS (a run-time loop, like the general path: keeps this rare path small
@@ -297,7 +304,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
 #pragma unroll
               for (int k = 0; k < 8; ++k) sub[k] = (F)0;
             }
-            const bool ev_sub = nxt.frame < base + n + j0 + 8u;
+            const bool ev_sub = next_frame < base + n + j0 + 8u;
             if (cnt == 8u && !__builtin_amdgcn_ballot_w64(ev_sub)) {
               chain.template tick_tile<8>(sub, ctx, n + j0);
             } else {
