@@ -142,6 +142,18 @@ class Env:
             return 0
         return fn
 
+    def torch_reduce_fn(self, rings):
+        """knh_reduce_fn fallback: the buffer the library hands over is one of the bench's own torch tensors."""
+        dist = self.dist
+
+        def fn(_user, buf, count, sample_type, root, stream):
+            for r in rings:
+                if r.data_ptr() == buf and r.numel() == count:
+                    dist.reduce(r, dst=root, op=dist.ReduceOp.SUM)  # enqueued on the current stream = the bank's stream
+                    return 0
+            return 1
+        return fn
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
@@ -164,24 +176,48 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     torch = env.torch
     w_all = configs.config(name, n_voices=total_voices, block_size=bs)
     lo, cnt = knaster_amd.shard_voice_range(total_voices, env.rank, env.world)
-    kwargs = dict(rank=env.rank, world=env.world)
-    if env.world > 1 and env.rehearse:
-        kwargs["reduce_fn"] = env.gloo_reduce_fn()
-    else:
-        kwargs["comm_id"] = env.comm_id()
-    bank = knaster_amd.VoiceBank(w_all.stages, total_voices, w_all.sample_type, w_all.out_channels, L.MIX_TREE, env.local_rank,
-                                 args.allow_fma, **kwargs)
-    for s, a in w_all.ctor.items():
-        bank.set_ctor_args(s, a)  # every rank hands over the whole list; the library keeps its range
-    bank.init(configs.SAMPLE_RATE, bs)
-    ugens = knaster_amd.chain_ugen_count(w_all.stages)
-    mine = np.arange(lo, lo + cnt, dtype=np.uint32)  # global indices of this rank's voices
-    restart = bank.prepare_many(mine, w_all.restart[0], w_all.restart[1], L.VALUE_TRIGGER)
-    release = bank.prepare_many(mine, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER)
     tdtype = torch.float64 if w_all.sample_type == L.F64 else torch.float32
     # the mixed stereo blocks of a launch: [BLOCKS_PER_STEP][channels][block_size], resident in HBM; two of them, used
     # alternately, so that the library's reduce of one launch overlaps the next launch's kernels
     rings = [torch.zeros((BLOCKS_PER_STEP, w_all.out_channels, bs), dtype=tdtype, device=env.dev) for _ in range(2)]
+
+    def make_bank(collective: str):
+        kwargs = dict(rank=env.rank, world=env.world)
+        if env.world > 1 and env.rehearse:
+            kwargs["reduce_fn"] = env.gloo_reduce_fn()
+        elif env.world > 1 and collective == "torch":
+            kwargs["reduce_fn"] = env.torch_reduce_fn(rings)
+        else:
+            kwargs["comm_id"] = env.comm_id()
+        b = knaster_amd.VoiceBank(w_all.stages, total_voices, w_all.sample_type, w_all.out_channels, L.MIX_TREE, env.local_rank,
+                                  args.allow_fma, **kwargs)
+        for s, a in w_all.ctor.items():
+            b.set_ctor_args(s, a)  # every rank hands over the whole list; the library keeps its range
+        b.init(configs.SAMPLE_RATE, bs)
+        return b
+
+    # The library's own RCCL reduce is the path; should its communicator fail to come up in some environment, every rank
+    # falls back (together) to torch.distributed's reduce handed to the library as its reduce function, and the line says so.
+    collective, why = "library RCCL (ncclReduce on the communicator's own stream)", None
+    bank = None
+    try:
+        bank = make_bank("native")
+        ok = 1.0
+    except L.KnasterHipError as e:
+        ok, why = 0.0, str(e)
+    if env.world > 1 and not env.rehearse and -env.max_over_ranks(-ok) < 1.0:  # min over ranks
+        if bank is not None:
+            bank.close()
+        bank = make_bank("torch")
+        collective = f"torch.distributed reduce as the library's reduce function (FALLBACK: the library's RCCL communicator failed: {why})"
+    elif bank is None:
+        raise RuntimeError(why)
+    if env.rehearse and env.world > 1:
+        collective = "host-side gloo reduce as the library's reduce function (rehearsal)"
+    ugens = knaster_amd.chain_ugen_count(w_all.stages)
+    mine = np.arange(lo, lo + cnt, dtype=np.uint32)  # global indices of this rank's voices
+    restart = bank.prepare_many(mine, w_all.restart[0], w_all.restart[1], L.VALUE_TRIGGER)
+    release = bank.prepare_many(mine, w_all.release[0], w_all.release[1], L.VALUE_TRIGGER)
     launch_no = [0]
 
     def schedule():
@@ -239,7 +275,7 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     rd, wr = bank.algorithmic_bytes_per_voice_block()
     out = dict(workload=w_all, ugens=ugens, elapsed=elapsed, kernel_avg_ms=kernel_avg_ms, launches=launches, host_rate=host_rate,
                sane=sane, peak=peak, bytes_per_voice_block=rd + wr, n_pre=n_pre, voices_rank0=cnt if env.rank == 0 else None,
-               ranks_seen=bank.ranks(), total_voices=total_voices, steps=steps)
+               ranks_seen=bank.ranks(), total_voices=total_voices, steps=steps, collective=collective)
     bank.close()
     return out
 
@@ -313,7 +349,7 @@ def main():
                 "parallelism": f"voices sharded over {world} rank(s), one process per GPU (knh_bank_create_rank); "
                                f"{BLOCKS_PER_STEP} blocks per launch; the library's ncclReduce of the stereo blocks to rank 0 once per "
                                f"launch, on its own stream",
-                "ranks_seen_by_rccl": m["ranks_seen"],
+                "ranks_seen_by_rccl": m["ranks_seen"], "collective": m["collective"],
                 "events": "t_restart on every voice at block 0 and t_release at block 32 of every 64-block cycle",
             },
             "roofline": {

@@ -23,6 +23,10 @@ pub struct knh_stage_desc {
     pub flags: u16,
     pub delayed_changes_per_block: u16,
     pub reserved: u16,
+    /// 0: the stage reads the output of the stage before it; k > 0: the output of stage k - 1
+    pub input: u16,
+    /// second operand of the KNH_STAGE_MATH_* stages (same numbering), 0 elsewhere
+    pub input2: u16,
 }
 
 #[repr(C)]
@@ -38,7 +42,7 @@ pub struct knh_bank_desc {
     pub allow_fma: u32,
 }
 
-pub const KNH_ABI_VERSION: u32 = 1;
+pub const KNH_ABI_VERSION: u32 = 2;
 
 // knh_status
 pub const KNH_OK: i32 = 0;
@@ -95,7 +99,12 @@ pub const KNH_STAGE_PINK_NOISE: u16 = 29;
 pub const KNH_STAGE_BROWN_NOISE: u16 = 30;
 pub const KNH_STAGE_RANDOM_LIN: u16 = 31;
 pub const KNH_STAGE_PAN2: u16 = 32;
-pub const KNH_STAGE_KIND_COUNT: u16 = 33;
+pub const KNH_STAGE_MATH_ADD: u16 = 33;
+pub const KNH_STAGE_MATH_SUB: u16 = 34;
+pub const KNH_STAGE_MATH_MUL: u16 = 35;
+pub const KNH_STAGE_MATH_DIV: u16 = 36;
+pub const KNH_STAGE_MATH_POW: u16 = 37;
+pub const KNH_STAGE_KIND_COUNT: u16 = 38;
 
 // knh_svf_type = SvfFilterType, knaster_core_dsp/src/ugens/svf.rs:19-39
 pub const KNH_SVF_LOW: u32 = 0;

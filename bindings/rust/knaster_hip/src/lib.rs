@@ -58,7 +58,7 @@ pub const MAX_PARAMS: usize = 6;
 pub type Stage = knh_stage_desc;
 
 pub fn stage(kind: u16) -> Stage {
-    Stage { kind, flags: 0, delayed_changes_per_block: 0, reserved: 0 }
+    Stage { kind, flags: 0, delayed_changes_per_block: 0, reserved: 0, input: 0, input2: 0 }
 }
 pub trait StageExt {
     /// `.precise_timing::<N>()` on the stage's node (wrappers_core.rs:106-111)

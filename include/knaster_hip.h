@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KNH_ABI_VERSION 1
+#define KNH_ABI_VERSION 2
 
 typedef enum knh_status {
   KNH_OK = 0,
@@ -138,6 +138,13 @@ typedef enum knh_value_kind {
  *     unpinned.
  * KNH_STAGE_SAFETY_LIMITER  x >> g.push(SafetyLimiter::new())   dynamics.rs:9-31     1    (none)
  *     clamp to [-1, 1], NaN -> 0; no parameters, no state
+ * KNH_STAGE_MATH_ADD/_SUB/_MUL/_DIV/_POW    a + b, a - b, a * b, a / b, a.pow(b) of TWO SIGNALS of the voice
+ *                           (MathUGen<_, U1, Op>, math.rs:17-165, as graph_edit.rs:936-971 creates it)   1   (none)
+ *     a = the output of stage `input`, b = the output of stage `input2` (both required).  No parameters, no state.  Pow
+ *     runs the device libm (tolerance only).  With these, with `input` on any other stage, and with source stages allowed
+ *     anywhere in the list (each starts a new signal), a voice is a small feed-forward graph rather than a chain: the
+ *     reference's "256 FM cascade" shape (knaster_benchmarks/benches/graph_dsp_performance.rs:37-72) is one.  Such voices
+ *     run in the single-wave kernel form, fused at knh_bank_init time.
  * KNH_STAGE_PAN2            x >> g.push(Pan2::new(pan))         pan.rs:12-37         1    pan (-1 .. 1)
  *     mono -> stereo with the cos/sin pan law: the voice's signal times left_gain goes to graph out 0, times
  *     right_gain to graph out 1 (`(voice >> pan).to_graph_out()`, knaster/examples/many_sines.rs:51-63).  Must be the
@@ -184,7 +191,12 @@ typedef enum knh_stage_kind {
   KNH_STAGE_BROWN_NOISE = 30,
   KNH_STAGE_RANDOM_LIN = 31,
   KNH_STAGE_PAN2 = 32,
-  KNH_STAGE_KIND_COUNT = 33
+  KNH_STAGE_MATH_ADD = 33,
+  KNH_STAGE_MATH_SUB = 34,
+  KNH_STAGE_MATH_MUL = 35,
+  KNH_STAGE_MATH_DIV = 36,
+  KNH_STAGE_MATH_POW = 37,
+  KNH_STAGE_KIND_COUNT = 38
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,
@@ -213,6 +225,13 @@ typedef struct knh_stage_desc {
    * warning, exactly like an unwrapped reference UGen (ugen.rs:339-341). */
   uint16_t delayed_changes_per_block;
   uint16_t reserved;
+  /* Which signal the stage reads.  0 (what a zero-initialised descriptor says): the output of the stage before it -- a
+   * chain on one running signal.  k > 0: the output of stage k - 1 of this list (an earlier one), so that a signal can feed
+   * several stages and stages need not follow their input directly.  Source stages read nothing (except SIN_WT with
+   * KNH_STAGE_FLAG_AR_FREQ, whose frequency this signal drives); wrapper stages (KNH_STAGE_WR_*) wrap the stage before
+   * them and keep 0.  `input2` is the second operand of the KNH_STAGE_MATH_* stages and 0 everywhere else. */
+  uint16_t input;
+  uint16_t input2;
 } knh_stage_desc;
 
 /* How the N per-voice signals are folded into the output block. */

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libknaster_hip.so")
 
-KNH_ABI_VERSION = 1
+KNH_ABI_VERSION = 2
 
 # knh_status
 OK, ERR_INVALID_ARGUMENT, ERR_OUT_OF_RANGE, ERR_UNSUPPORTED_CHAIN, ERR_DEVICE = 0, 1, 2, 3, 4
@@ -25,7 +25,8 @@ VALUE_FLOAT, VALUE_TRIGGER, VALUE_INTEGER, VALUE_BOOL, VALUE_SMOOTHING = 0, 1, 2
  STAGE_MUL_ENV_AR, STAGE_MUL_CONST, STAGE_ADD_CONST, STAGE_SUB_CONST, STAGE_DIV_CONST, STAGE_WR_MUL,
  STAGE_WR_ADD, STAGE_WR_SUB, STAGE_MUL_ENVELOPE, STAGE_WR_VSUB, STAGE_WR_DIV, STAGE_WR_VDIV, STAGE_WR_POWF,
  STAGE_WR_POWI, STAGE_POW_CONST, STAGE_SAMPLE_DELAY, STAGE_PHASOR, STAGE_SAFETY_LIMITER, STAGE_POLYBLEP, STAGE_ALLPASS_DELAY, STAGE_ALLPASS_FB_DELAY, STAGE_BUFFER_READER,
- STAGE_WHITE_NOISE, STAGE_PINK_NOISE, STAGE_BROWN_NOISE, STAGE_RANDOM_LIN, STAGE_PAN2) = range(33)
+ STAGE_WHITE_NOISE, STAGE_PINK_NOISE, STAGE_BROWN_NOISE, STAGE_RANDOM_LIN, STAGE_PAN2,
+ STAGE_MATH_ADD, STAGE_MATH_SUB, STAGE_MATH_MUL, STAGE_MATH_DIV, STAGE_MATH_POW) = range(38)
 STAGE_FLAG_AR_FREQ = 1
 STAGE_FLAG_SMOOTH_PARAMS = 2
 # knh_svf_type
@@ -41,12 +42,13 @@ STAGE_CTOR_ARGS = {  # STAGE_MUL_ENVELOPE takes 4 + 2 * n_max (variable)
     STAGE_DIV_CONST: 1, STAGE_WR_MUL: 1, STAGE_WR_ADD: 1, STAGE_WR_SUB: 1,
     STAGE_WR_VSUB: 1, STAGE_WR_DIV: 1, STAGE_WR_VDIV: 1, STAGE_WR_POWF: 1, STAGE_WR_POWI: 1, STAGE_POW_CONST: 1, STAGE_SAMPLE_DELAY: 1, STAGE_PHASOR: 1, STAGE_SAFETY_LIMITER: 0, STAGE_POLYBLEP: 2, STAGE_ALLPASS_DELAY: 1, STAGE_ALLPASS_FB_DELAY: 1, STAGE_BUFFER_READER: 3,
     STAGE_WHITE_NOISE: 1, STAGE_PINK_NOISE: 1, STAGE_BROWN_NOISE: 1, STAGE_RANDOM_LIN: 2, STAGE_PAN2: 1,
+    STAGE_MATH_ADD: 0, STAGE_MATH_SUB: 0, STAGE_MATH_MUL: 0, STAGE_MATH_DIV: 0, STAGE_MATH_POW: 0,
 }
 
 
 class StageDesc(C.Structure):
     _fields_ = [("kind", C.c_uint16), ("flags", C.c_uint16), ("delayed_changes_per_block", C.c_uint16),
-                ("reserved", C.c_uint16)]
+                ("reserved", C.c_uint16), ("input", C.c_uint16), ("input2", C.c_uint16)]
 
 
 class BankDesc(C.Structure):

@@ -22,6 +22,8 @@ class Stage:
     kind: int
     flags: int = 0
     delayed_changes_per_block: int = 0  # > 0: wrapped in WrPreciseTiming<N, _>
+    input: int = 0   # 0: reads the stage before it; k > 0: reads the output of stage k - 1 (knh_stage_desc.input)
+    input2: int = 0  # second operand of the STAGE_MATH_* stages, same numbering
 
 
 def _stage_array(stages: Sequence[Stage]):
@@ -30,6 +32,8 @@ def _stage_array(stages: Sequence[Stage]):
         arr[i].kind = s.kind
         arr[i].flags = s.flags
         arr[i].delayed_changes_per_block = s.delayed_changes_per_block
+        arr[i].input = s.input
+        arr[i].input2 = s.input2
     return arr
 
 

@@ -166,3 +166,34 @@ def c5_events(w: Workload, block: int):
     fvalues = np.where(voices % 2 == 0, p["freq"] * p["fm_ratio"] * k, 1000.0 * ((block // 2) % 16))
     kinds = np.full(nv, L.VALUE_FLOAT, dtype=np.uint32)
     return voices, stages, params, kinds, fvalues.astype(np.float64), delays
+
+
+def fm_cascade(depth: int, n_voices: int = 1, block_size: int = 128, sample_type: int = L.F32, detune: float = 0.001) -> Workload:
+    """knaster_benchmarks/benches/graph_dsp_performance.rs:37-72 ("256 FM cascade": depth = 256, one voice), as ONE voice that
+    is a graph of `depth` oscillators:
+         i = 0:  (c * s0).to_graph_out();  l = s0
+         i > 0:  add = l * 440.0;  mul = s_i * l;  node = mul + add;  node.to_graph_out();  l = node * c
+    The additive graph outputs are the reference's chain of Add nodes (graph.rs:850-864): acc = acc + node.  Voice v's
+    oscillators are detuned by (1 + detune * v) so that voices differ."""
+    st, ctor = [], {}
+
+    def push(stage, args=None):
+        st.append(stage)
+        if args is not None:
+            ctor[len(st) - 1] = args
+        return len(st)  # 1 + index: the value `input` takes to name this stage
+    s0 = push(Stage(L.STAGE_SIN_WT), 220.0)
+    acc = push(Stage(L.STAGE_MUL_CONST, input=s0), 0.05)
+    last = s0
+    for i in range(1, depth):
+        add = push(Stage(L.STAGE_MUL_CONST, input=last), 440.0)
+        s = push(Stage(L.STAGE_SIN_WT), 220.0 + i)
+        mul = push(Stage(L.STAGE_MATH_MUL, input=s, input2=last))
+        node = push(Stage(L.STAGE_MATH_ADD, input=mul, input2=add))
+        if i + 1 < depth:
+            last = push(Stage(L.STAGE_MUL_CONST, input=node), 0.05)
+        acc = push(Stage(L.STAGE_MATH_ADD, input=acc, input2=node))
+    w = Workload("FMC", st, n_voices, block_size, sample_type, 1, description=f"FM cascade of {depth} oscillators per voice")
+    scale = 1.0 + detune * np.arange(n_voices)
+    w.ctor = {s: (a * scale if st[s].kind == L.STAGE_SIN_WT else np.full(n_voices, a)).reshape(n_voices, 1) for s, a in ctor.items()}
+    return w

@@ -70,8 +70,22 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* PINK_NOISE  */ {14, 0, 1, 1, 'K', {nullptr}},
     /* BROWN_NOISE */ {3, 0, 1, 1, 'O', {nullptr}},
     /* RANDOM_LIN  */ {6, 1, 2, 1, 'G', {"freq"}},
-    /* PAN2        */ {2, 1, 1, 1, '2', {"pan"}},
+    /* PAN2        */ {2, 1, 1, 1, 'J', {"pan"}},
+    /* MATH_ADD    */ {0, 0, 0, 1, '+', {nullptr}},
+    /* MATH_SUB    */ {0, 0, 0, 1, '-', {nullptr}},
+    /* MATH_MUL    */ {0, 0, 0, 1, '*', {nullptr}},
+    /* MATH_DIV    */ {0, 0, 0, 1, '/', {nullptr}},
+    /* MATH_POW    */ {0, 0, 0, 1, '^', {nullptr}},
 };
+inline bool is_math2_kind(uint16_t kind) { return kind >= KNH_STAGE_MATH_ADD && kind <= KNH_STAGE_MATH_POW; }
+// A voice that is a graph rather than a chain: explicit operands, a MathUGen of two signals, or a second source.
+inline bool signature_is_dag(const std::string& sig) {
+  if (sig.find_first_of("@+-*/^") != std::string::npos) return true;
+  size_t sources = 0;
+  for (char c : sig) sources += std::strchr("WNPUKOGBF", c) != nullptr;
+  return sources > 1;
+}
+
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
 }
@@ -477,8 +491,9 @@ struct Bank final : knh_bank {
     const unsigned n_groups = (nv + 63u) / 64u;
     const char* jp = std::getenv("KNH_JIT_PIPE");
     // (a single voice group with a pre-built kernel stays on it: nothing to gain, and no compile at init)
+    // (a voice that is a graph, not a chain, runs in the single-wave form: the pipeline's edges carry one signal)
     const bool pipe_jit = !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 384 && !(jp && jp[0] == '0') &&
-                          !(entry && n_groups == 1);
+                          !(entry && n_groups == 1) && !signature_is_dag(signature);
     if (pipe_jit) {
       std::string why;
       unsigned cuts[2];
@@ -620,6 +635,7 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 3, v) = static_cast<W>(static_cast<uint32_t>(sb >> 32));
           } break;
           case KNH_STAGE_SAFETY_LIMITER: break;
+          case KNH_STAGE_MATH_ADD: case KNH_STAGE_MATH_SUB: case KNH_STAGE_MATH_MUL: case KNH_STAGE_MATH_DIV: case KNH_STAGE_MATH_POW: break;  // no state
           case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: {
             // fastrand::Rng::with_seed(next_randomness_seed()) (noise.rs:34,66,134): the state is the seed
             const uint64_t seed = a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u;
@@ -749,7 +765,7 @@ struct Bank final : knh_bank {
       KNH_HIP(hipMemcpy(d_seg_table, seg_rows.data(), seg_rows.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     const size_t n_waves = (nv + 63) / 64;
-    pan = !signature.empty() && signature.back() == '2';  // a Pan2 ends the chain: every voice has a left and a right signal
+    pan = !signature.empty() && stages.back().kind == KNH_STAGE_PAN2;  // a Pan2 ends the chain: every voice has a left and a right signal
     fold_planes = pan ? 2u : 1u;
     KNH_HIP(hipMalloc(&d_partials, fold_planes * n_waves * bs * sizeof(F)));
     KNH_HIP(hipMalloc(&d_out, desc.out_channels * bs * sizeof(F)));
@@ -1618,11 +1634,17 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
                         st[i].kind == KNH_STAGE_RANDOM_LIN ||
                         st[i].kind == KNH_STAGE_POLYBLEP || st[i].kind == KNH_STAGE_BUFFER_READER;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
+    const bool math2 = is_math2_kind(st[i].kind);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ)) { *why = "SMOOTH_PARAMS and AR_FREQ cannot be combined"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && is_wrapper_kind(st[i].kind)) { *why = "SMOOTH_PARAMS applies to a node, not to a wrapper stage"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].flags & KNH_STAGE_FLAG_AR_FREQ) && st[i].kind != KNH_STAGE_SIN_WT) { *why = "AR_FREQ is only defined for SIN_WT"; return KNH_ERR_INVALID_ARGUMENT; }
-    if (source && !ar && have_x) { *why = "a source stage must be first in the chain"; return KNH_ERR_INVALID_ARGUMENT; }
+    // operands: `input` / `input2` name the stage whose output is read (1 + its index), 0 = the stage before this one
+    if (st[i].input > i || st[i].input2 > i) { *why = "a stage reads the output of an earlier stage"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (math2 && (st[i].input == 0 || st[i].input2 == 0)) { *why = "a KNH_STAGE_MATH_* stage names both of its operands (input, input2)"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (!math2 && st[i].input2 != 0) { *why = "input2 is the second operand of the KNH_STAGE_MATH_* stages only"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (is_wrapper_kind(st[i].kind) && st[i].input != 0) { *why = "a wrapper stage wraps the stage before it (input = 0)"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (source && !ar && st[i].input != 0) { *why = "a source stage reads no signal"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((st[i].kind == KNH_STAGE_SAMPLE_DELAY || st[i].kind == KNH_STAGE_ALLPASS_DELAY || st[i].kind == KNH_STAGE_ALLPASS_FB_DELAY) &&
         sig->find_first_of("DYZ") != std::string::npos) {
@@ -1633,6 +1655,9 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if (st[i].kind == KNH_STAGE_PAN2 && i + 1 != n) { *why = "Pan2 ends the chain: it must be the last stage"; return KNH_ERR_INVALID_ARGUMENT; }
     if (st[i].kind == KNH_STAGE_PAN2 && st[i].delayed_changes_per_block > 0) { *why = "Pan2 cannot be wrapped in WrPreciseTiming here (its gains change at block boundaries)"; return KNH_ERR_INVALID_ARGUMENT; }
     sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
+    // explicit operands go into the signature (they are part of the kernel's type): "@a" / "@a,b", stage indices
+    if (math2) *sig += "@" + std::to_string(st[i].input - 1) + "," + std::to_string(st[i].input2 - 1);
+    else if (st[i].input != 0 && st[i].input != i) *sig += "@" + std::to_string(st[i].input - 1);
     have_x = true;
   }
   return KNH_OK;
@@ -1814,7 +1839,7 @@ static int32_t check_desc(const knh_bank_desc* desc, knh_bank** out_bank, std::s
   std::string why;
   int rc = build_signature(desc->stages, desc->n_stages, sig, &why);
   if (rc != KNH_OK) { g_create_error = why; return rc; }
-  if (sig->back() == '2' && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->stages[desc->n_stages - 1].kind == KNH_STAGE_PAN2 && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
   return KNH_OK;
 }
 
@@ -1873,7 +1898,7 @@ static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh
   std::string sig, why;
   int rc = build_signature(desc->stages, desc->n_stages, &sig, &why);
   if (rc != KNH_OK) { g_create_error = why; return rc; }
-  if (sig.back() == '2' && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->stages[desc->n_stages - 1].kind == KNH_STAGE_PAN2 && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
   // a chain without a pre-built kernel is fused at knh_bank_init time (hiprtc); entry == nullptr marks it
   const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
   // the reference's exact mix order (KNH_MIX_LEFT_FOLD) and banks of a single voice group keep one range

@@ -66,10 +66,10 @@ static const PipeEntry kPipes[] = {
     KNH_PIPE("NSAm", 3, G_N, G_S, G_Am),
     KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA),  // the delay's HBM traffic rides in the envelope wave
     KNH_PIPE("BmSA", 3, G_Bm, G_S, G_A),
-    KNH_PIPE_BIG("WmE2", 2, G_Wm, G_E2),     // many_sines: oscillator | envelope + pan + fold
-    KNH_PIPE("WmE2", 2, G_Wm, G_E2),
-    KNH_PIPE_BIG("WmSA2", 3, G_Wm, G_S, G_A2),
-    KNH_PIPE("WmSA2", 3, G_Wm, G_S, G_A2),
+    KNH_PIPE_BIG("WmEJ", 2, G_Wm, G_E2),     // many_sines: oscillator | envelope + pan + fold
+    KNH_PIPE("WmEJ", 2, G_Wm, G_E2),
+    KNH_PIPE_BIG("WmSAJ", 3, G_Wm, G_S, G_A2),
+    KNH_PIPE("WmSAJ", 3, G_Wm, G_S, G_A2),
 };
 const PipeEntry* find_pipe(const char* signature, bool allow_big) {
   for (const PipeEntry& e : kPipes)

@@ -33,8 +33,8 @@ static const KernelEntry kEntries[] = {
     KNH_CHAIN("WA", SinWt, MulAsr),
     KNH_CHAIN("WE", SinWt, MulAr),
     KNH_CHAIN("WmE", SinWt, MulVal, MulAr),                     // knaster/examples/many_sines.rs:51-63 minus Pan2
-    KNH_CHAIN("WmE2", SinWt, MulVal, MulAr, Pan2),               // knaster/examples/many_sines.rs:51-63: (env * sine.wr_mul) >> Pan2
-    KNH_CHAIN("WmSA2", SinWt, MulVal, Svf, MulAsr, Pan2),        // the C3 voice panned
+    KNH_CHAIN("WmEJ", SinWt, MulVal, MulAr, Pan2),               // knaster/examples/many_sines.rs:51-63: (env * sine.wr_mul) >> Pan2
+    KNH_CHAIN("WmSAJ", SinWt, MulVal, Svf, MulAsr, Pan2),        // the C3 voice panned
     KNH_CHAIN("WSA", SinWt, Svf, MulAsr),
     KNH_CHAIN("WSAm", SinWt, Svf, MulAsr, MulVal),
     KNH_CHAIN("WLAm", SinWt, OnePoleLp, MulAsr, MulVal),

@@ -29,7 +29,7 @@ static const WideEntry kWides[] = {
     KNH_WIDE("WSAm", SinWt, Svf, MulAsr, MulVal),
     KNH_WIDE("WmE", SinWt, MulVal, MulAr),
     KNH_WIDE("WmaRm", SinWt, MulVal, AddVal, SinWtAr, MulVal),
-    KNH_WIDE("WmE2", SinWt, MulVal, MulAr, Pan2),
+    KNH_WIDE("WmEJ", SinWt, MulVal, MulAr, Pan2),
 };
 const WideEntry* find_wide(const char* signature) {
   for (const WideEntry& e : kWides)

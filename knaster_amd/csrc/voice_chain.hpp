@@ -64,6 +64,7 @@ struct StageDefaults {
   // (take_params, one compare and one select per parameter and sample) instead of dropping to the per-sample path.
   static constexpr u32 kParamMask = 0u;
   template <typename R> static __device__ __forceinline__ void take_params(R&, const R&, bool) {}
+  static constexpr bool kBinary = false;  // a MathUGen of two signals (Math2): no tick, an apply(a, b)
 };
 
 // Event opcodes (host -> device state patches, applied at an in-block frame).
@@ -1809,6 +1810,136 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
 };
 
 // ---------------------------------------------------------------------------
+// Voices that are not a chain on one running signal but a small graph (DAG) of the same stages: `sine_a * sine_b`,
+// `l * 440 + s * l` (knaster_benchmarks/benches/graph_dsp_performance.rs:37-72), one signal feeding two consumers.
+// Every stage's output is a signal of its own, numbered by the stage's position; a stage reads the output of the stage
+// before it unless it says otherwise (At<S, A>), and MathUGen<_, U1, Op> of two signals (math.rs:94-165,
+// graph_edit.rs:936-971) is a stage with two operands (At<Math2<OP>, A, B>).  The voice's output is the last stage's.
+// All of it unrolls into straight-line code on registers, like a chain; it runs in the single-wave kernel.
+// ---------------------------------------------------------------------------
+template <int OP>  // 0 mul, 1 add, 2 sub, 3 div, 6 pow (ValT's numbering)
+struct Math2 : StageDefaults {
+  static constexpr int kSlots = 0;
+  static constexpr u32 kMutableMask = 0u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  static constexpr bool kBinary = true;
+  template <typename F> struct Regs {};
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>&, const W*, long) {}
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  template <typename F> static __device__ __forceinline__ F apply(F a, F b) {  // math.rs:22-85: a op b
+    if (OP == 0) return a * b;
+    if (OP == 1) return a + b;
+    if (OP == 2) return a - b;
+    if (OP == 3) return a / b;
+    return dev_pow(a, b);
+  }
+  template <typename F, bool FMA> static __device__ __forceinline__ F tick(Regs<F>&, F x, const Ctx&, u32, u32&) { return x; }
+  template <typename F, bool FMA, int T> static __device__ __forceinline__ void tick_tile(Regs<F>&, F (&)[T], const Ctx&, u32, u32&) {}
+  template <typename F> static __device__ __forceinline__ void on_event(Regs<F>&, u32, u32, u64, u32) {}
+};
+// a stage with explicit operands: A (and B for Math2) = the index of the stage whose output it reads, -1 = the stage before it
+template <typename S, int A = -1, int B = -1> struct At {};
+template <typename X> struct NodeOf { typedef X stage; static constexpr int a = -1, b = -1; static constexpr bool dag = X::kBinary; };
+template <typename S, int A, int B> struct NodeOf<At<S, A, B>> { typedef S stage; static constexpr int a = A, b = B; static constexpr bool dag = true; };
+
+template <typename F, bool FMA, int K, int BASE, int N, typename... Ns> struct DagChain;
+template <typename F, bool FMA, int K, int BASE, int N>
+struct DagChain<F, FMA, K, BASE, N> {
+  static constexpr int kSlots = BASE;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kPan = false;
+  __device__ __forceinline__ void pan_gains(F&, F&) const {}
+  template <typename W> __device__ __forceinline__ void load(const W*, long) {}
+  template <typename W> __device__ __forceinline__ void store(W*, long) const {}
+  template <int T> __device__ __forceinline__ void run_tile(F (&)[N][T], const Ctx&, u32) {}
+  __device__ __forceinline__ void run_one(F (&)[N], const Ctx&, u32) {}
+  __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
+  __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
+  __device__ __forceinline__ u32 collect_done(u32 acc) const { return acc; }
+  __device__ __forceinline__ void begin_block(u32, const Ctx&) {}
+};
+template <typename F, bool FMA, int K, int BASE, int N, typename N0, typename... Rest>
+struct DagChain<F, FMA, K, BASE, N, N0, Rest...> {
+  typedef typename NodeOf<N0>::stage S0;
+  static constexpr int A = NodeOf<N0>::a >= 0 ? NodeOf<N0>::a : K - 1;  // -1 for the first stage: no input (a source)
+  static constexpr int B = NodeOf<N0>::b;
+  static_assert(A < K && B < K, "a stage reads the output of an earlier stage");
+  static_assert(!S0::kBinary || (A >= 0 && B >= 0), "a MathUGen of two signals names both");
+  typedef DagChain<F, FMA, K + 1, BASE + S0::kSlots, N, Rest...> RestT;
+  static constexpr int kSlots = RestT::kSlots;
+  static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
+  static constexpr bool kPan = IsPan<S0>::value || RestT::kPan;
+  typename S0::template Regs<F> r;
+  u32 mark = 0xFFFFFFFFu;
+  RestT rest;
+  template <typename W> __device__ __forceinline__ void load(const W* s, long stride) {
+    S0::template load<F, W>(r, s + (long)BASE * stride, stride);
+    rest.load(s, stride);
+  }
+  template <typename W> __device__ __forceinline__ void store(W* s, long stride) const {
+    S0::template store<F, W>(r, s + (long)BASE * stride, stride);
+    rest.store(s, stride);
+  }
+  template <int T> __device__ __forceinline__ void run_tile(F (&sig)[N][T], const Ctx& c, u32 frame0) {
+    if constexpr (S0::kBinary) {
+#pragma unroll
+      for (int j = 0; j < T; ++j) sig[K][j] = S0::template apply<F>(sig[A][j], sig[B][j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < T; ++j) sig[K][j] = A >= 0 ? sig[A >= 0 ? A : 0][j] : (F)0;
+      S0::template tick_tile<F, FMA, T>(r, sig[K], c, frame0, mark);
+    }
+    rest.template run_tile<T>(sig, c, frame0);
+  }
+  __device__ __forceinline__ void run_one(F (&sig)[N], const Ctx& c, u32 frame) {
+    if constexpr (S0::kBinary) sig[K] = S0::template apply<F>(sig[A], sig[B]);
+    else sig[K] = S0::template tick<F, FMA>(r, A >= 0 ? sig[A >= 0 ? A : 0] : (F)0, c, frame, mark);
+    rest.run_one(sig, c, frame);
+  }
+  // the kernel's view: a voice's tile / sample is the last stage's signal (only called on the head of the list)
+  template <int T> __device__ __forceinline__ void tick_tile(F (&x)[T], const Ctx& c, u32 frame0) {
+    static_assert(K == 0, "tick_tile is the head's");
+    F sig[N][T];
+    run_tile<T>(sig, c, frame0);
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = sig[N - 1][j];
+  }
+  __device__ __forceinline__ F tick(F, const Ctx& c, u32 frame) {
+    static_assert(K == 0, "tick is the head's");
+    F sig[N];
+    run_one(sig, c, frame);
+    return sig[N - 1];
+  }
+  __device__ __forceinline__ u32 collect_done(u32 acc) const {
+    if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
+    return rest.collect_done(acc);
+  }
+  __device__ __forceinline__ void pan_gains(F& l, F& rg) const {
+    if constexpr (IsPan<S0>::value) { l = r.l; rg = r.r; }
+    else rest.pan_gains(l, rg);
+  }
+  __device__ __forceinline__ void on_event(u32 op, u32 slot, u64 bits, u32 frame) {
+    if (slot >= (u32)BASE && slot < (u32)(BASE + S0::kSlots)) S0::template on_event<F>(r, op, slot - BASE, bits, frame);
+    else rest.on_event(op, slot, bits, frame);
+  }
+  __device__ __forceinline__ bool last_env_stopped(bool dflt) const {
+    if constexpr (S0::kIsEnv) return rest.last_env_stopped(S0::template is_stopped<F>(r));
+    else return rest.last_env_stopped(dflt);
+  }
+  __device__ __forceinline__ void begin_block(u32 frame_begin, const Ctx& c) {
+    if constexpr (S0::kNeedsBind) S0::template bind<F>(r, c);
+    if constexpr (S0::kIsEnv && S0::kHasSeg) r.seg = frame_begin;
+    rest.begin_block(frame_begin, c);
+  }
+};
+// the kernel's chain type: a plain chain unless some stage names its operands
+template <bool DAG, typename F, bool FMA, typename... S> struct ChainSelect { typedef Chain<F, FMA, 0, S...> type; };
+template <typename F, bool FMA, typename... S> struct ChainSelect<true, F, FMA, S...> { typedef DagChain<F, FMA, 0, 0, (int)sizeof...(S), S...> type; };
+
+// ---------------------------------------------------------------------------
 // Kernel arguments
 // ---------------------------------------------------------------------------
 template <typename F>
@@ -1844,7 +1975,7 @@ constexpr int kTile = 8;  // samples evaluated stage-by-stage in registers
 // the bank has more 64-voice groups than the chip has SIMDs to give each its own (throughput regime).
 template <typename F, bool FMA, int WAVES, typename... S>
 __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a) {
-  typedef Chain<F, FMA, 0, S...> ChainT;
+  typedef typename ChainSelect<(false || ... || NodeOf<S>::dag), F, FMA, S...>::type ChainT;
   typedef typename WordOf<F>::type W;
   // frames per reduce tile: sized so that WAVES tiles + the sine table fit the CU's 160 KiB of LDS
   constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 8 ? 2 : 1);

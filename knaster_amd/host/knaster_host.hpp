@@ -16,8 +16,9 @@
 // instead of ~6 nodes per voice.  Parameter handles (`node.param("freq").set(v)`, `.set_at(v, t)`,
 // `.trig()`) and `carrier.link("freq", signal)` keep their meaning; GraphGen's event handling
 // (graph_gen.rs:110-166, scheduling.rs:95-121) is restated in `AudioProcessor::run_*`.
-// Anything that is not a supported voice chain is rejected at commit (the reference would run it on
-// the CPU; that is outside this engine).  Header-only; needs libknaster_hip.so.
+// A voice may be a small graph, not only a chain: `a * b` of two oscillators, one signal feeding two filters
+// (knh_stage_desc.input / KNH_STAGE_MATH_*).  Anything that is not a supported per-voice graph is rejected at
+// commit (the reference would run it on the CPU; that is outside this engine).  Header-only; needs libknaster_hip.so.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -162,7 +163,8 @@ template <typename F> class AudioProcessor;
 struct NodeRec {
   enum Type { UGEN, MATH } type = UGEN;
   UGenSpec spec;            // UGEN
-  uint16_t math_kind = 0;   // MATH: KNH_STAGE_{MUL,ADD,SUB,DIV}_CONST for op with a Constant; 0xFFFF = signal * signal
+  uint16_t math_kind = 0;   // MATH: KNH_STAGE_{MUL,ADD,SUB,DIV}_CONST for op with a Constant; 0xFFFF = signal (op) signal
+  uint16_t math2_kind = KNH_STAGE_MATH_MUL;  // MATH of two signals: KNH_STAGE_MATH_{ADD,SUB,MUL,DIV,POW}
   int in0 = -1, in1 = -1;   // input edges (node ids)
   int link_source = -1, link_param = -1;  // audio-rate parameter edge (graph_edit.rs:735-754)
   // where the node ended up after commit
@@ -187,7 +189,8 @@ struct ChainPlan {
   std::string signature() const {
     std::string s;
     for (auto& st : stages) {
-      s += std::to_string(st.kind) + "." + std::to_string(st.flags) + "." + std::to_string(st.delayed_changes_per_block) + ";";
+      s += std::to_string(st.kind) + "." + std::to_string(st.flags) + "." + std::to_string(st.delayed_changes_per_block) + "." +
+           std::to_string(st.input) + "." + std::to_string(st.input2) + ";";
     }
     return s;
   }
@@ -204,7 +207,12 @@ class Sig {  // SH / DH of graph_edit.rs:266-277: one or more output channels of
   Sig operator-(double c) const { return g_->math_const(*this, KNH_STAGE_SUB_CONST, c); }
   Sig operator/(double c) const { return g_->math_const(*this, KNH_STAGE_DIV_CONST, c); }
   Sig pow(double c) const { return g_->math_const(*this, KNH_STAGE_POW_CONST, c); }  // graph_edit.rs:451 with a Constant
-  Sig operator*(const Sig& o) const { return g_->math_sig(*this, o); }
+  // two signals: MathUGen<_, U1, Op> with both inputs connected (graph_edit.rs:936-971)
+  Sig operator*(const Sig& o) const { return g_->math_sig(*this, o, KNH_STAGE_MATH_MUL); }
+  Sig operator+(const Sig& o) const { return g_->math_sig(*this, o, KNH_STAGE_MATH_ADD); }
+  Sig operator-(const Sig& o) const { return g_->math_sig(*this, o, KNH_STAGE_MATH_SUB); }
+  Sig operator/(const Sig& o) const { return g_->math_sig(*this, o, KNH_STAGE_MATH_DIV); }
+  Sig pow(const Sig& o) const { return g_->math_sig(*this, o, KNH_STAGE_MATH_POW); }
   Sig operator>>(const Sig& sink) const { return g_->connect(*this, sink); }  // graph_edit.rs:1347-1417
   // .out([0,0]): the same channel twice (graph_edit.rs:280-292)
   Sig out(std::initializer_list<int> channels) const {
@@ -318,54 +326,87 @@ class Graph {
 
   void schedule(const SchedulingEvent& ev) { events_.push_back(ev); }
 
-  // ---- chain recognition -------------------------------------------------------------------------
-  void trace(int node, ChainPlan& p, std::vector<int>& visited) {
+  // ---- voice recognition -------------------------------------------------------------------------
+  // Walks back from `node` and appends the stages that produce its signal; returns that signal's name for a later
+  // stage's `input` (1 + the index of the stage whose output it is).  A node already met in this voice (one signal
+  // feeding two consumers) is not walked again.  A stage that reads the stage right before it says so with input = 0,
+  // so that plain chains keep the descriptors (and the pre-built kernels) they always had.
+  uint16_t trace(int node, ChainPlan& p, std::vector<int>& visited, std::map<int, uint16_t>& done) {
     if (node < 0) throw GraphError("unconnected input in a voice chain");
+    auto seen = done.find(node);
+    if (seen != done.end()) return seen->second;
     NodeRec& n = nodes_[static_cast<size_t>(node)];
-    if (n.bank >= 0) throw GraphError("a node feeds more than one voice chain (fan-out is not a per-voice chain)");
+    if (n.bank >= 0) throw GraphError("a node feeds more than one voice (fan-out across voices is not a per-voice graph)");
     visited.push_back(node);
+    auto in_of = [&](uint16_t src) -> uint16_t { return src == p.stages.size() ? 0 : src; };  // the stage before: the default
+    auto finish = [&]() -> uint16_t { return done[node] = static_cast<uint16_t>(p.stages.size()); };
     if (n.type == NodeRec::MATH) {
       if (n.math_kind != 0xFFFF) {  // signal (op) Constant: graph_edit.rs:1036-1066
-        trace(n.in0, p, visited);
+        const uint16_t src = trace(n.in0, p, visited, done);
         const NodeRec& c = nodes_[static_cast<size_t>(n.in1)];
-        push_stage(p, n.math_kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, n.in1, c.spec.args);
+        push_stage(p, n.math_kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, n.in1, c.spec.args, in_of(src));
         visited.push_back(n.in1);
-        return;
+        return finish();
       }
-      // signal * envelope (either operand order; multiplication commutes exactly)
       const NodeRec& a = nodes_[static_cast<size_t>(n.in0)];
       const NodeRec& b = nodes_[static_cast<size_t>(n.in1)];
-      int env = (b.type == NodeRec::UGEN && b.spec.is_env) ? n.in1 : (a.type == NodeRec::UGEN && a.spec.is_env) ? n.in0 : -1;
-      if (env < 0) throw GraphError("signal * signal is only fused when one side is an EnvAsr/EnvAr");
-      trace(env == n.in1 ? n.in0 : n.in1, p, visited);
-      const NodeRec& e = nodes_[static_cast<size_t>(env)];
-      if (!e.spec.wrappers.empty()) throw GraphError("wrappers on an envelope inside a product are not fused");
-      push_stage(p, e.spec.kind, e.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, e.spec.precise_timing_, env, e.spec.args);
-      visited.push_back(env);
-      return;
+      // signal * envelope (either operand order; multiplication commutes exactly)
+      int env = -1;
+      if (n.math2_kind == KNH_STAGE_MATH_MUL)
+        env = (b.type == NodeRec::UGEN && b.spec.is_env) ? n.in1 : (a.type == NodeRec::UGEN && a.spec.is_env) ? n.in0 : -1;
+      if (env >= 0) {
+        const uint16_t src = trace(env == n.in1 ? n.in0 : n.in1, p, visited, done);
+        const NodeRec& e = nodes_[static_cast<size_t>(env)];
+        if (!e.spec.wrappers.empty()) throw GraphError("wrappers on an envelope inside a product are not fused");
+        push_stage(p, e.spec.kind, e.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, e.spec.precise_timing_, env, e.spec.args, in_of(src));
+        visited.push_back(env);
+        return finish();
+      }
+      // signal (op) pushed Constant: the same Constant + MathUGen pair as `signal (op) number`
+      // (a Constant on the left only where the operation commutes exactly)
+      const bool a_const = a.type == NodeRec::UGEN && a.spec.is_constant, b_const = b.type == NodeRec::UGEN && b.spec.is_constant;
+      const bool commutes = n.math2_kind == KNH_STAGE_MATH_MUL || n.math2_kind == KNH_STAGE_MATH_ADD;
+      if (b_const || (a_const && commutes)) {
+        const int cn = b_const ? n.in1 : n.in0;
+        const uint16_t src = trace(b_const ? n.in0 : n.in1, p, visited, done);
+        const NodeRec& c = nodes_[static_cast<size_t>(cn)];
+        if (!c.spec.wrappers.empty()) throw GraphError("wrappers on a Constant operand are not fused");
+        const uint16_t kind = n.math2_kind == KNH_STAGE_MATH_MUL ? KNH_STAGE_MUL_CONST : n.math2_kind == KNH_STAGE_MATH_ADD ? KNH_STAGE_ADD_CONST
+                            : n.math2_kind == KNH_STAGE_MATH_SUB ? KNH_STAGE_SUB_CONST : n.math2_kind == KNH_STAGE_MATH_DIV ? KNH_STAGE_DIV_CONST : KNH_STAGE_POW_CONST;
+        push_stage(p, kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, cn, c.spec.args, in_of(src));
+        visited.push_back(cn);
+        return finish();
+      }
+      // two signals of the voice: MathUGen<_, U1, Op> with both operands named
+      const uint16_t sa = trace(n.in0, p, visited, done);
+      const uint16_t sb = trace(n.in1, p, visited, done);
+      push_stage(p, n.math2_kind, 0, 0, -1, {}, sa, sb);
+      return finish();
     }
     const UGenSpec& s = n.spec;
     if (s.is_env || s.is_constant) throw GraphError("an envelope/constant must be an operand of * + - /");
     const bool source = s.kind == KNH_STAGE_SIN_WT || s.kind == KNH_STAGE_SIN_NUMERIC || s.kind == KNH_STAGE_PHASOR || s.kind == KNH_STAGE_POLYBLEP ||
                         s.kind == KNH_STAGE_BUFFER_READER || s.kind == KNH_STAGE_WHITE_NOISE || s.kind == KNH_STAGE_PINK_NOISE ||
                         s.kind == KNH_STAGE_BROWN_NOISE || s.kind == KNH_STAGE_RANDOM_LIN;
-    uint16_t flags = 0;
+    uint16_t flags = 0, input = 0;
     if (source) {
       if (n.link_source >= 0) {
         if (!(s.kind == KNH_STAGE_SIN_WT && s.ar_params_ && n.link_param == 0))
           throw GraphError("only SinWt(..).ar_params() with link(\"freq\", ..) is fused");
-        trace(n.link_source, p, visited);
+        input = in_of(trace(n.link_source, p, visited, done));
         flags = KNH_STAGE_FLAG_AR_FREQ;
       }
     } else {
-      trace(n.in0, p, visited);
+      input = in_of(trace(n.in0, p, visited, done));
     }
     if (s.smooth_params_) flags |= KNH_STAGE_FLAG_SMOOTH_PARAMS;
-    push_stage(p, s.kind, flags, s.precise_timing_, node, s.args);
+    push_stage(p, s.kind, flags, s.precise_timing_, node, s.args, input);
     for (auto& w : s.wrappers) push_stage(p, w.first, 0, 0, node, {w.second});
+    return finish();
   }
-  static void push_stage(ChainPlan& p, uint16_t kind, uint16_t flags, uint16_t dcpb, int node, std::vector<double> args) {
-    p.stages.push_back(knh_stage_desc{kind, flags, dcpb, 0});
+  static void push_stage(ChainPlan& p, uint16_t kind, uint16_t flags, uint16_t dcpb, int node, std::vector<double> args, uint16_t input = 0,
+                         uint16_t input2 = 0) {
+    p.stages.push_back(knh_stage_desc{kind, flags, dcpb, 0, input, input2});
     p.stage_node.push_back(node);
     p.stage_args.push_back(std::move(args));
   }
@@ -386,7 +427,8 @@ class Graph {
       }
       if (pan && outputs_ != 2) throw GraphError("a Pan2 voice needs a stereo graph");
       Voice v;
-      trace(conn[0].first, v.plan, v.nodes);
+      std::map<int, uint16_t> done;
+      trace(conn[0].first, v.plan, v.nodes, done);
       voices.push_back(std::move(v));
     }
     new_outputs_.clear();
@@ -408,6 +450,7 @@ class Graph {
         const Voice& v = voices[members[vi]];
         for (size_t s = 0; s < v.plan.stages.size(); ++s) {
           int node = v.plan.stage_node[s];
+          if (node < 0) continue;  // a MathUGen of two signals: no parameters, found through v.nodes below
           NodeRec& nr = nodes_[static_cast<size_t>(node)];
           if (nr.bank < 0) { nr.bank = bank_index; nr.voice = static_cast<int>(vi); nr.stage = static_cast<int>(s); }
         }
@@ -490,10 +533,11 @@ class GraphEdit {
     }
     return Sig<F>(this, outs);
   }
-  Sig<F> math_sig(const Sig<F>& a, const Sig<F>& b) {  // graph_edit.rs:936-971
+  Sig<F> math_sig(const Sig<F>& a, const Sig<F>& b, uint16_t kind) {  // graph_edit.rs:936-971
     NodeRec m;
     m.type = NodeRec::MATH;
     m.math_kind = 0xFFFF;
+    m.math2_kind = kind;
     m.in0 = a.node();
     m.in1 = b.node();
     graph_->nodes_.push_back(m);

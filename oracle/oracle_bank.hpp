@@ -31,6 +31,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: return 1;
     case KNH_STAGE_RANDOM_LIN: return 2;
     case KNH_STAGE_PAN2: return 1;
+    case KNH_STAGE_MATH_ADD: case KNH_STAGE_MATH_SUB: case KNH_STAGE_MATH_MUL: case KNH_STAGE_MATH_DIV: case KNH_STAGE_MATH_POW: return 0;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
   return 0;
@@ -59,10 +60,55 @@ struct VoiceChainBuilder {
     targets.assign(stages.size(), ParamTarget{});
     bool have_x = false;
     NodeKey x = 0;
+    std::vector<NodeKey> out_of(stages.size(), 0);  // the node whose output 0 is stage s's signal
     for (size_t s = 0; s < stages.size(); ++s) {
       const knh_stage_desc& st = stages[s];
       if (stage_is_wrapper(st.kind)) throw std::runtime_error("wrapper stage without a node to wrap");
       const std::vector<double>& a = args[s];
+      // which signal the stage reads: the stage before it, or the one it names (knh_stage_desc.input)
+      if (st.input > s || st.input2 > s) throw std::runtime_error("a stage reads the output of an earlier stage");
+      if (st.input != 0) x = out_of[st.input - 1];
+      if (st.kind >= KNH_STAGE_MATH_ADD && st.kind <= KNH_STAGE_MATH_POW) {  // MathUGen<_, U1, Op> of two signals (graph_edit.rs:936-971)
+        if (st.input == 0 || st.input2 == 0) throw std::runtime_error("a MATH stage names both operands");
+        const MathOp op = st.kind == KNH_STAGE_MATH_ADD ? MathOp::Add : st.kind == KNH_STAGE_MATH_SUB ? MathOp::Sub
+                        : st.kind == KNH_STAGE_MATH_MUL ? MathOp::Mul : st.kind == KNH_STAGE_MATH_DIV ? MathOp::Div : MathOp::Pow;
+        UGenPtr<F> math2 = std::make_unique<MathUGen<F>>(1, op);
+        // wrapper stages that follow wrap this node
+        size_t s2 = s + 1;
+        std::vector<std::pair<size_t, size_t>> wr_targets;
+        while (s2 < stages.size() && stage_is_wrapper(stages[s2].kind)) {
+          size_t off = math2->parameters();
+          WrOp wop = WrOp::Mul;
+          switch (stages[s2].kind) {
+            case KNH_STAGE_WR_ADD: wop = WrOp::Add; break;
+            case KNH_STAGE_WR_SUB: wop = WrOp::Sub; break;
+            case KNH_STAGE_WR_VSUB: wop = WrOp::VSub; break;
+            case KNH_STAGE_WR_DIV: wop = WrOp::Div; break;
+            case KNH_STAGE_WR_VDIV: wop = WrOp::VDiv; break;
+            case KNH_STAGE_WR_POWF: wop = WrOp::Powf; break;
+            case KNH_STAGE_WR_POWI: wop = WrOp::Powi; break;
+            default: break;
+          }
+          if (wop == WrOp::Powi) math2 = std::make_unique<WrMath<F>>(std::move(math2), static_cast<int32_t>(args[s2][0]));
+          else math2 = std::make_unique<WrMath<F>>(std::move(math2), wop, fnew<F>(args[s2][0]));
+          wr_targets.emplace_back(s2, off);
+          ++s2;
+        }
+        NodeKey m = g.push(std::move(math2));
+        g.connect_to_node(out_of[st.input - 1], 0, 0, m, false);
+        g.connect_to_node(out_of[st.input2 - 1], 0, 1, m, false);
+        targets[s].node = m;
+        for (auto& [ws, off] : wr_targets) {
+          targets[ws].node = m;
+          targets[ws].index_offset = off;
+          targets[ws].n_params = stages[ws].kind == KNH_STAGE_WR_MUL ? 1 : 0;
+        }
+        for (size_t k = s; k < s2; ++k) out_of[k] = m;
+        x = m;
+        have_x = true;
+        s = s2 - 1;
+        continue;
+      }
       // Core UGen of the stage (the parameterised node).
       UGenPtr<F> core;
       switch (st.kind) {
@@ -169,9 +215,7 @@ struct VoiceChainBuilder {
         if (ar) {
           if (!have_x) throw std::runtime_error("AR_FREQ stage needs a preceding signal");
           g.connect_to_parameter(x, 0, 0, core_key);
-        } else if (have_x) {
-          throw std::runtime_error("a source stage must be first in the chain");
-        }
+        }  // (a source after the first stage starts a new signal of the voice)
       } else if (!two_node) {
         if (!have_x) throw std::runtime_error("processor stage needs a preceding signal");
         g.connect_to_node(x, 0, 0, core_key, false);
@@ -187,6 +231,7 @@ struct VoiceChainBuilder {
         targets[ws].index_offset = off;
         targets[ws].n_params = stages[ws].kind == KNH_STAGE_WR_MUL ? 1 : 0;
       }
+      for (size_t k = s; k < s2; ++k) out_of[k] = out_key;
       x = out_key;
       have_x = true;
       s = s2 - 1;

@@ -138,6 +138,23 @@ static void plan_many_sines_with_pan2() {
   } catch (const GraphError&) { threw = true; }
   CHECK(threw);
 }
+// A voice that is a graph: ring modulation of two oscillators, and the reference's "FM cascade"
+// (knaster_benchmarks/benches/graph_dsp_performance.rs:37-72) written with the same operators.
+static void plan_voices_that_are_graphs() {
+  auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
+  (void)processor;
+  graph->plan_only = true;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int i = 0; i < 3; ++i) {
+      auto a = g.push(SinWt(100. + i)), b = g.push(SinWt(200. + i).wr_mul(0.5));
+      ((a * b) * 0.1).out({0, 0}).to_graph_out();  // ring modulation
+    }
+  });
+  CHECK(graph->num_banks() == 1 && graph->bank(0).n_voices == 3);
+  const auto& st = graph->bank(0).plan.stages;
+  CHECK(st.size() == 5 && st[0].kind == KNH_STAGE_SIN_WT && st[1].kind == KNH_STAGE_SIN_WT && st[2].kind == KNH_STAGE_WR_MUL);
+  CHECK(st[3].kind == KNH_STAGE_MATH_MUL && st[3].input == 1 && st[3].input2 == 3 && st[4].kind == KNH_STAGE_MUL_CONST && st[4].input == 0);
+}
 static void plan_rejects_what_is_not_a_voice_chain() {
   auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
   (void)processor;
@@ -145,8 +162,8 @@ static void plan_rejects_what_is_not_a_voice_chain() {
   bool threw = false;
   try {
     graph->edit([&](GraphEdit<float>& g) {
-      auto a = g.push(SinWt(100.)), b = g.push(SinWt(200.));
-      (a * b).out({0, 0}).to_graph_out();  // ring modulation of two oscillators: not a per-voice chain shape we fuse
+      auto a = g.push(SinWt(100.)), e = g.push(EnvAsr(0.1, 0.1));
+      (a >> e).out({0, 0}).to_graph_out();  // an envelope is an operand of *, not a processor
     });
   } catch (const GraphError&) { threw = true; }
   CHECK(threw);
@@ -556,6 +573,71 @@ static void gpu_many_sines_with_pan2() {
   std::printf("  many_sines with Pan2: max |gpu - reference-shaped graph| = %.3g (peak %.3g, max |L - R| %.3g)\n", worst, peak, stereo);
   CHECK(worst <= 1e-5 && peak > 1e-3 && stereo > 1e-4);
 }
+// Graph-shaped voices end to end: ring modulation with fan-out, and eight-oscillator FM cascades built with the
+// operators of graph_dsp_performance.rs:37-72 -- each cascade's additive outputs are separate to_graph_out() calls, i.e.
+// separate voices of the mirror that share nodes: that sharing across voices is what the planner refuses, so here every
+// cascade sums its nodes itself (acc = acc + node, the Add chain the reference inserts).
+static void gpu_voices_that_are_graphs() {
+  const int N = 70, B = 64, D = 8;
+  auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+  kno::Graph<float> ref(0, 2, B, 48000);
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int v = 0; v < N; ++v) {
+      const double det = 1.0 + 0.003 * v;
+      auto s0 = g.push(SinWt(220. * det));
+      auto acc = s0 * 0.05;
+      auto last = s0;
+      for (int i = 1; i < D; ++i) {
+        auto s = g.push(SinWt((220. + i) * det));
+        auto add = last * 440.0;
+        auto mul = s * last;
+        auto node = mul + add;
+        acc = acc + node;
+        if (i + 1 < D) last = node * 0.05;
+      }
+      (acc * (1.0 / N)).out({0, 0}).to_graph_out();
+    }
+  });
+  CHECK(graph->num_banks() == 1 && graph->bank(0).n_voices == N);
+  for (int v = 0; v < N; ++v) {
+    const float det = float(1.0 + 0.003 * v);
+    auto s0 = ref.push(std::make_unique<kno::SinWt<float>>(float(220. * double(det))));
+    auto c0 = ref.push(std::make_unique<kno::Constant<float>>(0.05f));
+    auto acc = ref.math_nodes(s0, 0, kno::MathOp::Mul, c0, 0);
+    auto last = s0;
+    for (int i = 1; i < D; ++i) {
+      auto s = ref.push(std::make_unique<kno::SinWt<float>>(float((220. + i) * double(det))));
+      auto k440 = ref.push(std::make_unique<kno::Constant<float>>(440.0f));
+      auto add = ref.math_nodes(last, 0, kno::MathOp::Mul, k440, 0);
+      auto mul = ref.math_nodes(s, 0, kno::MathOp::Mul, last, 0);
+      auto node = ref.math_nodes(mul, 0, kno::MathOp::Add, add, 0);
+      acc = ref.math_nodes(acc, 0, kno::MathOp::Add, node, 0);
+      if (i + 1 < D) {
+        auto c = ref.push(std::make_unique<kno::Constant<float>>(0.05f));
+        last = ref.math_nodes(node, 0, kno::MathOp::Mul, c, 0);
+      }
+    }
+    auto g1 = ref.push(std::make_unique<kno::Constant<float>>(float(1.0 / N)));
+    auto out = ref.math_nodes(acc, 0, kno::MathOp::Mul, g1, 0);
+    ref.connect_to_output(out, 0, 0, true);
+    ref.connect_to_output(out, 0, 1, true);
+  }
+  ref.commit_changes();
+  std::vector<float> want(2 * B);
+  double worst = 0, peak = 0;
+  for (int block = 0; block < 4; ++block) {
+    processor->run_without_inputs();
+    ref.run({}, want.data());
+    auto out = processor->output_block();
+    for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < B; ++i) {
+        worst = std::max(worst, std::fabs(double(out.read(c, i)) - double(want[c * B + i])));
+        peak = std::max(peak, std::fabs(double(want[c * B + i])));
+      }
+  }
+  std::printf("  FM cascades as graph voices: max |gpu - reference-shaped graph| = %.3g (peak %.3g)\n", worst, peak);
+  CHECK(worst <= 1e-5 * std::max(1.0, peak) && peak > 1e-3);
+}
 
 int main(int argc, char** argv) {
   bool plan = false, gpu = false;
@@ -570,6 +652,7 @@ int main(int argc, char** argv) {
     RUN(plan_groups_voices_by_chain_shape);
     RUN(plan_noise_sources_take_seeds_in_construction_order);
     RUN(plan_many_sines_with_pan2);
+    RUN(plan_voices_that_are_graphs);
     RUN(plan_rejects_what_is_not_a_voice_chain);
     RUN(time_and_seconds);
   }
@@ -582,6 +665,7 @@ int main(int argc, char** argv) {
     RUN(gpu_segment_envelopes_of_ragged_length);
     RUN(gpu_polyblep_delay_limiter_voices);
     RUN(gpu_many_sines_with_pan2);
+    RUN(gpu_voices_that_are_graphs);
   }
   std::printf("%s (%d failures)\n", g_fail ? "HOST MIRROR FAILED" : "HOST MIRROR PASSED", g_fail);
   return g_fail ? 1 : 0;

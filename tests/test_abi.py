@@ -47,9 +47,17 @@ def test_chain_validation_and_ugen_count(knh):
     with pytest.raises(L.KnasterHipError) as e:      # processor without a source
         knh.VoiceBank([Stage(L.STAGE_SVF)], 4)
     assert e.value.status == L.ERR_INVALID_ARGUMENT
-    with pytest.raises(L.KnasterHipError) as e:      # second plain source mid-chain
-        knh.VoiceBank([Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT)], 4)
-    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    # a second source mid-list starts a second signal of the voice (a graph, not a chain): accepted since ABI 2
+    knh.VoiceBank([Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MATH_MUL, input=1, input2=2)], 4).close()
+    for bad in ([Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MATH_MUL)],                    # operands not named
+                [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MUL_CONST, input=3)],                                   # reads a later stage
+                [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MUL_CONST, input2=1)],                                  # input2 on a unary stage
+                [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT, input=1)],                                      # a source reads nothing
+                [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL, input=1)]):              # a wrapper wraps its neighbour
+        with pytest.raises(L.KnasterHipError) as e:
+            knh.VoiceBank(bad, 4)
+        assert e.value.status == L.ERR_INVALID_ARGUMENT
+    assert knh.chain_ugen_count([Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MATH_MUL, input=1, input2=2)]) == 3
     # a valid chain without a pre-built kernel is accepted: it is fused at init time (hiprtc)
     knh.VoiceBank([Stage(L.STAGE_SIN_NUMERIC), Stage(L.STAGE_ONEPOLE_HPF), Stage(L.STAGE_ONEPOLE_LPF),
                    Stage(L.STAGE_DIV_CONST)], 4).close()

@@ -1,0 +1,157 @@
+"""Voices that are small graphs (DAGs) rather than chains on one running signal: a second source in the stage list, stages
+that name the signal they read (knh_stage_desc.input), MathUGen<_, U1, Op> of two signals (KNH_STAGE_MATH_*).  The oracle
+builds the same voice as the reference's graph API would (one node per UGen, connect / math_nodes); bar: bit-identical per
+voice for everything built from + - * and table lookups."""
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, fire_all, make_gpu, make_oracle
+from knaster_amd import _lib as L
+from knaster_amd import configs
+from knaster_amd.bank import Stage, TRIGGER
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(knh, oracle, w, blocks, events=None, tol=None):
+    g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    o = make_oracle(oracle, w)
+    peak = 0.0
+    for b in range(blocks):
+        if events:
+            events(b, g)
+            events(b, o)
+        g_out, g_voices, g_flags = g.process_block_voices()
+        o_out, o_voices, o_flags, o_done = o.process_block()
+        if tol is None:
+            assert_bit_equal(g_voices, o_voices, f"{w.name} block {b} per-voice")
+            assert_bit_equal(g_out, o_out, f"{w.name} block {b} left-fold mix")
+        else:
+            assert np.max(np.abs(g_voices.astype(np.float64) - o_voices)) <= tol
+        np.testing.assert_array_equal(g.read_done_frames(), o_done)
+        peak = max(peak, float(np.abs(o_voices).max()))
+    g.close()
+    o.close()
+    assert peak > 1e-3
+    return peak
+
+
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+@pytest.mark.parametrize("op", [L.STAGE_MATH_MUL, L.STAGE_MATH_ADD, L.STAGE_MATH_SUB])
+def test_two_oscillators_combined(knh, oracle, op, sample_type):
+    """`a * b`, `a + b`, `a - b` of two SinWt (graph_edit.rs:936-971): ring modulation and friends, 200 voices."""
+    n = 200
+    p = configs.voice_parameters(n)
+    w = configs.Workload("ab", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT), Stage(op, input=1, input2=2), Stage(L.STAGE_MUL_CONST)],
+                         n, 96, sample_type, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: (p["freq"] * p["fm_ratio"]).reshape(n, 1), 3: np.full((n, 1), 0.5 / n)}
+    run_pair(knh, oracle, w, 3)
+
+
+@pytest.mark.parametrize("depth,n_voices,block_size", [(4, 130, 32), (12, 64, 128), (24, 3, 16)])
+def test_fm_cascade_voice(knh, oracle, depth, n_voices, block_size):
+    """The reference's "FM cascade" bench shape (graph_dsp_performance.rs:37-72) as one graph-shaped voice per lane."""
+    w = configs.fm_cascade(depth, n_voices, block_size)
+    st = w.stages
+    assert knh.chain_ugen_count(st) == sum(2 if s.kind == L.STAGE_MUL_CONST else 1 for s in st)
+    run_pair(knh, oracle, w, 3)
+
+
+def test_one_signal_feeding_two_filters_and_an_envelope(knh, oracle):
+    """Fan-out: one oscillator through a low-pass and a high-pass side by side, their difference through an EnvAsr, with
+    parameter changes at the start of blocks and (WrPreciseTiming on the first filter) in the middle of them."""
+    n = 150
+    p = configs.voice_parameters(n)
+    st = [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL),                 # 1, 2: the oscillator (and its wrapper)
+          Stage(L.STAGE_SVF, delayed_changes_per_block=3),               # 3: low-pass of it
+          Stage(L.STAGE_ONEPOLE_HPF, input=2),                           # 4: high-pass of the same signal
+          Stage(L.STAGE_MATH_SUB, input=3, input2=4),                    # 5
+          Stage(L.STAGE_MUL_ENV_ASR),                                    # 6
+          Stage(L.STAGE_MATH_ADD, input=6, input2=2),                    # 7: plus the dry oscillator
+          Stage(L.STAGE_MUL_CONST)]                                      # 8
+    w = configs.Workload("fan", st, n, 64, L.F32, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.5), 2: np.stack([np.zeros(n), p["cutoff"], p["q"], np.zeros(n)], axis=1),
+              5: np.tile([0.002, 0.004], (n, 1)), 7: np.full((n, 1), 1.0 / n)}
+    v = np.arange(n, dtype=np.uint32)
+
+    def ev(block, bank):
+        if block == 0:
+            fire_all(bank, n, 5, 3)
+            bank.param_apply_many(v, 3, 0, L.VALUE_FLOAT, 300.0 + v)          # the high-pass cutoffs
+        if block == 1:
+            for voice in range(0, n, 7):
+                bank.set_delay_within_block_for_param(voice, 2, 0, 5 + voice % 50)
+                bank.param_apply(voice, 2, 0, 500.0 + 10.0 * voice)
+        if block == 2:
+            fire_all(bank, n, 5, 2)
+            bank.param_apply_many(v[::2], 0, 0, L.VALUE_FLOAT, 100.0 + v[::2])
+    run_pair(knh, oracle, w, 5, ev)
+
+
+def random_dag(rng, n_stages):
+    """A random feed-forward voice: sources, unary stages on any earlier signal, MathUGens of any two earlier signals."""
+    st, ctor = [], {}
+    for i in range(n_stages):
+        have = len(st)
+        r = rng.random()
+        pick = lambda: int(rng.integers(1, have + 1))
+        if have == 0 or r < 0.25:
+            st.append(Stage(L.STAGE_SIN_WT))
+            ctor[have] = [float(rng.uniform(50, 3000))]
+        elif r < 0.55 and have >= 2:
+            kind = [L.STAGE_MATH_MUL, L.STAGE_MATH_ADD, L.STAGE_MATH_SUB][int(rng.integers(0, 3))]
+            st.append(Stage(kind, input=pick(), input2=pick()))
+        else:
+            kind = [L.STAGE_MUL_CONST, L.STAGE_ADD_CONST, L.STAGE_SUB_CONST, L.STAGE_SVF, L.STAGE_ONEPOLE_LPF, L.STAGE_SAFETY_LIMITER,
+                    L.STAGE_MUL_ENV_AR][int(rng.integers(0, 7))]
+            inp = 0 if rng.random() < 0.5 else pick()
+            st.append(Stage(kind, input=inp))
+            if kind in (L.STAGE_MUL_CONST, L.STAGE_ADD_CONST, L.STAGE_SUB_CONST):
+                ctor[have] = [float(rng.uniform(-1.5, 1.5))]
+            elif kind == L.STAGE_SVF:
+                ctor[have] = [float(rng.integers(0, 6)), float(rng.uniform(200, 6000)), float(rng.uniform(0.5, 3.0)), 0.0]
+            elif kind == L.STAGE_ONEPOLE_LPF:
+                ctor[have] = [float(rng.uniform(200, 6000))]
+            elif kind == L.STAGE_MUL_ENV_AR:
+                ctor[have] = [float(rng.uniform(0.0005, 0.003)), float(rng.uniform(0.001, 0.01))]
+    st.append(Stage(L.STAGE_SAFETY_LIMITER))  # keeps a runaway product finite
+    return st, ctor
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_dag_voices_match_the_oracle(knh, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    st, ctor = random_dag(rng, int(rng.integers(4, 12)))
+    n = int(rng.integers(1, 140))
+    w = configs.Workload(f"dag{seed}", st, n, int(rng.choice([16, 48, 64, 100])), L.F32 if seed % 3 else L.F64, 1)
+    w.ctor = {s: np.tile(np.asarray(a, dtype=np.float64), (n, 1)) * (1.0 + 0.01 * np.arange(n)).reshape(n, 1) if st[s].kind == L.STAGE_SIN_WT
+              else np.tile(np.asarray(a, dtype=np.float64), (n, 1)) for s, a in ctor.items()}
+    envs = [i for i, s in enumerate(st) if s.kind == L.STAGE_MUL_ENV_AR]
+
+    def ev(block, bank):
+        if block in (0, 2):
+            for e in envs:
+                fire_all(bank, n, e, 2)
+    g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    o = make_oracle(oracle, w)
+    for b in range(4):
+        ev(b, g)
+        ev(b, o)
+        _, gv, _ = g.process_block_voices()
+        _, ov, _, od = o.process_block()
+        assert_bit_equal(gv, ov, f"seed {seed} block {b}")
+        np.testing.assert_array_equal(g.read_done_frames(), od)
+    g.close()
+    o.close()
+
+
+def test_division_and_power_of_two_signals(knh, oracle):
+    n = 64
+    st = [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT), Stage(L.STAGE_ADD_CONST),          # 3: b + 2 (never near zero)
+          Stage(L.STAGE_MATH_DIV, input=1, input2=3),                                        # 4: a / (b + 2): exact
+          Stage(L.STAGE_MATH_POW, input=3, input2=1)]                                        # 5: (b + 2) ^ a: device pow
+    w = configs.Workload("divpow", st, n, 64, L.F32, 1)
+    w.ctor = {0: np.linspace(100, 900, n).reshape(n, 1), 1: np.linspace(50, 450, n).reshape(n, 1), 2: np.full((n, 1), 2.0)}
+    run_pair(knh, oracle, w, 2, tol=2e-5)
+    w.stages = st[:4]
+    run_pair(knh, oracle, w, 2)

@@ -498,3 +498,49 @@ def test_fan_pipeline_with_sample_accurate_changes_equals_single_wave_kernel(knh
             assert_bit_equal(v0, v1, f"block_size {block_size}: per-voice")
             assert_bit_equal(o0, o1, f"block_size {block_size}: mix")
         assert np.abs(outs["1"][-1][0]).max() > 0
+
+
+@pytest.mark.parametrize("shards", [1, 8])
+def test_full_size_c4_f64_oracle_subset_and_sharded_sum(knh, oracle, shards):
+    """BASELINE.json config C4 at its full size: 65 536 voices, f64, block 512.  (a) 96 sampled voices equal the oracle run on
+    just those voices, bit for bit; (b) the mix equals the documented tree fold of the per-voice signals (bit for bit) and the
+    f64 sum within 1e-12; (c) split over eight voice ranges as an 8-GPU run splits it (8 192 voices each, here all on this
+    GPU through knh_bank_create_multi_device), the sum of the ranges' mixes equals the one-bank mix within 1e-12."""
+    w = configs.config("C4")
+    assert w.n_voices == 65536 and w.sample_type == L.F64
+    if shards == 1:
+        g = make_gpu(knh, w, L.MIX_TREE)
+        pick = np.unique(np.concatenate([np.arange(0, 32), np.arange(32767, 32799), np.arange(w.n_voices - 32, w.n_voices)]))
+        sub = configs.Workload("sub", w.stages, len(pick), w.block_size, w.sample_type, w.out_channels,
+                               {s: a[pick] for s, a in w.ctor.items()})
+        o = make_oracle(oracle, sub, want_mix=False)
+        for block in range(3):
+            for bank, n in ((g, w.n_voices), (o, len(pick))):
+                if block == 0:
+                    fire_all(bank, n, *w.restart)
+                if block == 2:
+                    fire_all(bank, n, w.release[0], w.release[1])
+            out, voices, _ = g.process_block_voices()
+            _, o_voices, _, _ = o.process_block()
+            assert_bit_equal(voices[pick], o_voices, f"block {block}: sampled voices vs oracle")
+            assert_bit_equal(out[0], tree_mix(voices), f"block {block}: tree mix")
+            assert_bit_equal(out[0], out[1], "L == R")
+            ref = voices.sum(axis=0)
+            assert np.max(np.abs(out[0] - ref)) <= 1e-12 and np.max(np.abs(ref)) > 1e-4
+        g.close()
+        o.close()
+    else:
+        one = make_gpu(knh, w, L.MIX_TREE)
+        many = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE, devices=[0] * shards)
+        for s, a in w.ctor.items():
+            many.set_ctor_args(s, a)
+        many.init(configs.SAMPLE_RATE, w.block_size)
+        assert many.ranks() == shards
+        for bank in (one, many):
+            fire_all(bank, w.n_voices, *w.restart)
+            bank.param_apply_many(np.arange(w.n_voices, dtype=np.uint32), w.release[0], w.release[1], L.VALUE_TRIGGER, block_offset=2)
+        a, _ = one.process_blocks(4)
+        b, _ = many.process_blocks(4)
+        assert np.max(np.abs(a - b)) <= 1e-12 and np.max(np.abs(a)) > 1e-4
+        one.close()
+        many.close()

@@ -19,7 +19,7 @@ def test_graph_api_plans_voice_banks(knh):
     res = subprocess.run([BIN, "--plan"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     for name in ("plan_readme_example", "plan_groups_voices_by_chain_shape", "plan_rejects_what_is_not_a_voice_chain", "time_and_seconds",
-                 "plan_noise_sources_take_seeds_in_construction_order", "plan_many_sines_with_pan2"):
+                 "plan_noise_sources_take_seeds_in_construction_order", "plan_many_sines_with_pan2", "plan_voices_that_are_graphs"):
         assert f"ok   {name}" in res.stdout
 
 
@@ -29,7 +29,7 @@ def test_graph_api_end_to_end_on_gpu(knh):
     res = subprocess.run([BIN, "--gpu"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     for name in ("gpu_readme_example", "gpu_voice_graph_matches_reference_shaped_graph", "gpu_run_blocks_equals_block_by_block",
-                 "gpu_heterogeneous_voices_mix_on_device", "gpu_many_sines_with_pan2"):
+                 "gpu_heterogeneous_voices_mix_on_device", "gpu_many_sines_with_pan2", "gpu_voices_that_are_graphs"):
         assert f"ok   {name}" in res.stdout
 
 
