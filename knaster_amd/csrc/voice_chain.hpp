@@ -1773,6 +1773,8 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   // applied, `sw` the tile-relative frame at which the voice takes them over (T: never), `touched` the slots its changes
   // address.  A stage none of whose slots is touched in the whole wave runs its ordinary tile code.
   template <int T> __device__ __forceinline__ void tick_tile_sw(const Chain& cn, u32 sw, u64 touched, F (&x)[T], const Ctx& c, u32 frame0) {
+    // (sample by sample in every stage, also those no change addresses: this path is rare, and the kernels are better off
+    // without a second, eight-sample copy of every stage's tile code -- the wavefronts of a pipeline share an instruction cache)
     bool hit = false;
     if constexpr (S0::kParamMask != 0u) hit = __builtin_amdgcn_ballot_w64((touched & kStageBits) != 0ull) != 0;
     if (hit) {
@@ -1782,7 +1784,8 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
         x[j] = S0::template tick<F, FMA>(r, x[j], c, frame0 + j, mark);
       }
     } else {
-      S0::template tick_tile<F, FMA, T>(r, x, c, frame0, mark);
+#pragma unroll
+      for (int j = 0; j < T; ++j) x[j] = S0::template tick<F, FMA>(r, x[j], c, frame0 + j, mark);
     }
     rest.template tick_tile_sw<T>(cn.rest, sw, touched, x, c, frame0);
   }

@@ -138,7 +138,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
   u32 base = 0;  // absolute frame of the current block's frame 0
   auto apply_events_upto = [&](u32 n_abs) {
-    while (next_frame <= n_abs) {
+    while (__builtin_expect(next_frame <= n_abs, 0)) {
       const u32 op = nxt.slot_op >> 24, slot = nxt.slot_op & 0xFFFFFFu;
       if (slot >= SLOT_LO && slot < SLOT_HI) {  // every group scans the list, the owner applies
         chain.on_event(op, slot, nxt.bits, nxt.frame - base);
@@ -202,7 +202,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
         constexpr int VW = EdgeLayout<F, T>::VW;
         F* out_tile = sh.edge + (long)(I * 2 + (FOLDS ? 0 : (g & 1))) * EdgeLayout<F, T>::tile;
         F* out_row = out_tile + (long)lane * EdgeLayout<F, T>::stride + fo;
-        if (m == (u32)TW && !__builtin_amdgcn_ballot_w64(ev_inside)) {
+        if (__builtin_expect(m == (u32)TW && !__builtin_amdgcn_ballot_w64(ev_inside), 1)) {  // (the cold paths out of line: one instruction cache for all roles)
           chain.template tick_tile<TW>(x, ctx, n);
 #ifdef KNH_DAG_STAMPS
           asm volatile("" ::: "memory");
@@ -216,7 +216,11 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
             for (int k = 0; k < VW; ++k) v[k] = x[j * VW + k];
             out[j] = v;
           }
+#ifdef KNH_AB_NO_SW
+        } else if (false && [&]() -> bool {
+#else
         } else if (m == (u32)TW && ChainT::kParamBits != 0ull && !ChainT::kBinds && [&]() -> bool {
+#endif
           // (groups that hold a delay line, a segment table or a buffer reader keep to the general path: their registers --
           // a prefetched tile of the ring among them -- are not worth copying for this)
           // Voices of the wave change PARAMETERS inside this tile (sample-accurate changes out of a WrPreciseTiming queue:
@@ -287,8 +291,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
           // Some voice of the wave has a change inside this tile (sample-accurate parameter changes, WrPreciseTiming), or
           // the tile is a partial one at the end of a block: it is walked eight samples at a time, row to row in LDS (a
           // run-time loop: the register tile above is never indexed by a run-time value, which would put all of it, the
-          // fast path's too, in scratch memory).  Eight samples in which no voice has a change run as a small tile, any
-          // others sample by sample with the changes applied in front of their frame.
+          // fast path's too, in scratch memory), sample by sample with the changes applied in front of their frame.
           const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride + fo;
           for (u32 j0 = 0; j0 < m; j0 += 8u) {
             const u32 cnt = m - j0 < 8u ? m - j0 : 8u;
@@ -304,16 +307,11 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
 #pragma unroll
               for (int k = 0; k < 8; ++k) sub[k] = (F)0;
             }
-            const bool ev_sub = next_frame < base + n + j0 + 8u;
-            if (cnt == 8u && !__builtin_amdgcn_ballot_w64(ev_sub)) {
-              chain.template tick_tile<8>(sub, ctx, n + j0);
-            } else {
 #pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                if ((u32)k < cnt) {
-                  apply_events_upto(base + n + j0 + (u32)k);
-                  sub[k] = chain.tick(sub[k], ctx, n + j0 + (u32)k);
-                }
+            for (int k = 0; k < 8; ++k) {
+              if ((u32)k < cnt) {
+                apply_events_upto(base + n + j0 + (u32)k);
+                sub[k] = chain.tick(sub[k], ctx, n + j0 + (u32)k);
               }
             }
 #pragma unroll
