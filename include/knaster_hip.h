@@ -144,7 +144,10 @@ typedef enum knh_value_kind {
  *     runs the device libm (tolerance only).  With these, with `input` on any other stage, and with source stages allowed
  *     anywhere in the list (each starts a new signal), a voice is a small feed-forward graph rather than a chain: the
  *     reference's "256 FM cascade" shape (knaster_benchmarks/benches/graph_dsp_performance.rs:37-72) is one.  Such voices
- *     run in the single-wave kernel form, fused at knh_bank_init time.
+ *     run in the single-wave kernel form, fused at knh_bank_init time: every stage unrolls into the one kernel, so a voice
+ *     may hold at most 512 stages (KNH_ERR_UNSUPPORTED_CHAIN beyond; 91 stages fuse in 2 s, 379 in a minute).  The
+ *     256-oscillator cascade itself (1 531 stages in ONE voice) is therefore out of reach; it is parallel in time, not in
+ *     voices, and wants a different mapping.
  * KNH_STAGE_PAN2            x >> g.push(Pan2::new(pan))         pan.rs:12-37         1    pan (-1 .. 1)
  *     mono -> stereo with the cos/sin pan law: the voice's signal times left_gain goes to graph out 0, times
  *     right_gain to graph out 1 (`(voice >> pan).to_graph_out()`, knaster/examples/many_sines.rs:51-63).  Must be the

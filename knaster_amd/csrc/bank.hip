@@ -79,12 +79,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
 };
 inline bool is_math2_kind(uint16_t kind) { return kind >= KNH_STAGE_MATH_ADD && kind <= KNH_STAGE_MATH_POW; }
 // A voice that is a graph rather than a chain: explicit operands, a MathUGen of two signals, or a second source.
-inline bool signature_is_dag(const std::string& sig) {
-  if (sig.find_first_of("@+-*/^") != std::string::npos) return true;
-  size_t sources = 0;
-  for (char c : sig) sources += std::strchr("WNPUKOGBF", c) != nullptr;
-  return sources > 1;
-}
+inline bool signature_is_dag(const std::string& sig) { return sig.find('@') != std::string::npos; }
 
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
@@ -1655,10 +1650,58 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if (st[i].kind == KNH_STAGE_PAN2 && i + 1 != n) { *why = "Pan2 ends the chain: it must be the last stage"; return KNH_ERR_INVALID_ARGUMENT; }
     if (st[i].kind == KNH_STAGE_PAN2 && st[i].delayed_changes_per_block > 0) { *why = "Pan2 cannot be wrapped in WrPreciseTiming here (its gains change at block boundaries)"; return KNH_ERR_INVALID_ARGUMENT; }
     sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
-    // explicit operands go into the signature (they are part of the kernel's type): "@a" / "@a,b", stage indices
-    if (math2) *sig += "@" + std::to_string(st[i].input - 1) + "," + std::to_string(st[i].input2 - 1);
-    else if (st[i].input != 0 && st[i].input != i) *sig += "@" + std::to_string(st[i].input - 1);
     have_x = true;
+  }
+  // A voice that is a graph (a stage that names its operands, a MathUGen of two signals, a second source): every stage is
+  // annotated "@a,b,o" with the SIGNAL SLOTS it reads and writes -- they are part of the kernel's type (knh_dev::At).  Slots
+  // are handed out like registers, a signal's slot free again after its last reader, so that a voice of a thousand stages
+  // (the reference's 256-oscillator FM cascade) keeps a handful of signals alive, not a thousand.
+  bool dag = false;
+  {
+    uint32_t sources = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
+      sources += std::strchr("WNPUKOGBF", kKinds[st[i].kind].sig) != nullptr && !ar;
+      dag = dag || is_math2_kind(st[i].kind) || (st[i].input != 0 && st[i].input != i);
+    }
+    dag = dag || sources > 1;
+  }
+  if (dag && n > 512) {
+    // every stage unrolls into the one kernel the voice is fused into: 91 stages build in 2 s, 379 in a minute, and the
+    // time grows faster than the count (the reference's 256-oscillator FM cascade, 1 531 stages, does not finish)
+    *why = "a voice that is a graph may hold at most 512 stages";
+    return KNH_ERR_UNSUPPORTED_CHAIN;
+  }
+  if (dag) {
+    std::vector<int> a(n, -1), b(n, -1), last_use(n, -1);
+    for (uint32_t i = 0; i < n; ++i) {
+      const bool reads = i > 0 && !(std::strchr("WNPUKOGBF", (*sig)[i]) != nullptr);  // 'R' reads, the plain sources do not
+      if (is_math2_kind(st[i].kind)) { a[i] = st[i].input - 1; b[i] = st[i].input2 - 1; }
+      else if (reads) a[i] = st[i].input ? st[i].input - 1 : static_cast<int>(i) - 1;
+      if (a[i] >= 0) last_use[a[i]] = static_cast<int>(i);
+      if (b[i] >= 0) last_use[b[i]] = static_cast<int>(i);
+    }
+    last_use[n - 1] = static_cast<int>(n);  // the voice's output
+    std::vector<int> slot(n, -1);
+    std::vector<char> busy;
+    std::string out;
+    for (uint32_t i = 0; i < n; ++i) {
+      const int sa = a[i] >= 0 ? slot[a[i]] : -1, sb = b[i] >= 0 ? slot[b[i]] : -1;
+      // operands whose last reader this is give their slot back first: the stage may then write where it read
+      if (a[i] >= 0 && last_use[a[i]] == static_cast<int>(i)) busy[sa] = 0;
+      if (b[i] >= 0 && last_use[b[i]] == static_cast<int>(i) && sb >= 0) busy[sb] = 0;
+      int o = -1;
+      if (sa >= 0 && !busy[sa] && !is_math2_kind(st[i].kind)) o = sa;  // in place, like a chain
+      for (size_t k = 0; o < 0 && k < busy.size(); ++k)
+        if (!busy[k]) o = static_cast<int>(k);
+      if (o < 0) { o = static_cast<int>(busy.size()); busy.push_back(0); }
+      if (last_use[i] >= 0) busy[o] = 1;  // (a signal nobody reads holds its slot only while it is written)
+      slot[i] = o;
+      out.push_back((*sig)[i]);
+      auto num = [](int v) { return v < 0 ? std::string("_") : std::to_string(v); };  // "_": none
+      out += "@" + num(sa) + "," + num(sb) + "," + num(o);
+    }
+    *sig = out + "#" + std::to_string(busy.size());  // "#R": the number of slots
   }
   return KNH_OK;
 }

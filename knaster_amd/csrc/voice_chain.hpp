@@ -1843,38 +1843,45 @@ struct Math2 : StageDefaults {
   template <typename F, bool FMA, int T> static __device__ __forceinline__ void tick_tile(Regs<F>&, F (&)[T], const Ctx&, u32, u32&) {}
   template <typename F> static __device__ __forceinline__ void on_event(Regs<F>&, u32, u32, u64, u32) {}
 };
-// a stage with explicit operands: A (and B for Math2) = the index of the stage whose output it reads, -1 = the stage before it
-template <typename S, int A = -1, int B = -1> struct At {};
-template <typename X> struct NodeOf { typedef X stage; static constexpr int a = -1, b = -1; static constexpr bool dag = X::kBinary; };
-template <typename S, int A, int B> struct NodeOf<At<S, A, B>> { typedef S stage; static constexpr int a = A, b = B; static constexpr bool dag = true; };
+// A stage of a graph-shaped voice: the signal slots it reads (A, and B for Math2; -1: none -- a source) and writes (O).
+// The host hands slots out like registers (bank.hip, build_signature): a slot is free again after its signal's last
+// reader, and a stage whose operand dies with it writes in place.  Slots<R> at the end of the list: how many there are.
+template <typename S, int A, int B, int O> struct At {};
+template <int R> struct Slots {};
+template <typename X> struct NodeOf { static constexpr bool dag = false; };
+template <typename S, int A, int B, int O> struct NodeOf<At<S, A, B, O>> { typedef S stage; static constexpr int a = A, b = B, o = O; static constexpr bool dag = true; };
+template <int R> struct NodeOf<Slots<R>> { static constexpr bool dag = true; };
 
-template <typename F, bool FMA, int K, int BASE, int N, typename... Ns> struct DagChain;
-template <typename F, bool FMA, int K, int BASE, int N>
-struct DagChain<F, FMA, K, BASE, N> {
+template <typename F, bool FMA, int BASE, int R, int LAST, typename... Ns> struct DagChain;
+// end of the list: Slots<R> (LAST = the slot of the last stage's output: the voice's signal)
+template <typename F, bool FMA, int BASE, int R, int LAST, int R2>
+struct DagChain<F, FMA, BASE, R, LAST, Slots<R2>> {
+  static_assert(R == R2, "the slot count is the list's last entry");
   static constexpr int kSlots = BASE;
   static constexpr bool kUsesSine = false;
   static constexpr bool kPan = false;
+  static constexpr int kOut = LAST;
   __device__ __forceinline__ void pan_gains(F&, F&) const {}
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
   template <typename W> __device__ __forceinline__ void store(W*, long) const {}
-  template <int T> __device__ __forceinline__ void run_tile(F (&)[N][T], const Ctx&, u32) {}
-  __device__ __forceinline__ void run_one(F (&)[N], const Ctx&, u32) {}
+  template <int T> __device__ __forceinline__ void run_tile(F (&)[R][T], const Ctx&, u32) {}
+  __device__ __forceinline__ void run_one(F (&)[R], const Ctx&, u32) {}
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
   __device__ __forceinline__ u32 collect_done(u32 acc) const { return acc; }
   __device__ __forceinline__ void begin_block(u32, const Ctx&) {}
 };
-template <typename F, bool FMA, int K, int BASE, int N, typename N0, typename... Rest>
-struct DagChain<F, FMA, K, BASE, N, N0, Rest...> {
+template <typename F, bool FMA, int BASE, int R, int LAST, typename N0, typename... Rest>
+struct DagChain<F, FMA, BASE, R, LAST, N0, Rest...> {
   typedef typename NodeOf<N0>::stage S0;
-  static constexpr int A = NodeOf<N0>::a >= 0 ? NodeOf<N0>::a : K - 1;  // -1 for the first stage: no input (a source)
-  static constexpr int B = NodeOf<N0>::b;
-  static_assert(A < K && B < K, "a stage reads the output of an earlier stage");
-  static_assert(!S0::kBinary || (A >= 0 && B >= 0), "a MathUGen of two signals names both");
-  typedef DagChain<F, FMA, K + 1, BASE + S0::kSlots, N, Rest...> RestT;
+  static constexpr int A = NodeOf<N0>::a, B = NodeOf<N0>::b, O = NodeOf<N0>::o;
+  static_assert(A < R && B < R && O >= 0 && O < R, "signal slots are 0 .. R-1");
+  static_assert(!S0::kBinary || (A >= 0 && B >= 0), "a MathUGen of two signals reads both");
+  typedef DagChain<F, FMA, BASE + S0::kSlots, R, O, Rest...> RestT;
   static constexpr int kSlots = RestT::kSlots;
   static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
   static constexpr bool kPan = IsPan<S0>::value || RestT::kPan;
+  static constexpr int kOut = RestT::kOut;
   typename S0::template Regs<F> r;
   u32 mark = 0xFFFFFFFFu;
   RestT rest;
@@ -1886,35 +1893,35 @@ struct DagChain<F, FMA, K, BASE, N, N0, Rest...> {
     S0::template store<F, W>(r, s + (long)BASE * stride, stride);
     rest.store(s, stride);
   }
-  template <int T> __device__ __forceinline__ void run_tile(F (&sig)[N][T], const Ctx& c, u32 frame0) {
+  template <int T> __device__ __forceinline__ void run_tile(F (&sig)[R][T], const Ctx& c, u32 frame0) {
     if constexpr (S0::kBinary) {
 #pragma unroll
-      for (int j = 0; j < T; ++j) sig[K][j] = S0::template apply<F>(sig[A][j], sig[B][j]);
+      for (int j = 0; j < T; ++j) sig[O][j] = S0::template apply<F>(sig[A][j], sig[B][j]);
     } else {
+      if constexpr (A != O) {
 #pragma unroll
-      for (int j = 0; j < T; ++j) sig[K][j] = A >= 0 ? sig[A >= 0 ? A : 0][j] : (F)0;
-      S0::template tick_tile<F, FMA, T>(r, sig[K], c, frame0, mark);
+        for (int j = 0; j < T; ++j) sig[O][j] = A >= 0 ? sig[A >= 0 ? A : 0][j] : (F)0;
+      }
+      S0::template tick_tile<F, FMA, T>(r, sig[O], c, frame0, mark);
     }
     rest.template run_tile<T>(sig, c, frame0);
   }
-  __device__ __forceinline__ void run_one(F (&sig)[N], const Ctx& c, u32 frame) {
-    if constexpr (S0::kBinary) sig[K] = S0::template apply<F>(sig[A], sig[B]);
-    else sig[K] = S0::template tick<F, FMA>(r, A >= 0 ? sig[A >= 0 ? A : 0] : (F)0, c, frame, mark);
+  __device__ __forceinline__ void run_one(F (&sig)[R], const Ctx& c, u32 frame) {
+    if constexpr (S0::kBinary) sig[O] = S0::template apply<F>(sig[A], sig[B]);
+    else sig[O] = S0::template tick<F, FMA>(r, A >= 0 ? sig[A >= 0 ? A : 0] : (F)0, c, frame, mark);
     rest.run_one(sig, c, frame);
   }
-  // the kernel's view: a voice's tile / sample is the last stage's signal (only called on the head of the list)
+  // the kernel's view: a voice's tile / sample is the last stage's signal (called on the head of the list)
   template <int T> __device__ __forceinline__ void tick_tile(F (&x)[T], const Ctx& c, u32 frame0) {
-    static_assert(K == 0, "tick_tile is the head's");
-    F sig[N][T];
+    F sig[R][T];
     run_tile<T>(sig, c, frame0);
 #pragma unroll
-    for (int j = 0; j < T; ++j) x[j] = sig[N - 1][j];
+    for (int j = 0; j < T; ++j) x[j] = sig[kOut][j];
   }
   __device__ __forceinline__ F tick(F, const Ctx& c, u32 frame) {
-    static_assert(K == 0, "tick is the head's");
-    F sig[N];
+    F sig[R];
     run_one(sig, c, frame);
-    return sig[N - 1];
+    return sig[kOut];
   }
   __device__ __forceinline__ u32 collect_done(u32 acc) const {
     if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
@@ -1938,9 +1945,13 @@ struct DagChain<F, FMA, K, BASE, N, N0, Rest...> {
     rest.begin_block(frame_begin, c);
   }
 };
-// the kernel's chain type: a plain chain unless some stage names its operands
+// the slot count of a graph-shaped stage list (its last entry), 0 for a plain chain
+template <typename... S> struct SlotCount { static constexpr int value = 0; };
+template <typename S0, typename... S> struct SlotCount<S0, S...> { static constexpr int value = SlotCount<S...>::value; };
+template <int R> struct SlotCount<Slots<R>> { static constexpr int value = R; };
+// the kernel's chain type: a plain chain unless the list is a graph's
 template <bool DAG, typename F, bool FMA, typename... S> struct ChainSelect { typedef Chain<F, FMA, 0, S...> type; };
-template <typename F, bool FMA, typename... S> struct ChainSelect<true, F, FMA, S...> { typedef DagChain<F, FMA, 0, 0, (int)sizeof...(S), S...> type; };
+template <typename F, bool FMA, typename... S> struct ChainSelect<true, F, FMA, S...> { typedef DagChain<F, FMA, 0, SlotCount<S...>::value, 0, S...> type; };
 
 // ---------------------------------------------------------------------------
 // Kernel arguments
@@ -1978,7 +1989,7 @@ constexpr int kTile = 8;  // samples evaluated stage-by-stage in registers
 // the bank has more 64-voice groups than the chip has SIMDs to give each its own (throughput regime).
 template <typename F, bool FMA, int WAVES, typename... S>
 __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a) {
-  typedef typename ChainSelect<(false || ... || NodeOf<S>::dag), F, FMA, S...>::type ChainT;
+  typedef typename ChainSelect<(SlotCount<S...>::value > 0), F, FMA, S...>::type ChainT;
   typedef typename WordOf<F>::type W;
   // frames per reduce tile: sized so that WAVES tiles + the sine table fit the CU's 160 KiB of LDS
   constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 8 ? 2 : 1);

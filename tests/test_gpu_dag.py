@@ -155,3 +155,13 @@ def test_division_and_power_of_two_signals(knh, oracle):
     run_pair(knh, oracle, w, 2, tol=2e-5)
     w.stages = st[:4]
     run_pair(knh, oracle, w, 2)
+
+
+def test_graph_voices_have_a_stage_limit(knh):
+    """Every stage of a graph-shaped voice unrolls into its kernel: the build time grows faster than the stage count, so the
+    library refuses more than 512 stages (the reference's 256-oscillator cascade as one voice has 1 531) instead of hanging."""
+    w = configs.fm_cascade(256, 1, 128)
+    assert len(w.stages) == 1531
+    with pytest.raises(L.KnasterHipError) as e:
+        knh.VoiceBank(w.stages, 1, L.F32, 1)
+    assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
