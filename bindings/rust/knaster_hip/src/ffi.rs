@@ -40,6 +40,8 @@ pub struct knh_bank_desc {
     pub mix_mode: u32,
     pub device: i32,
     pub allow_fma: u32,
+    /// UGen::Inputs of the bank node: channels the voices read through KNH_STAGE_INPUT stages
+    pub in_channels: u32,
 }
 
 pub const KNH_ABI_VERSION: u32 = 2;
@@ -104,7 +106,8 @@ pub const KNH_STAGE_MATH_SUB: u16 = 34;
 pub const KNH_STAGE_MATH_MUL: u16 = 35;
 pub const KNH_STAGE_MATH_DIV: u16 = 36;
 pub const KNH_STAGE_MATH_POW: u16 = 37;
-pub const KNH_STAGE_KIND_COUNT: u16 = 38;
+pub const KNH_STAGE_INPUT: u16 = 38;
+pub const KNH_STAGE_KIND_COUNT: u16 = 39;
 
 // knh_svf_type = SvfFilterType, knaster_core_dsp/src/ugens/svf.rs:19-39
 pub const KNH_SVF_LOW: u32 = 0;
@@ -164,6 +167,8 @@ unsafe extern "C" {
     pub fn knh_bank_timing_read(bank: *mut knh_bank, kernel_ms: *mut f64, launches: *mut u64) -> i32;
     pub fn knh_bank_algorithmic_bytes_per_voice_block(bank: *const knh_bank, read_bytes: *mut u32, write_bytes: *mut u32) -> i32;
     // several GPUs of one node: one process owning them all, or one process per GPU with an RCCL reduce
+    pub fn knh_bank_set_input(bank: *mut knh_bank, n_blocks: u32, input: *const c_void) -> i32;
+    pub fn knh_bank_set_input_device(bank: *mut knh_bank, n_blocks: u32, in_device: *const c_void) -> i32;
     pub fn knh_bank_create_multi_device(desc: *const knh_bank_desc, devices: *const i32, n_devices: u32, out_bank: *mut *mut knh_bank) -> i32;
     pub fn knh_comm_unique_id(id: *mut u8) -> i32;
     pub fn knh_bank_create_rank(desc: *const knh_bank_desc, rank: u32, world: u32, comm_id: *const u8, out_bank: *mut *mut knh_bank) -> i32;

@@ -130,6 +130,7 @@ impl<F: Float> GpuVoiceBank<F> {
             mix_mode: KNH_MIX_TREE,
             device: -1,
             allow_fma: 0,
+            in_channels: 0,
         };
         let mut h = core::ptr::null_mut();
         if unsafe { knh_bank_create_sharded(&desc, host_threads, &mut h) } != KNH_OK {

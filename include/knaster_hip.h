@@ -148,6 +148,12 @@ typedef enum knh_value_kind {
  *     may hold at most 512 stages (KNH_ERR_UNSUPPORTED_CHAIN beyond; 91 stages fuse in 2 s, 379 in a minute).  The
  *     256-oscillator cascade itself (1 531 stages in ONE voice) is therefore out of reach; it is parallel in time, not in
  *     voices, and wants a different mapping.
+ * KNH_STAGE_INPUT           (graph input) >> ...   the bank NODE's input channel `channel`: UGen::Inputs > 0,
+ *                           `input.read(channel, frame)` in process_block (ugen.rs:263-284)               0    channel
+ *     a source whose signal is the same for every voice: whatever the host graph connected to that input of the bank
+ *     (another node's output feeding every voice's filter; or, with KNH_STAGE_FLAG_AR_FREQ on a following SIN_WT behind
+ *     e.g. a MUL_CONST, the buffer UGen::set_ar_param_buffer hands over, ugen.rs:309-329).  knh_bank_desc.in_channels says
+ *     how many there are; the samples of the next launch come from knh_bank_set_input[_device].  No parameters.
  * KNH_STAGE_PAN2            x >> g.push(Pan2::new(pan))         pan.rs:12-37         1    pan (-1 .. 1)
  *     mono -> stereo with the cos/sin pan law: the voice's signal times left_gain goes to graph out 0, times
  *     right_gain to graph out 1 (`(voice >> pan).to_graph_out()`, knaster/examples/many_sines.rs:51-63).  Must be the
@@ -199,7 +205,8 @@ typedef enum knh_stage_kind {
   KNH_STAGE_MATH_MUL = 35,
   KNH_STAGE_MATH_DIV = 36,
   KNH_STAGE_MATH_POW = 37,
-  KNH_STAGE_KIND_COUNT = 38
+  KNH_STAGE_INPUT = 38,
+  KNH_STAGE_KIND_COUNT = 39
 } knh_stage_kind;
 
 /* SvfFilterType: knaster_core_dsp/src/ugens/svf.rs:19-39 (out-of-range -> Low,
@@ -266,6 +273,8 @@ typedef struct knh_bank_desc {
    * the reference's scalar code.  1 = allow fused multiply-add (faster, last-bit
    * differences). */
   uint32_t allow_fma;
+  /* UGen::Inputs of the bank node (0 .. 16): input channels every voice can read through KNH_STAGE_INPUT stages. */
+  uint32_t in_channels;
 } knh_bank_desc;
 
 typedef struct knh_bank knh_bank;
@@ -366,6 +375,12 @@ int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t 
 int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process,
                                       size_t block_start_offset, uint64_t frame_clock,
                                       void* out_device, void* hip_stream);
+/* The input block(s) of the bank node for the NEXT process call: `in` = host [n_blocks][in_channels][block_size] of F,
+ * channel-major per block like the output (what Task::run hands a node as its input channels,
+ * knaster_graph/src/task.rs:17-32); copied.  Needed before every process call of a bank with KNH_STAGE_INPUT stages;
+ * n_blocks must match that call.  The _device form takes device memory of the same layout, read in stream order. */
+int32_t knh_bank_set_input(knh_bank* bank, uint32_t n_blocks, const void* in);
+int32_t knh_bank_set_input_device(knh_bank* bank, uint32_t n_blocks, const void* in_device);
 /* Parity/debug: also materialise every voice's own signal,
  * voices_out = host [n_voices][block_size] of F ([2][n_voices][block_size] for a chain that ends in
  * KNH_STAGE_PAN2: every voice's left signals, then every voice's right signals).  `out` may be NULL. */

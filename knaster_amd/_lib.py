@@ -26,7 +26,7 @@ VALUE_FLOAT, VALUE_TRIGGER, VALUE_INTEGER, VALUE_BOOL, VALUE_SMOOTHING = 0, 1, 2
  STAGE_WR_ADD, STAGE_WR_SUB, STAGE_MUL_ENVELOPE, STAGE_WR_VSUB, STAGE_WR_DIV, STAGE_WR_VDIV, STAGE_WR_POWF,
  STAGE_WR_POWI, STAGE_POW_CONST, STAGE_SAMPLE_DELAY, STAGE_PHASOR, STAGE_SAFETY_LIMITER, STAGE_POLYBLEP, STAGE_ALLPASS_DELAY, STAGE_ALLPASS_FB_DELAY, STAGE_BUFFER_READER,
  STAGE_WHITE_NOISE, STAGE_PINK_NOISE, STAGE_BROWN_NOISE, STAGE_RANDOM_LIN, STAGE_PAN2,
- STAGE_MATH_ADD, STAGE_MATH_SUB, STAGE_MATH_MUL, STAGE_MATH_DIV, STAGE_MATH_POW) = range(38)
+ STAGE_MATH_ADD, STAGE_MATH_SUB, STAGE_MATH_MUL, STAGE_MATH_DIV, STAGE_MATH_POW, STAGE_INPUT) = range(39)
 STAGE_FLAG_AR_FREQ = 1
 STAGE_FLAG_SMOOTH_PARAMS = 2
 # knh_svf_type
@@ -42,7 +42,7 @@ STAGE_CTOR_ARGS = {  # STAGE_MUL_ENVELOPE takes 4 + 2 * n_max (variable)
     STAGE_DIV_CONST: 1, STAGE_WR_MUL: 1, STAGE_WR_ADD: 1, STAGE_WR_SUB: 1,
     STAGE_WR_VSUB: 1, STAGE_WR_DIV: 1, STAGE_WR_VDIV: 1, STAGE_WR_POWF: 1, STAGE_WR_POWI: 1, STAGE_POW_CONST: 1, STAGE_SAMPLE_DELAY: 1, STAGE_PHASOR: 1, STAGE_SAFETY_LIMITER: 0, STAGE_POLYBLEP: 2, STAGE_ALLPASS_DELAY: 1, STAGE_ALLPASS_FB_DELAY: 1, STAGE_BUFFER_READER: 3,
     STAGE_WHITE_NOISE: 1, STAGE_PINK_NOISE: 1, STAGE_BROWN_NOISE: 1, STAGE_RANDOM_LIN: 2, STAGE_PAN2: 1,
-    STAGE_MATH_ADD: 0, STAGE_MATH_SUB: 0, STAGE_MATH_MUL: 0, STAGE_MATH_DIV: 0, STAGE_MATH_POW: 0,
+    STAGE_MATH_ADD: 0, STAGE_MATH_SUB: 0, STAGE_MATH_MUL: 0, STAGE_MATH_DIV: 0, STAGE_MATH_POW: 0, STAGE_INPUT: 1,
 }
 
 
@@ -54,7 +54,7 @@ class StageDesc(C.Structure):
 class BankDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_voices", C.c_uint32), ("sample_type", C.c_uint32),
                 ("n_stages", C.c_uint32), ("stages", C.POINTER(StageDesc)), ("out_channels", C.c_uint32),
-                ("mix_mode", C.c_uint32), ("device", C.c_int32), ("allow_fma", C.c_uint32)]
+                ("mix_mode", C.c_uint32), ("device", C.c_int32), ("allow_fma", C.c_uint32), ("in_channels", C.c_uint32)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/knaster_hip.h
@@ -102,6 +102,8 @@ COMM_ID_BYTES = 128
 # knh_reduce_fn: int32 (*)(void* user, void* device_buf, size_t count, uint32 sample_type, uint32 root, void* hip_stream)
 REDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
 PROTOTYPES.update({
+    "knh_bank_set_input": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "knh_bank_set_input_device": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "knh_bank_create_multi_device": (C.c_int32, [C.POINTER(BankDesc), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]),
     "knh_comm_unique_id": (C.c_int32, [C.c_void_p]),
     "knh_bank_create_rank": (C.c_int32, [C.POINTER(BankDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),

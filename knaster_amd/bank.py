@@ -64,7 +64,7 @@ class VoiceBank:
     def __init__(self, stages: Sequence[Stage], n_voices: int, sample_type: int = L.F32, out_channels: int = 2,
                  mix_mode: int = L.MIX_TREE, device: int = -1, allow_fma: bool = False, host_threads: int = 0,
                  devices: Optional[Sequence[int]] = None, rank: Optional[int] = None, world: int = 1,
-                 comm_id: Optional[bytes] = None, reduce_fn=None):
+                 comm_id: Optional[bytes] = None, reduce_fn=None, in_channels: int = 0):
         """devices=[..]: one process, voice ranges on several GPUs (knh_bank_create_multi_device).
         rank/world (+ comm_id from comm_unique_id(), or reduce_fn): one process per GPU, n_voices is the TOTAL
         (knh_bank_create_rank / _custom).  Voice indices are global in both."""
@@ -75,8 +75,9 @@ class VoiceBank:
         self.dtype = np.float64 if sample_type == L.F64 else np.float32
         self.out_channels = out_channels
         self._stage_arr = _stage_array(self.stages)
+        self.in_channels = int(in_channels)
         desc = L.BankDesc(L.KNH_ABI_VERSION, self.n_voices, sample_type, len(self.stages), self._stage_arr,
-                          out_channels, mix_mode, device, 1 if allow_fma else 0)
+                          out_channels, mix_mode, device, 1 if allow_fma else 0, self.in_channels)
         h = C.c_void_p()
         self._keep = None
         if devices is not None:
@@ -205,6 +206,15 @@ class VoiceBank:
             self._check(self._lib.knh_bank_param_apply_many_at(self._h, block_offset, n, *ptrs))
         else:
             self._check(self._lib.knh_bank_param_apply_many(self._h, n, *ptrs))
+
+    def set_input(self, blocks):
+        """The bank node's input block(s) for the next process call: [n_blocks, in_channels, block_size] (or one block
+        [in_channels, block_size]) -- knh_bank_set_input."""
+        a = np.ascontiguousarray(np.asarray(blocks, dtype=self.dtype))
+        if a.ndim == 2:
+            a = a.reshape(1, *a.shape)
+        assert a.shape[1:] == (self.in_channels, self.block_size), a.shape
+        self._check(self._lib.knh_bank_set_input(self._h, a.shape[0], a.ctypes.data_as(C.c_void_p)))
 
     def process_block(self, frames_to_process: Optional[int] = None, block_start_offset: int = 0, frame_clock: int = 0,
                       out: Optional[np.ndarray] = None):

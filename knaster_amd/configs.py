@@ -69,6 +69,7 @@ class Workload:
     description: str = ""
     delay_times: np.ndarray = None  # D3: per-voice SampleDelay delay_time set before block 0 (stage 3, param 0)
     buffer: tuple = None  # (stage, samples, sample_rate): the Buffer of a BufferReader stage
+    in_channels: int = 0  # UGen::Inputs of the bank node (KNH_STAGE_INPUT stages read them)
 
 
 def config(name: str, n_voices: int | None = None, block_size: int | None = None, sample_type: int | None = None,

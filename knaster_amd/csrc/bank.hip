@@ -76,6 +76,7 @@ const KindInfo kKinds[KNH_STAGE_KIND_COUNT] = {
     /* MATH_MUL    */ {0, 0, 0, 1, '*', {nullptr}},
     /* MATH_DIV    */ {0, 0, 0, 1, '/', {nullptr}},
     /* MATH_POW    */ {0, 0, 0, 1, '^', {nullptr}},
+    /* INPUT       */ {1, 0, 1, 0, 'I', {nullptr}},
 };
 inline bool is_math2_kind(uint16_t kind) { return kind >= KNH_STAGE_MATH_ADD && kind <= KNH_STAGE_MATH_POW; }
 // A voice that is a graph rather than a chain: explicit operands, a MathUGen of two signals, or a second source.
@@ -277,6 +278,8 @@ struct knh_bank {
     }
     return rc;
   }
+  // the bank node's input block(s) for the next process call (host memory: copied; or device memory)
+  virtual int set_input(uint32_t n_blocks, const void* host, const void* dev) = 0;
   virtual int read_done_frames(uint32_t* out) = 0;
   virtual int synchronize() = 0;
   virtual int debug_read(uint32_t* out16) = 0;
@@ -427,10 +430,10 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
-    void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out};
+    void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out, h_input};
     for (void* p : host_ptrs)
       if (p) (void)hipHostFree(p);
     for (hipEvent_t e : list_done)
@@ -464,6 +467,39 @@ struct Bank final : knh_bank {
     if (!samples || n_frames == 0 || n_frames >= (1ull << 31) || !(sr > 0.0)) return fail(KNH_ERR_INVALID_ARGUMENT, "empty buffer or bad sample rate");
     h_buffer.assign(static_cast<const F*>(samples), static_cast<const F*>(samples) + n_frames);
     buffer_sr = sr;
+    return KNH_OK;
+  }
+
+  // the bank node's input channels for the next launch
+  F* d_input = nullptr;           // [in_blocks_cap][in_channels][block_size]
+  F* h_input = nullptr;           // pinned staging of the same
+  uint32_t in_blocks_cap = 0, in_blocks_set = 0;
+  const void* in_device = nullptr;  // set_input_device: read where it is
+  bool in_host_pending = false;
+  bool uses_input = false;
+  int set_input(uint32_t n_blocks, const void* host, const void* dev) override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    if (desc.in_channels == 0) return fail(KNH_ERR_INVALID_ARGUMENT, "the bank has no input channels (knh_bank_desc.in_channels)");
+    if (n_blocks == 0 || n_blocks > 4096 || (!host && !dev)) return fail(KNH_ERR_INVALID_ARGUMENT, "knh_bank_set_input: n_blocks in 1..4096 and a buffer");
+    KNH_HIP(hipSetDevice(device));
+    in_blocks_set = n_blocks;
+    in_device = dev;
+    in_host_pending = false;
+    if (dev) return KNH_OK;
+    const size_t elems = static_cast<size_t>(n_blocks) * desc.in_channels * block_size;
+    if (n_blocks > in_blocks_cap) {
+      KNH_HIP(hipDeviceSynchronize());
+      if (d_input) KNH_HIP(hipFree(d_input));
+      if (h_input) KNH_HIP(hipHostFree(h_input));
+      d_input = nullptr; h_input = nullptr;
+      KNH_HIP(hipMalloc(&d_input, elems * sizeof(F)));
+      KNH_HIP(hipHostMalloc(&h_input, elems * sizeof(F)));
+      in_blocks_cap = n_blocks;
+    } else {
+      KNH_HIP(hipStreamSynchronize(own_stream));  // the copy of the launch before may still be reading the staging buffer
+    }
+    std::memcpy(h_input, host, elems * sizeof(F));
+    in_host_pending = true;
     return KNH_OK;
   }
 
@@ -630,6 +666,11 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 3, v) = static_cast<W>(static_cast<uint32_t>(sb >> 32));
           } break;
           case KNH_STAGE_SAFETY_LIMITER: break;
+          case KNH_STAGE_INPUT: {
+            uses_input = true;
+            if (!(a[0] >= 0.0) || a[0] >= static_cast<double>(desc.in_channels)) return fail(KNH_ERR_INVALID_ARGUMENT, "KNH_STAGE_INPUT: channel is not below knh_bank_desc.in_channels");
+            slot(S.slot_base, v) = static_cast<W>(static_cast<uint32_t>(a[0]));
+          } break;
           case KNH_STAGE_MATH_ADD: case KNH_STAGE_MATH_SUB: case KNH_STAGE_MATH_MUL: case KNH_STAGE_MATH_DIV: case KNH_STAGE_MATH_POW: break;  // no state
           case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: {
             // fastrand::Rng::with_seed(next_randomness_seed()) (noise.rs:34,66,134): the state is the seed
@@ -1474,6 +1515,20 @@ struct Bank final : knh_bank {
     a.delay_stride = delay_stride;
     a.buffer = d_buffer;
     a.buffer_frames = static_cast<uint32_t>(h_buffer.size());
+    a.input = nullptr;
+    a.in_channels = desc.in_channels;
+    if (uses_input) {
+      if (in_blocks_set != n_blocks) return fail(KNH_ERR_INVALID_ARGUMENT, "a bank with KNH_STAGE_INPUT stages needs knh_bank_set_input for exactly the blocks of this call");
+      if (in_device) {
+        a.input = in_device;
+      } else {
+        if (in_host_pending)
+          KNH_HIP(hipMemcpyAsync(d_input, h_input, static_cast<size_t>(n_blocks) * desc.in_channels * block_size * sizeof(F), hipMemcpyHostToDevice, s));
+        in_host_pending = false;
+        a.input = d_input;
+      }
+      in_blocks_set = 0;  // one set_input per process call
+    }
     a.ev_start = have_events ? h_ev_start : nullptr;  // pinned host memory, device-visible
     a.events = h_events;
     a.partials = d_partials;
@@ -1627,7 +1682,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     const bool source = st[i].kind == KNH_STAGE_SIN_WT || st[i].kind == KNH_STAGE_SIN_NUMERIC || st[i].kind == KNH_STAGE_PHASOR ||
                         st[i].kind == KNH_STAGE_WHITE_NOISE || st[i].kind == KNH_STAGE_PINK_NOISE || st[i].kind == KNH_STAGE_BROWN_NOISE ||
                         st[i].kind == KNH_STAGE_RANDOM_LIN ||
-                        st[i].kind == KNH_STAGE_POLYBLEP || st[i].kind == KNH_STAGE_BUFFER_READER;
+                        st[i].kind == KNH_STAGE_POLYBLEP || st[i].kind == KNH_STAGE_BUFFER_READER || st[i].kind == KNH_STAGE_INPUT;
     const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
     const bool math2 = is_math2_kind(st[i].kind);
     if (st[i].flags & ~(KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "unknown stage flag"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1661,7 +1716,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     uint32_t sources = 0;
     for (uint32_t i = 0; i < n; ++i) {
       const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
-      sources += std::strchr("WNPUKOGBF", kKinds[st[i].kind].sig) != nullptr && !ar;
+      sources += std::strchr("WNPUKOGBFI", kKinds[st[i].kind].sig) != nullptr && !ar;
       dag = dag || is_math2_kind(st[i].kind) || (st[i].input != 0 && st[i].input != i);
     }
     dag = dag || sources > 1;
@@ -1675,7 +1730,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
   if (dag) {
     std::vector<int> a(n, -1), b(n, -1), last_use(n, -1);
     for (uint32_t i = 0; i < n; ++i) {
-      const bool reads = i > 0 && !(std::strchr("WNPUKOGBF", (*sig)[i]) != nullptr);  // 'R' reads, the plain sources do not
+      const bool reads = i > 0 && !(std::strchr("WNPUKOGBFI", (*sig)[i]) != nullptr);  // 'R' reads, the plain sources do not
       if (is_math2_kind(st[i].kind)) { a[i] = st[i].input - 1; b[i] = st[i].input2 - 1; }
       else if (reads) a[i] = st[i].input ? st[i].input - 1 : static_cast<int>(i) - 1;
       if (a[i] >= 0) last_use[a[i]] = static_cast<int>(i);
@@ -1879,6 +1934,7 @@ static int32_t check_desc(const knh_bank_desc* desc, knh_bank** out_bank, std::s
   if (desc->sample_type > KNH_F64) { g_create_error = "unknown sample type"; return KNH_ERR_INVALID_ARGUMENT; }
   if (desc->out_channels < 1 || desc->out_channels > 2) { g_create_error = "out_channels must be 1 or 2"; return KNH_ERR_INVALID_ARGUMENT; }
   if (desc->mix_mode > KNH_MIX_LEFT_FOLD) { g_create_error = "unknown mix mode"; return KNH_ERR_INVALID_ARGUMENT; }
+  if (desc->in_channels > 16) { g_create_error = "in_channels must be at most 16"; return KNH_ERR_INVALID_ARGUMENT; }
   std::string why;
   int rc = build_signature(desc->stages, desc->n_stages, sig, &why);
   if (rc != KNH_OK) { g_create_error = why; return rc; }
@@ -1930,18 +1986,10 @@ int32_t knh_bank_create_rank_custom(const knh_bank_desc* desc, uint32_t rank, ui
 uint32_t knh_bank_ranks(const knh_bank* bank) { return bank ? bank->ranks() : 0; }
 
 static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank) {
-  if (out_bank) *out_bank = nullptr;
-  if (!desc || !out_bank) { g_create_error = "null argument"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->abi_version != KNH_ABI_VERSION) { g_create_error = "ABI version mismatch"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->n_voices == 0 || !desc->stages) { g_create_error = "n_voices must be > 0 and stages non-null"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->sample_type > KNH_F64) { g_create_error = "unknown sample type"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->out_channels < 1 || desc->out_channels > 2) { g_create_error = "out_channels must be 1 or 2"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->mix_mode > KNH_MIX_LEFT_FOLD) { g_create_error = "unknown mix mode"; return KNH_ERR_INVALID_ARGUMENT; }
+  std::string sig;
+  int rc = check_desc(desc, out_bank, &sig);
+  if (rc != KNH_OK) return rc;
   if (host_threads > 64) { g_create_error = "host_threads must be at most 64"; return KNH_ERR_INVALID_ARGUMENT; }
-  std::string sig, why;
-  int rc = build_signature(desc->stages, desc->n_stages, &sig, &why);
-  if (rc != KNH_OK) { g_create_error = why; return rc; }
-  if (desc->stages[desc->n_stages - 1].kind == KNH_STAGE_PAN2 && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
   // a chain without a pre-built kernel is fused at knh_bank_init time (hiprtc); entry == nullptr marks it
   const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
   // the reference's exact mix order (KNH_MIX_LEFT_FOLD) and banks of a single voice group keep one range
@@ -1977,7 +2025,17 @@ int32_t knh_bank_init(knh_bank* bank, uint32_t sample_rate, size_t block_size) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   return bank->init(sample_rate, block_size);
 }
-uint16_t knh_bank_inputs(const knh_bank*) { return 0; }
+uint16_t knh_bank_inputs(const knh_bank* bank) { return bank ? static_cast<uint16_t>(bank->desc.in_channels) : 0; }
+int32_t knh_bank_set_input(knh_bank* bank, uint32_t n_blocks, const void* in) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (!in) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null input");
+  return bank->set_input(n_blocks, in, nullptr);
+}
+int32_t knh_bank_set_input_device(knh_bank* bank, uint32_t n_blocks, const void* in_device) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (!in_device) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null input");
+  return bank->set_input(n_blocks, nullptr, in_device);
+}
 uint16_t knh_bank_outputs(const knh_bank* bank) { return bank ? static_cast<uint16_t>(bank->desc.out_channels) : 0; }
 uint16_t knh_bank_stage_parameters(const knh_bank* bank, uint32_t stage) {
   if (!bank || stage >= bank->stages.size()) return 0;

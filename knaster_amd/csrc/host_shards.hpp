@@ -92,6 +92,16 @@ struct ShardedBank final : knh_bank {
     }
     return KNH_OK;
   }
+  int set_input(uint32_t n_blocks, const void* host, const void* dev) override {  // every range reads the same input block(s)
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    if (dev && multi_device()) return fail(KNH_ERR_INVALID_ARGUMENT, "a bank on several GPUs takes its input from host memory");
+    for (int k = 0; k < n(); ++k) {
+      int rc = shard[k]->set_input(n_blocks, host, dev);
+      if (rc != KNH_OK) return adopt(k, rc);
+    }
+    KNH_HIP(hipSetDevice(device));
+    return KNH_OK;
+  }
   int init(uint32_t sr, size_t bs) override {
     if (initialised) return fail(KNH_ERR_INVALID_ARGUMENT, "already initialised");
     for (int k = 0; k < n(); ++k) {  // one after the other: a run-time fused kernel is compiled once and found in the cache by the rest

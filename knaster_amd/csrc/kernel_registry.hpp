@@ -3,7 +3,7 @@
 // Signature: one character per device stage, in chain order:
 //   W SinWt   R SinWt.ar_params() driven by the running signal   N SinNumeric
 //   S SvfFilter   L OnePoleLpf   H OnePoleHpf   A x*EnvAsr   E x*EnvAr   V x*Envelope (segments)   D SampleDelay   P Phasor   X SafetyLimiter   B PolyBlep   Y AllpassDelay   Z AllpassFeedbackDelay   F BufferReader   U WhiteNoise   K PinkNoise   O BrownNoise   G RandomLin
-//   J Pan2 (last stage only: two output channels)
+//   J Pan2 (last stage only: two output channels)   I an input channel of the bank node (a source shared by all voices)
 //   + - * / ^  MathUGen of two signals; "@a" / "@a,b" after a stage: the stage(s) whose output it reads, when not the one before it
 //   m x*value   a x+value   s x-value   d x/value   v value-x   q value/x   p x.powf(value)   i x.powi(n)
 #pragma once

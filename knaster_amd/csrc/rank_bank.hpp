@@ -67,6 +67,10 @@ struct RankBank final : knh_bank {
   int set_buffer(uint32_t stage, const void* samples, size_t n_frames, double sr) override {
     return local ? adopt(local->set_buffer(stage, samples, n_frames, sr)) : KNH_OK;
   }
+  int set_input(uint32_t n_blocks, const void* host, const void* dev) override {  // every rank is handed the same input block(s)
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    return local ? adopt(local->set_input(n_blocks, host, dev)) : KNH_OK;
+  }
   int init(uint32_t sr, size_t bs) override {
     if (initialised) return fail(KNH_ERR_INVALID_ARGUMENT, "already initialised");
     if (knh_device_count() <= 0) return fail(KNH_ERR_NO_DEVICE, "no gfx950 device visible; this engine has no CPU path");

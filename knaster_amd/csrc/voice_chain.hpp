@@ -87,6 +87,8 @@ struct Ctx {
   u32 delay_stride;
   const void* buffer;       // BufferReader: the bank's shared single-channel Buffer, samples of F
   u32 buffer_frames;
+  const void* input_block;  // the bank node's input channels for the block being processed: [in_channels][in_stride] of F
+  u32 in_stride;            // = block_size
 };
 
 // ---------------------------------------------------------------------------
@@ -392,6 +394,31 @@ struct PinkNoise : StageDefaults {
       for (int k = 0; k < 9; ++k) r.white[k] = rel == (u32)(5 + k) ? v : r.white[k];
     }
   }
+};
+
+// One input channel of the bank NODE (UGen::Inputs > 0, ugen.rs:232-284: `input.read(channel, frame)`; also what an
+// audio-rate parameter buffer, ugen.rs:309-329, amounts to): a source whose signal is the same for every voice -- whatever
+// the host graph connected to that input.  slot 0: the channel.
+struct InputCh : StageDefaults {
+  static constexpr int kSlots = 1;
+  static constexpr u32 kMutableMask = 0u;
+  static constexpr bool kUsesSine = false;
+  static constexpr bool kIsEnv = false;
+  static constexpr bool kNeedsBind = false;
+  static constexpr bool kHasSeg = false;
+  template <typename F> struct Regs { u32 ch; };
+  template <typename F, typename W> static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.ch = (u32)s[0]; }
+  template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx& c, u32 frame, u32&) {
+    return reinterpret_cast<const F*>(c.input_block)[r.ch * c.in_stride + frame];
+  }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F> static __device__ __forceinline__ void on_event(Regs<F>&, u32, u32, u64, u32) {}
 };
 
 // SafetyLimiter -- dynamics.rs:9-31: clamp to [-1, 1] (a NaN passes the clamp), then NaN -> 0.  No state.
@@ -1972,6 +1999,8 @@ struct VoiceKernelArgs {
   u32 delay_stride;
   const void* buffer;               // BufferReader's shared Buffer (single channel, F), or null
   u32 buffer_frames;
+  const void* input;                // the bank node's input channels, [n_blocks][in_channels][block_size] of F, or null
+  u32 in_channels;
   const u32* ev_start;              // [n_voices + 1] or null when the block has no events
   const Event* events;
   F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its 64 voices
@@ -2023,6 +2052,8 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ctx.delay_stride = a.delay_stride;
   ctx.buffer = a.buffer;
   ctx.buffer_frames = a.buffer_frames;
+  ctx.input_block = a.input;
+  ctx.in_stride = a.block_size;
 
   const u32 wave_global = blockIdx.x * WAVES + wave;
   const u32 v0 = wave_global * 64u;
@@ -2058,6 +2089,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   F(*my)[TS] = tile[wave];
   for (u32 b = 0; b < a.n_blocks; ++b, base += a.block_size) {
+    ctx.input_block = reinterpret_cast<const F*>(a.input) + (long)b * a.in_channels * a.block_size;
     chain.begin_block(a.frame_begin, ctx);
     F* partial_row = a.partials + ((long)b * n_waves_total + wave_global) * a.block_size;
     for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {

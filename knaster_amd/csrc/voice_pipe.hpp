@@ -108,6 +108,8 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   ctx.delay_stride = a.delay_stride;
   ctx.buffer = a.buffer;
   ctx.buffer_frames = a.buffer_frames;
+  ctx.input_block = a.input;
+  ctx.in_stride = a.block_size;
   const bool live = (u32)lane < nv;
   const u32 voice = live ? v0 + lane : v0 + nv - 1;
   ChainT chain;
@@ -183,7 +185,10 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
 #pragma unroll
         for (int j = 0; j < TW; ++j) x[j] = (F)0;
       }
-      if (ti == 0) chain.begin_block(a.frame_begin, ctx);
+      if (ti == 0) {
+        ctx.input_block = reinterpret_cast<const F*>(a.input) + (long)blk * a.in_channels * a.block_size;
+        chain.begin_block(a.frame_begin, ctx);
+      }
       const u32 n_tile = a.frame_begin + (u32)ti * T;
       const u32 m_tile = a.frame_end - n_tile < (u32)T ? a.frame_end - n_tile : (u32)T;
       const u32 n = n_tile + fo;                                                            // the window's first frame

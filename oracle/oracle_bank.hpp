@@ -31,6 +31,7 @@ inline int stage_n_ctor_args(uint16_t kind) {
     case KNH_STAGE_WHITE_NOISE: case KNH_STAGE_PINK_NOISE: case KNH_STAGE_BROWN_NOISE: return 1;
     case KNH_STAGE_RANDOM_LIN: return 2;
     case KNH_STAGE_PAN2: return 1;
+    case KNH_STAGE_INPUT: return 1;
     case KNH_STAGE_MATH_ADD: case KNH_STAGE_MATH_SUB: case KNH_STAGE_MATH_MUL: case KNH_STAGE_MATH_DIV: case KNH_STAGE_MATH_POW: return 0;
     case KNH_STAGE_MUL_ENVELOPE: return -1;  // 4 + 2 * n_max
   }
@@ -60,14 +61,24 @@ struct VoiceChainBuilder {
     targets.assign(stages.size(), ParamTarget{});
     bool have_x = false;
     NodeKey x = 0;
-    std::vector<NodeKey> out_of(stages.size(), 0);  // the node whose output 0 is stage s's signal
+    std::vector<NodeKey> out_of(stages.size(), 0);  // the node whose output is stage s's signal (GRAPH_KEY: a graph input) ...
+    std::vector<uint16_t> ch_of(stages.size(), 0);  // ... and which of its channels (a graph input's number)
+    uint16_t x_ch = 0;
     for (size_t s = 0; s < stages.size(); ++s) {
       const knh_stage_desc& st = stages[s];
       if (stage_is_wrapper(st.kind)) throw std::runtime_error("wrapper stage without a node to wrap");
       const std::vector<double>& a = args[s];
       // which signal the stage reads: the stage before it, or the one it names (knh_stage_desc.input)
       if (st.input > s || st.input2 > s) throw std::runtime_error("a stage reads the output of an earlier stage");
-      if (st.input != 0) x = out_of[st.input - 1];
+      if (st.input != 0) { x = out_of[st.input - 1]; x_ch = ch_of[st.input - 1]; }
+      if (st.kind == KNH_STAGE_INPUT) {  // the bank node's input channel: the voice graph's own input of that number
+        out_of[s] = GRAPH_KEY;
+        ch_of[s] = static_cast<uint16_t>(a[0]);
+        x = GRAPH_KEY;
+        x_ch = ch_of[s];
+        have_x = true;
+        continue;
+      }
       if (st.kind >= KNH_STAGE_MATH_ADD && st.kind <= KNH_STAGE_MATH_POW) {  // MathUGen<_, U1, Op> of two signals (graph_edit.rs:936-971)
         if (st.input == 0 || st.input2 == 0) throw std::runtime_error("a MATH stage names both operands");
         const MathOp op = st.kind == KNH_STAGE_MATH_ADD ? MathOp::Add : st.kind == KNH_STAGE_MATH_SUB ? MathOp::Sub
@@ -95,16 +106,17 @@ struct VoiceChainBuilder {
           ++s2;
         }
         NodeKey m = g.push(std::move(math2));
-        g.connect_to_node(out_of[st.input - 1], 0, 0, m, false);
-        g.connect_to_node(out_of[st.input2 - 1], 0, 1, m, false);
+        g.connect_to_node(out_of[st.input - 1], ch_of[st.input - 1], 0, m, false);
+        g.connect_to_node(out_of[st.input2 - 1], ch_of[st.input2 - 1], 1, m, false);
         targets[s].node = m;
         for (auto& [ws, off] : wr_targets) {
           targets[ws].node = m;
           targets[ws].index_offset = off;
           targets[ws].n_params = stages[ws].kind == KNH_STAGE_WR_MUL ? 1 : 0;
         }
-        for (size_t k = s; k < s2; ++k) out_of[k] = m;
+        for (size_t k = s; k < s2; ++k) { out_of[k] = m; ch_of[k] = 0; }
         x = m;
+        x_ch = 0;
         have_x = true;
         s = s2 - 1;
         continue;
@@ -214,15 +226,16 @@ struct VoiceChainBuilder {
       if (is_source) {
         if (ar) {
           if (!have_x) throw std::runtime_error("AR_FREQ stage needs a preceding signal");
+          if (x == GRAPH_KEY) throw std::runtime_error("an audio-rate parameter edge starts at a node, not at a graph input");
           g.connect_to_parameter(x, 0, 0, core_key);
         }  // (a source after the first stage starts a new signal of the voice)
       } else if (!two_node) {
         if (!have_x) throw std::runtime_error("processor stage needs a preceding signal");
-        g.connect_to_node(x, 0, 0, core_key, false);
+        g.connect_to_node(x, x_ch, 0, core_key, false);
       } else {
         if (!have_x) throw std::runtime_error("math stage needs a preceding signal");
         NodeKey m = g.push(std::move(math));
-        g.connect_to_node(x, 0, 0, m, false);
+        g.connect_to_node(x, x_ch, 0, m, false);
         g.connect_to_node(core_key, 0, 1, m, false);
         out_key = m;
       }
@@ -231,12 +244,14 @@ struct VoiceChainBuilder {
         targets[ws].index_offset = off;
         targets[ws].n_params = stages[ws].kind == KNH_STAGE_WR_MUL ? 1 : 0;
       }
-      for (size_t k = s; k < s2; ++k) out_of[k] = out_key;
+      for (size_t k = s; k < s2; ++k) { out_of[k] = out_key; ch_of[k] = 0; }
       x = out_key;
+      x_ch = 0;
       have_x = true;
       s = s2 - 1;
     }
     if (!have_x) throw std::runtime_error("empty chain");
+    if (x == GRAPH_KEY) throw std::runtime_error("a voice that is only a bank input has no node to connect to the output");
     return x;
   }
 };
@@ -265,6 +280,7 @@ struct OracleBank {
       for (uint32_t s = 0; s < n_stages; ++s) ctor[v][s].assign(static_cast<size_t>(std::max(0, stage_n_ctor_args(stages[s].kind))), 0.0);
   }
   std::shared_ptr<Buffer<F>> buffer;
+  uint32_t in_channels = 0;  // UGen::Inputs of the bank node: every voice graph has that many graph inputs
   // A chain that ends in Pan2: `(voice >> pan).to_graph_out()` (many_sines.rs:59-60) -- the node's outputs 0 and 1
   // go to graph outputs 0 and 1, and every voice has two signals: voice_block is [2][n_voices][block_size].
   bool pan() const { return !stages.empty() && stages.back().kind == KNH_STAGE_PAN2; }
@@ -275,7 +291,7 @@ struct OracleBank {
     b.buffer = buffer;
     if (pan() && out_channels != 2) throw std::runtime_error("a chain ending in Pan2 has two output channels");
     if (want_mix) {
-      mix_graph = std::make_unique<Graph<F>>(0, out_channels, bs, sr);
+      mix_graph = std::make_unique<Graph<F>>(in_channels, out_channels, bs, sr);
       mix_targets.resize(n_voices);
       for (uint32_t v = 0; v < n_voices; ++v) {
         NodeKey x = b.build(*mix_graph, ctor[v], mix_targets[v]);
@@ -287,7 +303,7 @@ struct OracleBank {
       voice_targets.resize(n_voices);
       const uint16_t planes = pan() ? 2 : 1;
       for (uint32_t v = 0; v < n_voices; ++v) {
-        voice_graphs.push_back(std::make_unique<Graph<F>>(0, planes, bs, sr));
+        voice_graphs.push_back(std::make_unique<Graph<F>>(in_channels, planes, bs, sr));
         NodeKey x = b.build(*voice_graphs[v], ctor[v], voice_targets[v]);
         for (uint16_t c = 0; c < planes; ++c) voice_graphs[v]->connect_to_output(x, c, c, true);
         voice_graphs[v]->commit_changes();
@@ -330,13 +346,16 @@ struct OracleBank {
     });
     return rc;
   }
-  // out: [out_channels][block_size] (may be null).  Returns KNH_FLAG_*.
-  uint32_t process_block(F* out) {
+  // out: [out_channels][block_size] (may be null); in: [in_channels][block_size] (the bank node's input block).  Returns KNH_FLAG_*.
+  uint32_t process_block(F* out, const F* in = nullptr) {
     uint32_t flags = 0;
+    std::vector<const F*> ins;
+    for (uint32_t c = 0; c < in_channels; ++c) ins.push_back(in ? in + static_cast<size_t>(c) * block_size : nullptr);
+    if (in_channels && !in) throw std::runtime_error("a bank with input channels needs an input block");
     if (want_mix) {
       std::vector<F> tmp;
       if (!out) { tmp.resize(out_channels * block_size); out = tmp.data(); }
-      mix_graph->run({}, out);
+      mix_graph->run(ins, out);
       if (mix_graph->last_flags.done_) flags |= KNH_FLAG_ANY_DONE;
     }
     if (want_voices) {
@@ -344,11 +363,11 @@ struct OracleBank {
       if (pan()) lr.resize(2 * block_size);
       for (uint32_t v = 0; v < n_voices; ++v) {
         if (pan()) {  // [left][right] of this voice -> the two planes
-          voice_graphs[v]->run({}, lr.data());
+          voice_graphs[v]->run(ins, lr.data());
           std::copy(lr.begin(), lr.begin() + block_size, voice_block.begin() + static_cast<size_t>(v) * block_size);
           std::copy(lr.begin() + block_size, lr.end(), voice_block.begin() + (static_cast<size_t>(n_voices) + v) * block_size);
         } else {
-          voice_graphs[v]->run({}, voice_block.data() + static_cast<size_t>(v) * block_size);
+          voice_graphs[v]->run(ins, voice_block.data() + static_cast<size_t>(v) * block_size);
         }
         uint32_t f = 0xFFFFFFFFu;
         done_frames[v] = voice_graphs[v]->last_flags.done(&f) ? f : 0xFFFFFFFFu;

@@ -18,7 +18,8 @@ struct BankBase {
   virtual int param_apply(uint32_t voice, uint32_t stage, uint32_t param, ParameterValue v) = 0;
   virtual int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) = 0;
   virtual int schedule(uint32_t voice, uint32_t stage, uint32_t param, ParameterValue v, int mode, uint32_t s, uint32_t t) = 0;
-  virtual int process(void* out, void* voices, uint32_t* flags, uint32_t* done) = 0;
+  virtual int process(void* out, void* voices, uint32_t* flags, uint32_t* done, const void* in) = 0;
+  virtual void set_in_channels(uint32_t n) = 0;
   virtual size_t mix_tasks() const = 0;
   virtual size_t mix_buffer_len() const = 0;
   std::string err;
@@ -70,9 +71,10 @@ struct BankImpl : BankBase {
     Time tm = mode == 2 ? Time::at(Seconds{s, t}) : Time::after(Seconds{s, t});
     return b.schedule(voice, stage, param, v, mode != 0, tm);
   }
-  int process(void* out, void* voices, uint32_t* flags, uint32_t* done) override {
+  void set_in_channels(uint32_t n) override { b.in_channels = n; }
+  int process(void* out, void* voices, uint32_t* flags, uint32_t* done, const void* in) override {
     try {
-      uint32_t f = b.process_block(static_cast<F*>(out));
+      uint32_t f = b.process_block(static_cast<F*>(out), static_cast<const F*>(in));
       if (flags) *flags = f;
       if (voices && b.want_voices) std::memcpy(voices, b.voice_block.data(), b.voice_block.size() * sizeof(F));
       if (done && b.want_voices) std::memcpy(done, b.done_frames.data(), b.done_frames.size() * sizeof(uint32_t));
@@ -150,7 +152,12 @@ int kno_bank_schedule(void* h, uint32_t voice, uint32_t stage, uint32_t param, u
   return static_cast<BankBase*>(h)->schedule(voice, stage, param, make_value(kind, f, i), time_mode, seconds, tesimals);
 }
 int kno_bank_process_block(void* h, void* out, void* voices_out, uint32_t* flags, uint32_t* done_frames) {
-  return static_cast<BankBase*>(h)->process(out, voices_out, flags, done_frames);
+  return static_cast<BankBase*>(h)->process(out, voices_out, flags, done_frames, nullptr);
+}
+// the bank node's input channels (UGen::Inputs): declared before init, one [in_channels][block_size] block per process call
+void kno_bank_set_in_channels(void* h, uint32_t n) { static_cast<BankBase*>(h)->set_in_channels(n); }
+int kno_bank_process_block_in(void* h, const void* in, void* out, void* voices_out, uint32_t* flags, uint32_t* done_frames) {
+  return static_cast<BankBase*>(h)->process(out, voices_out, flags, done_frames, in);
 }
 size_t kno_bank_mix_tasks(void* h) { return static_cast<BankBase*>(h)->mix_tasks(); }
 size_t kno_bank_mix_buffer_len(void* h) { return static_cast<BankBase*>(h)->mix_buffer_len(); }
@@ -234,7 +241,7 @@ double kno_baseline_run(const knh_stage_desc* stages, uint32_t n_stages, uint32_
       if (release_stage >= 0 && i == warmup_blocks + release_block)
         for (uint32_t v = 0; v < nv; ++v) shards[t]->param_apply(v, static_cast<uint32_t>(release_stage), release_param, ParameterValue::Trig());
       void* dst = i < warmup_blocks ? scratch.data() : outs[t].data() + static_cast<size_t>(i - warmup_blocks) * out_len * esz;
-      shards[t]->process(dst, nullptr, nullptr, nullptr);
+      shards[t]->process(dst, nullptr, nullptr, nullptr, nullptr);
     }
   };
   auto run_range = [&](uint32_t from, uint32_t to) {

@@ -61,6 +61,9 @@ def load() -> C.CDLL:
         lib.kno_bank_param_apply_many.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
         lib.kno_bank_schedule.argtypes = [vp, u32, u32, u32, u32, f64, i64, i32, u32, u32]
         lib.kno_bank_process_block.argtypes = [vp, vp, vp, C.POINTER(u32), vp]
+        lib.kno_bank_set_in_channels.argtypes = [vp, u32]
+        lib.kno_bank_set_in_channels.restype = None
+        lib.kno_bank_process_block_in.argtypes = [vp, vp, vp, vp, C.POINTER(u32), vp]
         lib.kno_bank_mix_tasks.restype = sz
         lib.kno_bank_mix_tasks.argtypes = [vp]
         lib.kno_bank_mix_buffer_len.restype = sz
@@ -164,6 +167,15 @@ class OracleBank:
         k, f, i = self._value(value)
         self._check(self._lib.kno_bank_schedule(self._h, voice, stage, param, k, f, i, time_mode, seconds, tesimals))
 
+    def set_in_channels(self, n: int):
+        """UGen::Inputs of the bank node; before init."""
+        self._lib.kno_bank_set_in_channels(self._h, int(n))
+        self.in_channels = int(n)
+
+    def set_input(self, block):
+        """The input block of the next process_block call: [in_channels, B]."""
+        self._input = np.ascontiguousarray(np.asarray(block, dtype=self.dtype)).reshape(self.in_channels, self.block_size)
+
     def process_block(self):
         """-> (out [ch, B], voices [N, B] ([2, N, B] for a chain ending in Pan2) or None, flags, done_frames or None)"""
         out = np.zeros((self.out_channels, self.block_size), dtype=self.dtype)
@@ -172,9 +184,14 @@ class OracleBank:
         voices = np.zeros(shape, dtype=self.dtype) if self.want_voices else None
         done = np.zeros(self.n_voices, dtype=np.uint32) if self.want_voices else None
         flags = C.c_uint32(0)
-        self._check(self._lib.kno_bank_process_block(
-            self._h, out.ctypes.data_as(C.c_void_p), None if voices is None else voices.ctypes.data_as(C.c_void_p),
-            C.byref(flags), None if done is None else done.ctypes.data_as(C.c_void_p)))
+        if getattr(self, "in_channels", 0):
+            self._check(self._lib.kno_bank_process_block_in(
+                self._h, self._input.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                None if voices is None else voices.ctypes.data_as(C.c_void_p), C.byref(flags), None if done is None else done.ctypes.data_as(C.c_void_p)))
+        else:
+            self._check(self._lib.kno_bank_process_block(
+                self._h, out.ctypes.data_as(C.c_void_p), None if voices is None else voices.ctypes.data_as(C.c_void_p),
+                C.byref(flags), None if done is None else done.ctypes.data_as(C.c_void_p)))
         return out, voices, int(flags.value), done
 
     def mix_tasks(self):

@@ -9,6 +9,8 @@ from knaster_amd import configs
 
 def make_oracle(oracle, w: configs.Workload, want_mix=True, want_voices=True):
     b = oracle.OracleBank(w.stages, w.n_voices, w.sample_type, w.out_channels, want_mix, want_voices)
+    if getattr(w, "in_channels", 0):
+        b.set_in_channels(w.in_channels)
     for s, a in w.ctor.items():
         b.set_ctor_args(s, a)
     if w.buffer is not None:
@@ -18,7 +20,8 @@ def make_oracle(oracle, w: configs.Workload, want_mix=True, want_voices=True):
 
 
 def make_gpu(knh, w: configs.Workload, mix_mode=L.MIX_TREE, allow_fma=False, host_threads=0):
-    b = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, mix_mode, -1, allow_fma, host_threads)
+    b = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, mix_mode, -1, allow_fma, host_threads,
+                      in_channels=getattr(w, "in_channels", 0))
     for s, a in w.ctor.items():
         b.set_ctor_args(s, a)
     if w.buffer is not None:

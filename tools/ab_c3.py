@@ -24,7 +24,8 @@ def open_lib(path):
 
     class Desc(C.Structure):
         _fields_ = [("abi", C.c_uint32), ("n_voices", C.c_uint32), ("sample_type", C.c_uint32), ("n_stages", C.c_uint32),
-                    ("stages", C.POINTER(Stage)), ("out_channels", C.c_uint32), ("mix_mode", C.c_uint32), ("device", C.c_int32), ("allow_fma", C.c_uint32)]
+                    ("stages", C.POINTER(Stage)), ("out_channels", C.c_uint32), ("mix_mode", C.c_uint32), ("device", C.c_int32), ("allow_fma", C.c_uint32),
+                    ("in_channels", C.c_uint32)]  # (ABI 2; an ABI 1 library does not read that far)
     lib.knh_bank_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
     lib.knh_bank_set_ctor_args.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.knh_bank_init.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t]
@@ -44,7 +45,7 @@ def make(libt, w):
     arr = (Stage * len(w.stages))()
     for i, s in enumerate(w.stages):
         arr[i].kind, arr[i].flags, arr[i].dcpb = s.kind, s.flags, s.delayed_changes_per_block
-    d = Desc(abi, w.n_voices, w.sample_type, len(w.stages), arr, w.out_channels, 0, -1, 0)
+    d = Desc(abi, w.n_voices, w.sample_type, len(w.stages), arr, w.out_channels, 0, -1, 0, 0)
     h = C.c_void_p()
     assert lib.knh_bank_create(C.byref(d), C.byref(h)) == 0, lib.knh_last_error(None)
     for s, a in w.ctor.items():
