@@ -167,6 +167,8 @@ unsafe extern "C" {
     pub fn knh_bank_timing_read(bank: *mut knh_bank, kernel_ms: *mut f64, launches: *mut u64) -> i32;
     pub fn knh_bank_algorithmic_bytes_per_voice_block(bank: *const knh_bank, read_bytes: *mut u32, write_bytes: *mut u32) -> i32;
     // several GPUs of one node: one process owning them all, or one process per GPU with an RCCL reduce
+    pub fn knh_bank_process_blocks_begin(bank: *mut knh_bank, n_blocks: u32, frame_clock: u64) -> i32;
+    pub fn knh_bank_process_blocks_end(bank: *mut knh_bank, out: *mut c_void) -> i32;
     pub fn knh_bank_set_input(bank: *mut knh_bank, n_blocks: u32, input: *const c_void) -> i32;
     pub fn knh_bank_set_input_device(bank: *mut knh_bank, n_blocks: u32, in_device: *const c_void) -> i32;
     pub fn knh_bank_create_multi_device(desc: *const knh_bank_desc, devices: *const i32, n_devices: u32, out_bank: *mut *mut knh_bank) -> i32;

@@ -404,6 +404,14 @@ int32_t knh_bank_process_blocks_device(knh_bank* bank, uint32_t n_blocks, uint64
  * banks (voices of different shapes) keep one output buffer in HBM and read it back once. */
 int32_t knh_bank_process_blocks_device_add(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock,
                                            void* out_device, void* hip_stream);
+/* knh_bank_process_blocks in two halves, for a host that renders launch after launch to host memory (offline rendering:
+ * AudioProcessor::run_without_inputs in a loop, processor.rs:142-179): _begin enqueues the launch and the copy of its mixed
+ * blocks into pinned memory and returns; _end waits for the OLDEST outstanding launch and copies its blocks to `out`
+ * ([n_blocks][out_channels][block_size] of F).  Up to two launches may be outstanding, so that the host's work for launch
+ * k + 1 (parameter calls, event assembly) and its kernels run while launch k's blocks cross PCIe.  Same samples as
+ * knh_bank_process_blocks; no flag summary (knh_bank_read_done_frames, or a blocking call, reports those). */
+int32_t knh_bank_process_blocks_begin(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock);
+int32_t knh_bank_process_blocks_end(knh_bank* bank, void* out);
 /* Device-memory helpers for hosts that do not link HIP themselves (the library owns the allocations):
  * zero-initialised allocation on `device` (-1: current), free, and a synchronising device-to-host read. */
 void* knh_device_malloc(size_t bytes, int32_t device);

@@ -102,6 +102,8 @@ COMM_ID_BYTES = 128
 # knh_reduce_fn: int32 (*)(void* user, void* device_buf, size_t count, uint32 sample_type, uint32 root, void* hip_stream)
 REDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
 PROTOTYPES.update({
+    "knh_bank_process_blocks_begin": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "knh_bank_process_blocks_end": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "knh_bank_set_input": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "knh_bank_set_input_device": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "knh_bank_create_multi_device": (C.c_int32, [C.POINTER(BankDesc), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]),

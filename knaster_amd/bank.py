@@ -251,6 +251,19 @@ class VoiceBank:
         self._check(self._lib.knh_bank_process_blocks(self._h, n_blocks, frame_clock, out.ctypes.data_as(C.c_void_p), C.byref(flags)))
         return out, int(flags.value)
 
+    def process_blocks_begin(self, n_blocks: int, frame_clock: int = 0):
+        """Enqueue a launch and the copy of its blocks to pinned host memory; fetch them with process_blocks_end (up to two
+        may be outstanding)."""
+        self._check(self._lib.knh_bank_process_blocks_begin(self._h, n_blocks, frame_clock))
+        self._begun = getattr(self, "_begun", []) + [n_blocks]
+
+    def process_blocks_end(self):
+        """-> out [n_blocks, ch, B] of the oldest outstanding launch."""
+        n_blocks = self._begun.pop(0)
+        out = np.zeros((n_blocks, self.out_channels, self.block_size), dtype=self.dtype)
+        self._check(self._lib.knh_bank_process_blocks_end(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def process_blocks_device(self, n_blocks: int, out_device_ptr: int = 0, hip_stream: int = 0, frame_clock: int = 0):
         self._check(self._lib.knh_bank_process_blocks_device(self._h, n_blocks, frame_clock, C.c_void_p(out_device_ptr or None),
                                                              C.c_void_p(hip_stream or None)))

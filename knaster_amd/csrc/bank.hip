@@ -243,7 +243,22 @@ struct QueuedChange {  // WrPreciseTiming::waiting_changes entry, precise_timing
 // The bank
 // ---------------------------------------------------------------------------
 struct knh_bank {
-  virtual ~knh_bank() = default;
+  virtual ~knh_bank() {
+    // the pipelined host output (knh_bank_process_blocks_begin / _end); the derived bank has already waited for the device
+    if (pipe_stream || pipe[0].dev || pipe[1].dev) (void)hipSetDevice(device);
+    for (PipeSlot& p : pipe) {
+      if (p.done) (void)hipEventDestroy(p.done);
+      if (p.dev) (void)hipFree(p.dev);
+      if (p.host) (void)hipHostFree(p.host);
+    }
+    if (pipe_stream) (void)hipStreamDestroy(pipe_stream);
+  }
+  struct PipeSlot { void* dev = nullptr; void* host = nullptr; hipEvent_t done = nullptr; size_t cap = 0, bytes = 0; };
+  PipeSlot pipe[2];
+  hipStream_t pipe_stream = nullptr;
+  unsigned pipe_head = 0, pipe_count = 0;
+  // a stream that is to read the mix of the launch just enqueued waits for whatever sums it across GPUs (rank banks)
+  virtual int order_after_collective(void* /*stream*/) { return KNH_OK; }
   std::string err;
   std::vector<std::string> warnings;
   knh_bank_desc desc{};
@@ -2011,7 +2026,13 @@ int32_t knh_bank_create_sharded(const knh_bank_desc* desc, uint32_t host_threads
   return create_bank(desc, host_threads, out_bank);
 }
 
-void knh_bank_destroy(knh_bank* bank) { delete bank; }
+void knh_bank_destroy(knh_bank* bank) {
+  if (bank && bank->pipe_stream) {  // launches begun and never fetched still hold the bank's buffers
+    (void)hipSetDevice(bank->device);
+    (void)hipStreamSynchronize(bank->pipe_stream);
+  }
+  delete bank;
+}
 
 int32_t knh_bank_set_ctor_args(knh_bank* bank, uint32_t stage, uint32_t first_voice, uint32_t count, const double* args, uint32_t n_args) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
@@ -2085,6 +2106,49 @@ int32_t knh_bank_process_blocks_device(knh_bank* bank, uint32_t n_blocks, uint64
 int32_t knh_bank_process_blocks_device_add(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out_device, void* hip_stream) {
   if (!bank) return KNH_ERR_INVALID_ARGUMENT;
   return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false, true);
+}
+int32_t knh_bank_process_blocks_begin(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (!bank->initialised) return bank->fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+  if (bank->pipe_count == 2) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "two launches are outstanding: fetch one with knh_bank_process_blocks_end first");
+  if (n_blocks == 0 || n_blocks > 4096) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "n_blocks must be in 1..4096");
+  auto hip = [&](hipError_t e, const char* what) { return e == hipSuccess ? KNH_OK : bank->fail(KNH_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+  int rc = hip(hipSetDevice(bank->device), "hipSetDevice");
+  if (rc != KNH_OK) return rc;
+  if (!bank->pipe_stream && (rc = hip(hipStreamCreateWithFlags(&bank->pipe_stream, hipStreamNonBlocking), "hipStreamCreate")) != KNH_OK) return rc;
+  knh_bank::PipeSlot& p = bank->pipe[(bank->pipe_head + bank->pipe_count) % 2];
+  const size_t bytes = static_cast<size_t>(n_blocks) * bank->desc.out_channels * bank->block_size * (bank->desc.sample_type == KNH_F64 ? 8 : 4);
+  if (bytes > p.cap) {
+    if (p.dev) (void)hipFree(p.dev);
+    if (p.host) (void)hipHostFree(p.host);
+    p.dev = p.host = nullptr;
+    p.cap = 0;
+    if ((rc = hip(hipMalloc(&p.dev, bytes), "hipMalloc")) != KNH_OK) return rc;
+    if ((rc = hip(hipMemset(p.dev, 0, bytes), "hipMemset")) != KNH_OK) return rc;
+    if ((rc = hip(hipHostMalloc(&p.host, bytes), "hipHostMalloc")) != KNH_OK) return rc;
+    p.cap = bytes;
+  }
+  if (!p.done && (rc = hip(hipEventCreateWithFlags(&p.done, hipEventDisableTiming), "hipEventCreate")) != KNH_OK) return rc;
+  p.bytes = bytes;
+  rc = bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, p.dev, nullptr, nullptr, bank->pipe_stream, false);
+  if (rc != KNH_OK) return rc;
+  if ((rc = bank->order_after_collective(bank->pipe_stream)) != KNH_OK) return rc;
+  if ((rc = hip(hipSetDevice(bank->device), "hipSetDevice")) != KNH_OK) return rc;
+  if ((rc = hip(hipMemcpyAsync(p.host, p.dev, bytes, hipMemcpyDeviceToHost, bank->pipe_stream), "hipMemcpyAsync")) != KNH_OK) return rc;
+  if ((rc = hip(hipEventRecord(p.done, bank->pipe_stream), "hipEventRecord")) != KNH_OK) return rc;
+  bank->pipe_count += 1;
+  return KNH_OK;
+}
+int32_t knh_bank_process_blocks_end(knh_bank* bank, void* out) {
+  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+  if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output");
+  if (bank->pipe_count == 0) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "no launch is outstanding (knh_bank_process_blocks_begin)");
+  knh_bank::PipeSlot& p = bank->pipe[bank->pipe_head];
+  if (hipSetDevice(bank->device) != hipSuccess || hipEventSynchronize(p.done) != hipSuccess) return bank->fail(KNH_ERR_DEVICE, "waiting for the launch failed");
+  std::memcpy(out, p.host, p.bytes);
+  bank->pipe_head = (bank->pipe_head + 1) % 2;
+  bank->pipe_count -= 1;
+  return KNH_OK;
 }
 void* knh_device_malloc(size_t bytes, int32_t device) {
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return nullptr;

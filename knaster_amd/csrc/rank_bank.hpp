@@ -54,6 +54,11 @@ struct RankBank final : knh_bank {
     return rc;
   }
   bool mine(uint32_t v) const { return v >= lo && v < hi; }
+  int order_after_collective(void* stream) override {
+    if (!comm) return KNH_OK;
+    int rc = knh_comm_wait(comm, stream);
+    return rc == KNH_OK ? KNH_OK : fail(rc, knh_comm_last_error(comm));
+  }
   uint32_t ranks() const override { return comm ? knh_comm_world(comm) : world; }
 
   int set_ctor(uint32_t stage, uint32_t first, uint32_t count, const double* args, uint32_t n_args) override {

@@ -544,3 +544,44 @@ def test_full_size_c4_f64_oracle_subset_and_sharded_sum(knh, oracle, shards):
         assert np.max(np.abs(a - b)) <= 1e-12 and np.max(np.abs(a)) > 1e-4
         one.close()
         many.close()
+
+
+@pytest.mark.parametrize("kind", ["plain", "host_sharded", "multi_device", "rank"])
+def test_pipelined_host_output_equals_blocking_calls(knh, kind):
+    """knh_bank_process_blocks_begin / _end (two launches in flight, blocks copied to pinned memory behind the kernels) give
+    the samples knh_bank_process_blocks gives, for every kind of bank; misuse is refused."""
+    import ctypes
+    w = configs.config("C3", n_voices=700, block_size=64)
+    kw = {"plain": {}, "host_sharded": {"host_threads": 3}, "multi_device": {"devices": [0, 0]}, "rank": {"rank": 0, "world": 1}}[kind]
+
+    def make():
+        b = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE, -1, False, **kw)
+        for s, a in w.ctor.items():
+            b.set_ctor_args(s, a)
+        b.init(configs.SAMPLE_RATE, w.block_size)
+        return b
+
+    def events(bank, launch):  # the C3 script's blocks 0..5, one per launch, addressed to block 1 of the launch
+        c3_script(w, launch, bank, 1 if sizes[launch] > 1 else 0)
+    a, b = make(), make()
+    sizes = [4, 1, 7, 3, 5, 2]
+    want = []
+    for launch, k in enumerate(sizes):
+        events(a, launch)
+        want.append(a.process_blocks(k)[0])
+    scratch = np.zeros(8, dtype=np.float32)
+    assert b._lib.knh_bank_process_blocks_end(b._h, scratch.ctypes.data_as(ctypes.c_void_p)) != L.OK  # nothing outstanding
+    got = []
+    for launch, k in enumerate(sizes):
+        events(b, launch)
+        b.process_blocks_begin(k)
+        if launch == 1:
+            assert b._lib.knh_bank_process_blocks_begin(b._h, 1, 0) != L.OK  # two outstanding is the limit
+        if launch >= 1:
+            got.append(b.process_blocks_end())
+    got.append(b.process_blocks_end())
+    for launch in range(len(sizes)):
+        assert_bit_equal(got[launch], want[launch], f"{kind}: launch {launch}")
+    assert np.abs(want[1]).max() > 0
+    a.close()
+    b.close()
