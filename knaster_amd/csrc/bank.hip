@@ -533,7 +533,7 @@ struct Bank final : knh_bank {
     // single-wave form.
     // The 64-sample-tile pipeline only where the block is made of whole tiles: a partial tile runs sample by sample,
     // and a 32- or 96-frame block would be half partial tiles (its 32-sample form has none).
-    if (pipe && pipe->big && bs % (sizeof(F) == 4 ? 64u : 32u) != 0) pipe = knh::find_pipe(signature.c_str(), false);
+    if (pipe && pipe->form != 0 && bs % (sizeof(F) == 4 ? 64u : 32u) != 0) pipe = knh::find_pipe(signature.c_str(), 1u);
     const unsigned n_groups = (nv + 63u) / 64u;
     const char* jp = std::getenv("KNH_JIT_PIPE");
     // (a single voice group with a pre-built kernel stays on it: nothing to gain, and no compile at init)
@@ -1793,8 +1793,11 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
     // The 64-sample-tile form with the fold in the last stage group is used where one is built (kernels.hip): measured
     // 3 % faster than the 32-sample form over C3's note cycle, 12 % with every envelope at rest.  KNH_PIPE_BIG=0 keeps the
     // 32-sample tiles and the mixer wavefront (A/B runs).
+    // KNH_PIPE_BIG=1: 64-sample tiles with the fold in the last stage group (round 1's form); default: 64-sample tiles, the
+    // last group in place and a mixer wavefront on the fourth SIMD.
     const char* big_env = std::getenv("KNH_PIPE_BIG");
-    if (b->entry && level >= 1) b->pipe = knh::find_pipe(sig.c_str(), !(big_env && big_env[0] == '0'));
+    const unsigned forms = big_env && big_env[0] == '0' ? 1u : (big_env && big_env[0] == '1' ? 3u : 7u);
+    if (b->entry && level >= 1) b->pipe = knh::find_pipe(sig.c_str(), forms);
     if (b->entry && level >= 2 && d.sample_type == KNH_F32) b->dag = knh::find_dag(sig.c_str());
     // Occupancy regime: the wave pipeline minimises latency when every 64-voice group can have a CU to
     // itself (<= ~1.5 groups per CU); beyond that throughput wins and the groups are packed 4 or 8 to a

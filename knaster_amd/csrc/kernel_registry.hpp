@@ -26,11 +26,12 @@ struct KernelEntry {
 struct PipeEntry {
   const char* signature;
   int n_groups;
-  bool big;  // 64-sample tiles (f64: 32), the last stage group folds (no mixer wavefront)
+  int form;  // knh_dev::PIPE_MIXER (32-sample tiles, f64: 16), PIPE_FOLD or PIPE_INPLACE (64-sample tiles, f64: 32): voice_pipe.hpp
   VoiceLaunchFn<float> f32[2];
   VoiceLaunchFn<double> f64[2];
 };
-const PipeEntry* find_pipe(const char* signature, bool allow_big = true);
+// the first entry for the chain whose form is in `forms` (bit i = form i)
+const PipeEntry* find_pipe(const char* signature, unsigned forms = 7u);
 // Five-role (dependence-cut) pipeline for source -> SVF -> x*envelope -> post chains, f32 banks (voice_dag.hpp).
 struct DagEntry {
   const char* signature;

@@ -8,12 +8,13 @@
 namespace knh {
 using namespace knh_dev;
 
-// BIG: 64-sample tiles (32 for f64) with the fold done by the last stage group instead of a mixer wavefront
-template <typename F, bool FMA, bool BIG, typename... Gs>
+// FORM: PIPE_MIXER = 32-sample tiles (16 for f64) and a mixer wavefront; PIPE_FOLD / PIPE_INPLACE = 64-sample tiles (32 for
+// f64) with the fold done by the last stage group / by a mixer wavefront behind a last group that works in place
+template <typename F, bool FMA, int FORM, typename... Gs>
 static hipError_t launch_pipe(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
   if (n_wavefronts == 0) return hipSuccess;
-  constexpr int T = BIG ? PipeTile<F>::big : PipeTile<F>::value;
-  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, BIG, Gs...>), dim3(n_wavefronts), dim3(PipeWaves<T, BIG, Gs...>::value * 64), 0, stream, args);
+  constexpr int T = FORM != PIPE_MIXER ? PipeTile<F>::big : PipeTile<F>::value;
+  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, FORM, Gs...>), dim3(n_wavefronts), dim3(PipeWaves<T, FORM, Gs...>::value * 64), 0, stream, args);
   return hipGetLastError();
 }
 // 64-sample tiles (32 for f64) WITH a mixer wavefront: for pipelines with a Fan group (the fold costs the same per
@@ -22,17 +23,17 @@ template <typename F, bool FMA, typename... Gs>
 static hipError_t launch_pipe_wide_tile(const VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream) {
   if (n_wavefronts == 0) return hipSuccess;
   constexpr int T = PipeTile<F>::big;
-  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, false, Gs...>), dim3(n_wavefronts), dim3(PipeWaves<T, false, Gs...>::value * 64), 0, stream, args);
+  hipLaunchKernelGGL((voice_pipe_kernel<F, FMA, T, PIPE_MIXER, Gs...>), dim3(n_wavefronts), dim3(PipeWaves<T, PIPE_MIXER, Gs...>::value * 64), 0, stream, args);
   return hipGetLastError();
 }
 #define KNH_PIPE_FAN(sig, n, ...)                                                                                       \
-  {sig, n, false, {launch_pipe_wide_tile<float, false, __VA_ARGS__>, launch_pipe_wide_tile<float, true, __VA_ARGS__>}, \
+  {sig, n, PIPE_MIXER, {launch_pipe_wide_tile<float, false, __VA_ARGS__>, launch_pipe_wide_tile<float, true, __VA_ARGS__>}, \
    {launch_pipe_wide_tile<double, false, __VA_ARGS__>, launch_pipe_wide_tile<double, true, __VA_ARGS__>}}
-#define KNH_PIPE_AS(sig, n, big, ...)                                                               \
-  {sig, n, big, {launch_pipe<float, false, big, __VA_ARGS__>, launch_pipe<float, true, big, __VA_ARGS__>}, \
-   {launch_pipe<double, false, big, __VA_ARGS__>, launch_pipe<double, true, big, __VA_ARGS__>}}
-#define KNH_PIPE(sig, n, ...) KNH_PIPE_AS(sig, n, false, __VA_ARGS__)
-#define KNH_PIPE_BIG(sig, n, ...) KNH_PIPE_AS(sig, n, true, __VA_ARGS__)
+#define KNH_PIPE_AS(sig, n, form, ...)                                                               \
+  {sig, n, form, {launch_pipe<float, false, form, __VA_ARGS__>, launch_pipe<float, true, form, __VA_ARGS__>}, \
+   {launch_pipe<double, false, form, __VA_ARGS__>, launch_pipe<double, true, form, __VA_ARGS__>}}
+#define KNH_PIPE(sig, n, ...) KNH_PIPE_AS(sig, n, PIPE_MIXER, __VA_ARGS__)
+#define KNH_PIPE_BIG(sig, n, ...) KNH_PIPE_AS(sig, n, PIPE_INPLACE, __VA_ARGS__), KNH_PIPE_AS(sig, n, PIPE_FOLD, __VA_ARGS__)
 
 typedef Group<SinWt, MulVal> G_Wm;
 typedef Group<SinWt> G_W;
@@ -71,9 +72,9 @@ static const PipeEntry kPipes[] = {
     KNH_PIPE_BIG("WmSAJ", 3, G_Wm, G_S, G_A2),
     KNH_PIPE("WmSAJ", 3, G_Wm, G_S, G_A2),
 };
-const PipeEntry* find_pipe(const char* signature, bool allow_big) {
+const PipeEntry* find_pipe(const char* signature, unsigned forms) {
   for (const PipeEntry& e : kPipes)
-    if (std::strcmp(e.signature, signature) == 0 && (allow_big || !e.big)) return &e;
+    if (std::strcmp(e.signature, signature) == 0 && ((forms >> e.form) & 1u)) return &e;
   return nullptr;
 }
 

@@ -49,9 +49,9 @@ template <typename F, bool FMA, int BASE, int K, typename... S> struct GroupChai
 };
 
 // Samples per pipeline step.  `value`: three double-buffered edges + the mixer's beside the 64 KiB sine table.
-// `big`: twice that, for pipelines whose last stage group does the fold itself (FOLD, below) -- one edge buffer
-// fewer and no mixer wavefront, so the doubled tiles still fit the 160 KiB; the per-tile costs of the busiest wave
-// (LDS hand-over, block/event bookkeeping, the barrier) are then paid half as often.
+// `big`: twice that, for the forms with one tile fewer (PIPE_FOLD, PIPE_INPLACE below), so that the doubled tiles still
+// fit the 160 KiB; the per-tile costs of the busiest wave (LDS hand-over, block/event bookkeeping, the barrier) are
+// then paid half as often.
 template <typename F> struct PipeTile {
   static constexpr int value = sizeof(F) == 4 ? 32 : 16;
   static constexpr int big = 2 * value;
@@ -67,9 +67,29 @@ template <typename F, int TILE> struct EdgeLayout {
   static constexpr int tile = 64 * stride;                // elements per buffer
   typedef F Vec __attribute__((ext_vector_type(16 / sizeof(F))));
 };
+// How a pipeline's tiles reach the fold over the voices:
+//   PIPE_MIXER    a mixer wavefront reads the last group's own double-buffered edge (short tiles: four edges beside the sine table)
+//   PIPE_FOLD     the last stage group folds its tile itself (one private buffer, no mixer wavefront)
+//   PIPE_INPLACE  the last stage group writes its tile over the one it read (it holds the whole tile in registers by then),
+//                 and a mixer wavefront folds it one step later; the edge into the last group is triple-buffered for that.
+//                 As many tiles as PIPE_FOLD, so the long tiles fit, and the fold runs on the CU's fourth SIMD instead of
+//                 in the busiest wavefront.
+enum { PIPE_MIXER = 0, PIPE_FOLD = 1, PIPE_INPLACE = 2 };
+template <int MODE, int NG> struct EdgeMap {
+  static_assert(MODE != PIPE_INPLACE || NG >= 2, "an in-place last group reads an edge");
+  static constexpr int tiles = MODE == PIPE_MIXER ? NG * 2 : NG * 2 - 1;
+  // the buffer (in tiles) group I writes its global tile g to / reads it from
+  static __device__ __forceinline__ int out_tile(int I, int g) {
+    if (MODE == PIPE_FOLD && I == NG - 1) return I * 2;
+    if (MODE == PIPE_INPLACE && I >= NG - 2) return (NG - 2) * 2 + g % 3;
+    return I * 2 + (g & 1);
+  }
+  static __device__ __forceinline__ int in_tile(int I, int g) { return I > 0 ? out_tile(I - 1, g) : 0; }
+  static __device__ __forceinline__ int mixer_tile(int g) { return out_tile(NG - 1, g); }
+};
 template <typename F> struct PipeShared {
   float* sine;
-  F* edge;  // [NG][2][64][stride]; edge i carries group i's output, the last one to the mixer (FOLD: one private buffer)
+  F* edge;  // tiles of [64][stride]; edge i carries group i's output: EdgeMap says which tile holds what
   // The workgroup's piece of the launch's event list (contiguous: the list is sorted by voice), copied into spare LDS at
   // kernel start when it fits: applying an event is then an LDS read, not a round trip to pinned host memory (~1 us,
   // during which the wave -- and at the next barrier its whole pipeline -- stands still).  ev_lds_n == 0: read in place.
@@ -83,13 +103,14 @@ __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelA
 
 // One stage group = one wavefront.  I: group index, NG: number of chain groups (mixer excluded),
 // LAST_ENV: index of the group holding the chain's last envelope stage (-1: none).
-// FOLD: the last group also folds its tile over the voices (what pipe_run_mixer does in a wavefront of its own
+// MODE PIPE_FOLD: the last group also folds its tile over the voices (what pipe_run_mixer does in a wavefront of its own
 // otherwise): it stores the tile in a buffer no other wavefront touches and reads it back column-wise.
-template <typename F, bool FMA, int T, bool FOLD, int NG, int I, int BASE, int LAST_ENV, typename G>
+template <typename F, bool FMA, int T, int MODE, int NG, int I, int BASE, int LAST_ENV, typename G>
 __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv, int fan_i) {
   typedef typename GroupChain<F, FMA, BASE, G>::type ChainT;
   typedef typename WordOf<F>::type W;
-  constexpr bool FOLDS = FOLD && I == NG - 1;
+  constexpr bool FOLDS = MODE == PIPE_FOLD && I == NG - 1;
+  typedef EdgeMap<MODE, NG> Map;
   // A Fan group's wavefront works on a WINDOW of every tile: TW samples starting fo samples into it (an ordinary group's
   // window is the tile).  Everything below -- the register tile, the event paths, the LDS rows -- is per window.
   constexpr int KF = GroupInfo<G>::fan_for(T);
@@ -156,7 +177,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   const u32 n_frames = a.frame_end - a.frame_begin;
   const int tpb = (int)((n_frames + T - 1) / T);           // tiles per block
   const int n_tiles = tpb * (int)a.n_blocks;
-  const int n_steps = n_tiles + NG - (FOLD ? 1 : 0);
+  const int n_steps = n_tiles + NG - (MODE == PIPE_FOLD ? 1 : 0);
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   int blk = 0, ti = 0;                                      // position of this group's next tile
 #ifdef KNH_DAG_STAMPS  // diagnostic build only: cycles this wavefront is busy per tile (tools/pipe_stamps.py)
@@ -173,7 +194,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       if (I > 0) {
         typedef typename EdgeLayout<F, T>::Vec Vec;
         constexpr int VW = EdgeLayout<F, T>::VW;
-        const Vec* in = reinterpret_cast<const Vec*>(sh.edge + (long)((I - 1) * 2 + (g & 1)) * EdgeLayout<F, T>::tile +
+        const Vec* in = reinterpret_cast<const Vec*>(sh.edge + (long)Map::in_tile(I, g) * EdgeLayout<F, T>::tile +
                                                      (long)lane * EdgeLayout<F, T>::stride + fo);
 #pragma unroll
         for (int j = 0; j < TW / VW; ++j) {
@@ -205,7 +226,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       {  // every group, the last one included, hands its tile on as 64 rows of T samples
         typedef typename EdgeLayout<F, T>::Vec Vec;
         constexpr int VW = EdgeLayout<F, T>::VW;
-        F* out_tile = sh.edge + (long)(I * 2 + (FOLDS ? 0 : (g & 1))) * EdgeLayout<F, T>::tile;
+        F* out_tile = sh.edge + (long)Map::out_tile(I, g) * EdgeLayout<F, T>::tile;
         F* out_row = out_tile + (long)lane * EdgeLayout<F, T>::stride + fo;
         if (__builtin_expect(m == (u32)TW && !__builtin_amdgcn_ballot_w64(ev_inside), 1)) {  // (the cold paths out of line: one instruction cache for all roles)
           chain.template tick_tile<TW>(x, ctx, n);
@@ -267,7 +288,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
           }
           // eight samples at a time, row to row in LDS (a run-time loop, like the general path: keeps this rare path small
           // and the register tile of the fast path out of it)
-          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride + fo;
+          const F* in_row = sh.edge + (long)Map::in_tile(I, g) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride + fo;
           for (u32 j0 = 0; j0 < (u32)TW; j0 += 8u) {
             F sub[8];
             if (I > 0) {
@@ -297,7 +318,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
           // the tile is a partial one at the end of a block: it is walked eight samples at a time, row to row in LDS (a
           // run-time loop: the register tile above is never indexed by a run-time value, which would put all of it, the
           // fast path's too, in scratch memory), sample by sample with the changes applied in front of their frame.
-          const F* in_row = sh.edge + (long)((I > 0 ? I - 1 : 0) * 2 + (g & 1)) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride + fo;
+          const F* in_row = sh.edge + (long)Map::in_tile(I, g) * EdgeLayout<F, T>::tile + (long)lane * EdgeLayout<F, T>::stride + fo;
           for (u32 j0 = 0; j0 < m; j0 += 8u) {
             const u32 cnt = m - j0 < 8u ? m - j0 : 8u;
             F sub[8];
@@ -454,7 +475,7 @@ __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelA
 }
 
 // The mixer wavefront: folds the tile the last chain group finished in the previous step.
-template <typename F, bool FMA, int T, int NG, bool PAN>
+template <typename F, bool FMA, int T, int MODE, int NG, bool PAN>
 __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global,
                                                u32 v0, u32 nv) {
   const u32 n_frames = a.frame_end - a.frame_begin;
@@ -474,7 +495,7 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
 #endif
       const u32 rel = (u32)ti * T;
       const u32 len = n_frames - rel < (u32)T ? n_frames - rel : (u32)T;
-      const F* tile = sh.edge + (long)((NG - 1) * 2 + (g & 1)) * EdgeLayout<F, T>::tile;
+      const F* tile = sh.edge + (long)EdgeMap<MODE, NG>::mixer_tile(g) * EdgeLayout<F, T>::tile;
       pipe_fold_tile<F, FMA, T, PAN>(tile, a, lane, wave_global, n_waves_total, blk, a.frame_begin + rel, len, v0, nv);
       if (++ti == tpb) { ti = 0; ++blk; }
 #ifdef KNH_DAG_STAMPS
@@ -490,18 +511,18 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
 }
 
 // W0: the first wavefront of group I (a Fan group takes several)
-template <typename F, bool FMA, int T, bool FOLD, int NG, int I, int BASE, int W0, int LAST_ENV, typename G, typename... Rest>
+template <typename F, bool FMA, int T, int MODE, int NG, int I, int BASE, int W0, int LAST_ENV, typename G, typename... Rest>
 __device__ __forceinline__ u32 pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv) {
   constexpr int KF = GroupInfo<G>::fan_for(T);
-  if (wave >= W0 && wave < W0 + KF) return pipe_run_group<F, FMA, T, FOLD, NG, I, BASE, LAST_ENV, G>(sh, a, lane, wave_global, v0, nv, wave - W0);
+  if (wave >= W0 && wave < W0 + KF) return pipe_run_group<F, FMA, T, MODE, NG, I, BASE, LAST_ENV, G>(sh, a, lane, wave_global, v0, nv, wave - W0);
   if constexpr (sizeof...(Rest) > 0)
-    return pipe_dispatch<F, FMA, T, FOLD, NG, I + 1, BASE + GroupInfo<G>::slots, W0 + KF, LAST_ENV, Rest...>(wave, sh, a, lane, wave_global, v0, nv);
+    return pipe_dispatch<F, FMA, T, MODE, NG, I + 1, BASE + GroupInfo<G>::slots, W0 + KF, LAST_ENV, Rest...>(wave, sh, a, lane, wave_global, v0, nv);
   return 0xFFFFFFFFu;
 }
 // wavefronts of a pipeline: one per group (K per Fan group), plus the mixer unless the last group folds
-template <int T, bool FOLD, typename... Gs> struct PipeWaves {
+template <int T, int MODE, typename... Gs> struct PipeWaves {
   static constexpr int chain = (0 + ... + GroupInfo<Gs>::fan_for(T));
-  static constexpr int value = chain + (FOLD ? 0 : 1);
+  static constexpr int value = chain + (MODE == PIPE_FOLD ? 0 : 1);
 };
 
 template <int I, typename... Gs> struct LastEnv;
@@ -511,19 +532,20 @@ template <int I, typename G, typename... Rest> struct LastEnv<I, G, Rest...> {
   static constexpr int value = later >= 0 ? later : (GroupInfo<G>::has_env ? I : -1);
 };
 
-// One workgroup = 64 voices = one wavefront per stage group (K for a Fan group) + the mixer, or without it with FOLD.
-template <typename F, bool FMA, int T, bool FOLD, typename... Gs>
-__global__ void __launch_bounds__((PipeWaves<T, FOLD, Gs...>::value * 64)) voice_pipe_kernel(VoiceKernelArgs<F> a) {
+// One workgroup = 64 voices = one wavefront per stage group (K for a Fan group) + the mixer, or without it with PIPE_FOLD.
+template <typename F, bool FMA, int T, int MODE, typename... Gs>
+__global__ void __launch_bounds__((PipeWaves<T, MODE, Gs...>::value * 64)) voice_pipe_kernel(VoiceKernelArgs<F> a) {
   constexpr int NG = (int)sizeof...(Gs);
-  constexpr int CHAINW = PipeWaves<T, FOLD, Gs...>::chain;  // wavefronts that run stage groups
-  constexpr int WAVES = PipeWaves<T, FOLD, Gs...>::value;
+  constexpr int CHAINW = PipeWaves<T, MODE, Gs...>::chain;  // wavefronts that run stage groups
+  constexpr int WAVES = PipeWaves<T, MODE, Gs...>::value;
   static_assert(T <= 64 && T % 8 == 0, "a tile column per lane of the folding wavefront");
   constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
   __shared__ float sine[kSine ? 16384 : 1];
-  // the last edge feeds the mixer; with FOLD it is one buffer private to the last group
-  __shared__ __attribute__((aligned(16))) F edge[(NG * 2 - (FOLD ? 1 : 0)) * EdgeLayout<F, T>::tile];
+  // the last edge feeds the mixer; with PIPE_FOLD it is one buffer private to the last group, with PIPE_INPLACE there is none
+  // (the edge before it has three buffers instead)
+  __shared__ __attribute__((aligned(16))) F edge[EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile];
   // what is left of the CU's 160 KiB holds the workgroup's events (16 bytes each), up to 2 048 of them
-  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 1) - (long)sizeof(F) * (NG * 2 - (FOLD ? 1 : 0)) * EdgeLayout<F, T>::tile;
+  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 1) - (long)sizeof(F) * EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile;
 #ifndef KNH_EVCAP_MAX
 #define KNH_EVCAP_MAX 2048
 #endif
@@ -563,8 +585,8 @@ __global__ void __launch_bounds__((PipeWaves<T, FOLD, Gs...>::value * 64)) voice
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
   u32 done_frame = 0xFFFFFFFFu;
   constexpr bool kPan = (false || ... || GroupInfo<Gs>::pan);
-  if (wave == CHAINW) pipe_run_mixer<F, FMA, T, NG, kPan>(sh, a, lane, wave_global, v0, nv);
-  else done_frame = pipe_dispatch<F, FMA, T, FOLD, NG, 0, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
+  if (wave == CHAINW) pipe_run_mixer<F, FMA, T, MODE, NG, kPan>(sh, a, lane, wave_global, v0, nv);
+  else done_frame = pipe_dispatch<F, FMA, T, MODE, NG, 0, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
   // mark_done of a voice = that of the last node in task order that set one: combine the groups in chain order
   constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);
   if constexpr (kAnyEnv) {

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 FORMS = {  # environment switches read by knh_bank_create / knh_bank_init
     "pipe64": {"KNH_PIPELINE": "1", "KNH_PIPE_BIG": "1"},
+    "pipe64inplace": {"KNH_PIPELINE": "1", "KNH_PIPE_BIG": "2"},
     "pipe32": {"KNH_PIPELINE": "1", "KNH_PIPE_BIG": "0"},
     "single": {"KNH_PIPELINE": "0"},
     "wide4": {"KNH_PIPELINE": "0", "KNH_WIDE": "4"},

@@ -77,12 +77,13 @@ def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pip
                                                       ("D3", 500, 512), ("B3", 300, 256)])
 def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
     """KNH_PIPELINE 0 = one wavefront per 64 voices, 1 = linear wave pipeline, 2 = five-role pipeline where built;
-    "1big" = the linear pipeline with 64-sample tiles and the fold in its last stage group (KNH_PIPE_BIG=1, where built)."""
+    "1big" = the linear pipeline with 64-sample tiles and the fold in its last stage group (KNH_PIPE_BIG=1, where built);
+    "1inplace" = 64-sample tiles, the last stage group works in place and a mixer wavefront folds (the default where built)."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
     outs = {}
-    for pipeline in ("0", "1", "2", "1big"):
+    for pipeline in ("0", "1", "2", "1big", "1inplace"):
         monkeypatch.setenv("KNH_PIPELINE", pipeline[0])
-        monkeypatch.setenv("KNH_PIPE_BIG", "1" if pipeline.endswith("big") else "0")
+        monkeypatch.setenv("KNH_PIPE_BIG", "1" if pipeline.endswith("big") else ("2" if pipeline.endswith("inplace") else "0"))
         g = make_gpu(knh, w)
         res = []
         for block in range(6):
@@ -96,7 +97,7 @@ def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_vo
             res.append((out, voices, flags, g.read_done_frames()))
         outs[pipeline] = res
         g.close()
-    for other in ("1", "2", "1big"):
+    for other in ("1", "2", "1big", "1inplace"):
         for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["0"], outs[other]):
             assert_bit_equal(v0, v1, f"per-voice, pipeline {other}")
             assert_bit_equal(o0, o1, f"mix, pipeline {other}")

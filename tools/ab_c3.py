@@ -72,11 +72,20 @@ def run(libt, h, w, launches):
 
 
 def main():
-    paths = sys.argv[1:3]
+    # "lib.so@KNH_PIPE_BIG=1": that environment switch is set while the bank of that side is created (the library reads its
+    # switches in knh_bank_create / knh_bank_init), so two forms of one build can be compared too
+    specs = [a.split("@") for a in sys.argv[1:3]]
+    paths = [sp[0] for sp in specs]
     name = sys.argv[3] if len(sys.argv) > 3 else "C3"
     w = configs.config(name)
     libs = [open_lib(p) for p in paths]
-    banks = [make(l, w) for l in libs]
+    banks = []
+    for l, sp in zip(libs, specs):
+        sets = dict(kv.split("=", 1) for kv in sp[1:])
+        os.environ.update(sets)
+        banks.append(make(l, w))
+        for k in sets:
+            del os.environ[k]
     for l, h in zip(libs, banks):
         run(l, h, w, 200)  # clocks up, both warmed
     for rnd in range(4):
@@ -85,7 +94,7 @@ def main():
             run(l, h, w, 100)
             ms, cnt = C.c_double(0), C.c_uint64(0)
             l[0].knh_bank_timing_read(h, C.byref(ms), C.byref(cnt))
-            print(f"round {rnd} {tag} ({os.path.basename(paths['AB'.index(tag)])}): {ms.value / max(cnt.value, 1):.4f} ms per 64-block launch", flush=True)
+            print(f"round {rnd} {tag} ({os.path.basename(sys.argv[1 + 'AB'.index(tag)])}): {ms.value / max(cnt.value, 1):.4f} ms per 64-block launch", flush=True)
     for l, h in zip(libs, banks):
         l[0].knh_bank_destroy(h)
 
