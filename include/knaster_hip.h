@@ -246,11 +246,12 @@ typedef struct knh_stage_desc {
 
 /* How the N per-voice signals are folded into the output block. */
 typedef enum knh_mix_mode {
-  /* Deterministic three-level fold: left fold over each wavefront's 64 voices in
-   * voice order, left fold over each group of 16 consecutive wavefront partials,
-   * left fold over the group results.  Same result on every run; differs from the
-   * reference's single left fold only by f32 reassociation (bounded; see
-   * DESIGN.md "mixdown"). */
+  /* Pairwise sum in voice order, a binary tree over the voice index: level by level
+   * neighbours are added in pairs (v0+v1, v2+v3, ...), a node without a right
+   * neighbour passes through unchanged.  The order of the additions depends on the
+   * number of voices only (not on the kernel form, the grouping of voices into
+   * wavefronts or the device): same result on every run; differs from the reference's
+   * single left fold only by reassociation (bounded; see DESIGN.md "mixdown"). */
   KNH_MIX_TREE = 0,
   /* Bit-exact reference order ((v0+v1)+v2)+... in sample precision
    * (knaster_graph/src/graph.rs:827-872).  Serial in the voice axis: slower. */

@@ -32,8 +32,27 @@ static hipError_t launch_pipe_wide_tile(const VoiceKernelArgs<F>& args, unsigned
 #define KNH_PIPE_AS(sig, n, form, ...)                                                               \
   {sig, n, form, {launch_pipe<float, false, form, __VA_ARGS__>, launch_pipe<float, true, form, __VA_ARGS__>}, \
    {launch_pipe<double, false, form, __VA_ARGS__>, launch_pipe<double, true, form, __VA_ARGS__>}}
-#define KNH_PIPE(sig, n, ...) KNH_PIPE_AS(sig, n, PIPE_MIXER, __VA_ARGS__)
-#define KNH_PIPE_BIG(sig, n, ...) KNH_PIPE_AS(sig, n, PIPE_INPLACE, __VA_ARGS__), KNH_PIPE_AS(sig, n, PIPE_FOLD, __VA_ARGS__)
+// This file is compiled once per form (KNH_PIPE_PART = PIPE_MIXER, PIPE_FOLD, PIPE_INPLACE: build.py), each time with the
+// table of that form's kernels; find_pipe() lives in the PIPE_MIXER part and looks through all three.
+#ifndef KNH_PIPE_PART
+#error "KNH_PIPE_PART: 0, 1 or 2 (knaster_amd/build.py)"
+#endif
+#if KNH_PIPE_PART == 0
+#define KNH_PIPE(sig, n, ...) KNH_PIPE_AS(sig, n, PIPE_MIXER, __VA_ARGS__),
+#define KNH_PIPE_BIG(sig, n, ...)
+#define KNH_PIPE_FAN_(sig, n, ...) KNH_PIPE_FAN(sig, n, __VA_ARGS__),
+#define KNH_PIPE_TABLE pipes_mixer
+#elif KNH_PIPE_PART == 1
+#define KNH_PIPE(sig, n, ...)
+#define KNH_PIPE_BIG(sig, n, ...) KNH_PIPE_AS(sig, n, PIPE_FOLD, __VA_ARGS__),
+#define KNH_PIPE_FAN_(sig, n, ...)
+#define KNH_PIPE_TABLE pipes_fold
+#else
+#define KNH_PIPE(sig, n, ...)
+#define KNH_PIPE_BIG(sig, n, ...) KNH_PIPE_AS(sig, n, PIPE_INPLACE, __VA_ARGS__),
+#define KNH_PIPE_FAN_(sig, n, ...)
+#define KNH_PIPE_TABLE pipes_inplace
+#endif
 
 typedef Group<SinWt, MulVal> G_Wm;
 typedef Group<SinWt> G_W;
@@ -53,29 +72,44 @@ typedef Group<PolyBlepOsc, MulVal> G_Bm;
 typedef Group<MulAr, Pan2> G_E2;
 typedef Group<MulAsr, Pan2> G_A2;
 
-static const PipeEntry kPipes[] = {
-    KNH_PIPE_BIG("WmSA", 3, G_Wm, G_S, G_A),   // C3/C4: oscillator | filter | envelope + fold, 64-sample tiles
-    KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A),       // the same with 32-sample tiles and a mixer wavefront (KNH_PIPE_BIG=0)
-    KNH_PIPE_BIG("WSAm", 3, G_W, G_S, G_Am),
-    KNH_PIPE("WSAm", 3, G_W, G_S, G_Am),
-    KNH_PIPE_BIG("WSA", 3, G_W, G_S, G_A),
-    KNH_PIPE("WSA", 3, G_W, G_S, G_A),
-    KNH_PIPE("WS", 2, G_W, G_S),
-    KNH_PIPE("WmaRm", 2, G_Wma, G_Rm),     // C5: modulator | carrier
-    KNH_PIPE_FAN("Nm", 2, G_Np, F_Nm),     // C2: phase | sin * gain on eight wavefronts | mixer
-    KNH_PIPE_FAN("N", 2, G_Np, F_N),
-    KNH_PIPE("NSAm", 3, G_N, G_S, G_Am),
-    KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA),  // the delay's HBM traffic rides in the envelope wave
-    KNH_PIPE("BmSA", 3, G_Bm, G_S, G_A),
-    KNH_PIPE_BIG("WmEJ", 2, G_Wm, G_E2),     // many_sines: oscillator | envelope + pan + fold
-    KNH_PIPE("WmEJ", 2, G_Wm, G_E2),
-    KNH_PIPE_BIG("WmSAJ", 3, G_Wm, G_S, G_A2),
-    KNH_PIPE("WmSAJ", 3, G_Wm, G_S, G_A2),
+// (host-only tables: a namespace-scope constant with external linkage would be emitted for the device too)
+const PipeEntry* pipes_mixer(int* n);
+const PipeEntry* pipes_fold(int* n);
+const PipeEntry* pipes_inplace(int* n);
+static const PipeEntry kTable[] = {
+    KNH_PIPE_BIG("WmSA", 3, G_Wm, G_S, G_A)   // C3/C4: oscillator | filter | envelope (+ fold), 64-sample tiles
+    KNH_PIPE("WmSA", 3, G_Wm, G_S, G_A)       // the same with 32-sample tiles and a mixer wavefront (KNH_PIPE_BIG=0)
+    KNH_PIPE_BIG("WSAm", 3, G_W, G_S, G_Am)
+    KNH_PIPE("WSAm", 3, G_W, G_S, G_Am)
+    KNH_PIPE_BIG("WSA", 3, G_W, G_S, G_A)
+    KNH_PIPE("WSA", 3, G_W, G_S, G_A)
+    KNH_PIPE("WS", 2, G_W, G_S)
+    KNH_PIPE("WmaRm", 2, G_Wma, G_Rm)     // C5: modulator | carrier
+    KNH_PIPE_FAN_("Nm", 2, G_Np, F_Nm)    // C2: phase | sin * gain on eight wavefronts | mixer
+    KNH_PIPE_FAN_("N", 2, G_Np, F_N)
+    KNH_PIPE("NSAm", 3, G_N, G_S, G_Am)
+    KNH_PIPE("WmSDA", 3, G_Wm, G_S, G_DA)  // the delay's HBM traffic rides in the envelope wave
+    KNH_PIPE("BmSA", 3, G_Bm, G_S, G_A)
+    KNH_PIPE_BIG("WmEJ", 2, G_Wm, G_E2)     // many_sines: oscillator | envelope + pan (+ fold)
+    KNH_PIPE("WmEJ", 2, G_Wm, G_E2)
+    KNH_PIPE_BIG("WmSAJ", 3, G_Wm, G_S, G_A2)
+    KNH_PIPE("WmSAJ", 3, G_Wm, G_S, G_A2)
 };
+const PipeEntry* KNH_PIPE_TABLE(int* n) {
+  *n = (int)(sizeof(kTable) / sizeof(kTable[0]));
+  return kTable;
+}
+#if KNH_PIPE_PART == 0
 const PipeEntry* find_pipe(const char* signature, unsigned forms) {
-  for (const PipeEntry& e : kPipes)
-    if (std::strcmp(e.signature, signature) == 0 && ((forms >> e.form) & 1u)) return &e;
+  const PipeEntry* (*const tables[])(int*) = {pipes_inplace, pipes_fold, pipes_mixer};  // preferred form first
+  for (auto table : tables) {
+    int n = 0;
+    const PipeEntry* e = table(&n);
+    for (int i = 0; i < n; ++i)
+      if (std::strcmp(e[i].signature, signature) == 0 && ((forms >> e[i].form) & 1u)) return &e[i];
+  }
   return nullptr;
 }
+#endif
 
 }  // namespace knh

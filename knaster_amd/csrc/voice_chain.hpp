@@ -1442,7 +1442,8 @@ struct SampleDelay : StageDefaults {
     if (rp >= r.len) rp -= r.len;
     // delay >= T  <=>  off <= len - T;  neither the T stores nor the T loads may cross the end of the ring
     const bool dead = r.len == 0u;  // a lane past the last voice: takes part in nothing
-    const bool vec_ok = dead || (r.len >= (u32)T && r.off <= r.len - (u32)T && r.wp <= r.len - (u32)T && rp <= r.len - (u32)T);
+    // (off == 0 is a delay of 0 or of the whole ring: the sample just stored comes straight back -- tick() forwards it)
+    const bool vec_ok = dead || (r.len >= (u32)T && r.off != 0u && r.off <= r.len - (u32)T && r.wp <= r.len - (u32)T && rp <= r.len - (u32)T);
     if (__builtin_amdgcn_ballot_w64(!vec_ok) == 0) {
       // Large tiles (the pipelined kernels, one wavefront per SIMD: nothing else hides HBM latency) are read one
       // tile ahead: this tile comes out of registers filled during the previous one, and the next tile's loads go
@@ -2003,7 +2004,7 @@ struct VoiceKernelArgs {
   u32 in_channels;
   const u32* ev_start;              // [n_voices + 1] or null when the block has no events
   const Event* events;
-  F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its 64 voices
+  F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its voices
                                     // (chains ending in Pan2: [n_blocks][2][n_waves][block_size], left and right)
   F* voices_out;                    // [n_voices][block_size] or null (n_blocks == 1 only); Pan2 chains: [2][n_voices][block_size]
   u32* done_frames;                 // [n_voices]
@@ -2012,6 +2013,73 @@ struct VoiceKernelArgs {
 
 constexpr int kWave = 64;
 constexpr int kTile = 8;  // samples evaluated stage-by-stage in registers
+
+// ---------------------------------------------------------------------------
+// KNH_MIX_TREE: the voices of a bank are summed pairwise, in voice order -- a binary tree over the voice index:
+//   node(0, v) = voice v;  node(L, i) = node(L-1, 2i) + node(L-1, 2i+1), or node(L-1, 2i) alone where 2i+1 does not exist.
+// The order of the additions depends on the number of voices only, not on the kernel form.  A wavefront folds the subtree
+// of its own 64 voices and fold_tree_kernel continues from those nodes upwards.
+// ---------------------------------------------------------------------------
+// t[0..N): nodes of one level, each standing for `unit` voices, the first of them voice 0 of the subtree; nv = voices that
+// exist in it.  FULL: all of them do.
+template <typename F, int N, bool FULL>
+__device__ __forceinline__ F tree_reduce(F (&t)[N], u32 unit, u32 nv) {
+  static_assert((N & (N - 1)) == 0, "a power of two");
+#pragma unroll
+  for (int w = N, step = 1; w > 1; w >>= 1, step <<= 1) {
+#pragma unroll
+    for (int i = 0; i < w / 2; ++i) {
+      const F sum = t[2 * i] + t[2 * i + 1];
+      t[i] = (FULL || (u32)((2 * i + 1) * step) * unit < nv) ? sum : t[2 * i];  // the right child exists: its first voice does
+    }
+  }
+  return t[0];
+}
+// the subtree over col[0], col[st], .. col[(N - 1) st]; the values are read B at a time (B = N: all reads ahead of all adds)
+template <typename F, int N, bool FULL, int B>
+__device__ __forceinline__ F tree_cols(const F* col, int st, u32 nv) {
+  constexpr int BB = B < N ? B : N;
+  F node[N / BB];
+#pragma unroll
+  for (int c = 0; c < N / BB; ++c) {
+    F t[BB];
+#pragma unroll
+    for (int k = 0; k < BB; ++k) t[k] = col[(c * BB + k) * st];
+    node[c] = tree_reduce<F, BB, FULL>(t, 1u, nv > (u32)(c * BB) ? nv - (u32)(c * BB) : 0u);
+  }
+  return tree_reduce<F, N / BB, FULL>(node, (u32)BB, nv);
+}
+// Pan2: the subtrees over col[k st] * gl[k gst] and over col[k st] * gr[k gst] (pan.rs:36: the product is rounded, then summed)
+template <typename F, int N, bool FULL, int B>
+__device__ __forceinline__ void tree_cols_pan(const F* col, int st, const F* gl, const F* gr, int gst, u32 nv, F& left, F& right) {
+  constexpr int BB = B < N ? B : N;
+  F nl[N / BB], nr[N / BB];
+#pragma unroll
+  for (int c = 0; c < N / BB; ++c) {
+    F t[BB], p[BB];
+#pragma unroll
+    for (int k = 0; k < BB; ++k) t[k] = col[(c * BB + k) * st];
+    const u32 sub = nv > (u32)(c * BB) ? nv - (u32)(c * BB) : 0u;
+#pragma unroll
+    for (int k = 0; k < BB; ++k) p[k] = t[k] * gl[(c * BB + k) * gst];
+    nl[c] = tree_reduce<F, BB, FULL>(p, 1u, sub);
+#pragma unroll
+    for (int k = 0; k < BB; ++k) p[k] = t[k] * gr[(c * BB + k) * gst];
+    nr[c] = tree_reduce<F, BB, FULL>(p, 1u, sub);
+  }
+  left = tree_reduce<F, N / BB, FULL>(nl, (u32)BB, nv);
+  right = tree_reduce<F, N / BB, FULL>(nr, (u32)BB, nv);
+}
+// a wavefront's 64 voices, nv of them live
+template <typename F, int B>
+__device__ __forceinline__ F fold_group(const F* col, int st, u32 nv) {
+  return nv == 64u ? tree_cols<F, 64, true, B>(col, st, nv) : tree_cols<F, 64, false, B>(col, st, nv);
+}
+template <typename F, int B>
+__device__ __forceinline__ void fold_group_pan(const F* col, int st, const F* gl, const F* gr, int gst, u32 nv, F& l, F& r) {
+  if (nv == 64u) tree_cols_pan<F, 64, true, B>(col, st, gl, gr, gst, nv, l, r);
+  else tree_cols_pan<F, 64, false, B>(col, st, gl, gr, gst, nv, l, r);
+}
 
 // LDS: sine table (64 KiB, only if a stage uses it) + one [TN][68] transpose tile per wave.
 // WAVES = wavefronts (64-voice groups) per workgroup sharing the table: 1 for small banks, 4 or 8 when
@@ -2125,39 +2193,18 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if constexpr (!ChainT::kPan) {
-        if ((u32)lane < len) {
-          F acc;
-          if (nv == 64u) {  // full wavefront: 16 LDS reads in flight ahead of the serial adds
-#pragma unroll
-            for (int vb = 0; vb < 64; vb += 16) {
-              F t[16];
-#pragma unroll
-              for (int k = 0; k < 16; ++k) t[k] = my[lane][vb + k];
-              if (vb == 0) acc = t[0];
-#pragma unroll
-              for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
-            }
-          } else {
-            acc = my[lane][0];
-            for (u32 v = 1; v < nv; ++v) acc = acc + my[lane][v];
-          }
-          partial_row[n0 + lane] = acc;
-        }
+        if ((u32)lane < len) partial_row[n0 + lane] = fold_group<F, 16>(&my[lane][0], 1, nv);
         if (a.voices_out) {
           for (u32 v = 0; v < nv; ++v)
             if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[lane][v];
         }
       } else {
-        // Pan2: each voice's sample times its two gains (two roundings, then the adds: pan.rs:36 and the Add chain)
+        // Pan2: each voice's sample times its two gains (pan.rs:36), then one sum per channel
         if ((u32)lane < len) {
           const F* gl = pan_gain[wave][0];
           const F* gr = pan_gain[wave][1];
-          F accl = my[lane][0] * gl[0], accr = my[lane][0] * gr[0];
-          for (u32 v = 1; v < nv; ++v) {
-            const F t = my[lane][v];
-            accl = mad<FMA>(t, gl[v], accl);
-            accr = mad<FMA>(t, gr[v], accr);
-          }
+          F accl, accr;
+          fold_group_pan<F, 16>(&my[lane][0], 1, gl, gr, 1, nv, accl, accr);
           F* pl = a.partials + (((long)b * 2 + 0) * n_waves_total + wave_global) * a.block_size;
           F* pr = a.partials + (((long)b * 2 + 1) * n_waves_total + wave_global) * a.block_size;
           pl[n0 + lane] = accl;
@@ -2223,55 +2270,61 @@ __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows
   }
 }
 
-// Deterministic tree fold of the per-wavefront partial rows (KNH_MIX_TREE):
-//   level 2: left fold of each group of 16 consecutive rows; level 3: left fold of the group results.
-// One 256-thread workgroup handles 16 frames: thread (g, f) folds group g (+16, +32, ...) for frame f.
+// KNH_MIX_TREE, from the per-wavefront rows upwards: the rows are consecutive nodes of one level of the tree described at
+// tree_reduce, and the same rule goes on -- pairs of neighbours, a node without a right neighbour passes through.
+// One 256-thread workgroup handles 16 frames: thread (g, f) folds the 16 rows [256 p + 16 g, + 16) of pass p (four levels,
+// in registers), thread (0, f) the 16 results of the pass (four more), and the passes' results meet on a small stack in
+// LDS the way a binary counter carries (pass k merges with as many finished neighbours as k has trailing one bits).
 template <typename F>
 __global__ void __launch_bounds__(256) fold_tree_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
                                                          u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate, u32* zero_flags) {
   __shared__ F part[16][17];
+  __shared__ F stack[32][16];
   if (zero_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { zero_flags[0] = 0u; zero_flags[1] = 0u; }  // see fold_rows_kernel
   rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
   out += (long)blockIdx.y * channels * out_stride;
   const u32 f = threadIdx.x & 15u, g = threadIdx.x >> 4;
   const u32 n = frame_begin + blockIdx.x * 16u + f;
   const bool in_range = n < frame_end;
-  const u32 n_groups = (n_rows + 15u) / 16u;
-  F total = (F)0;
-  for (u32 g0 = 0; g0 < n_groups; g0 += 16) {  // 256 groups of rows at a time
-    const u32 grp = g0 + g;
+  u32 depth = 0;
+  const u32 n_pass = (n_rows + 255u) / 256u;
+  for (u32 p = 0; p < n_pass; ++p) {
+    const u32 r0 = p * 256u + g * 16u;
     F acc = (F)0;
-    if (in_range && grp < n_groups) {
-      const u32 r0 = grp * 16u;
+    if (in_range && r0 < n_rows) {
       const u32 cnt = n_rows - r0 < 16u ? n_rows - r0 : 16u;
-      const F* p = rows + (long)r0 * row_len + n;
-      if (cnt == 16u) {
-        F v[16];
+      const F* q = rows + (long)r0 * row_len + n;
+      F v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = p[(long)k * row_len];
-        acc = v[0];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) acc = acc + v[k];
-      } else {
-        acc = p[0];
-        for (u32 k = 1; k < cnt; ++k) acc = acc + p[(long)k * row_len];
-      }
+      for (int k = 0; k < 16; ++k) v[k] = (u32)k < cnt ? q[(long)k * row_len] : (F)0;
+      acc = cnt == 16u ? tree_reduce<F, 16, true>(v, 1u, 16u) : tree_reduce<F, 16, false>(v, 1u, cnt);
     }
     part[g][f] = acc;
     __syncthreads();
     if (g == 0 && in_range) {
-      const u32 m = n_groups - g0 < 16u ? n_groups - g0 : 16u;
-      u32 k = 0;
-      if (g0 == 0) { total = part[0][f]; k = 1; }
-      for (; k < m; ++k) total = total + part[k][f];
+      const u32 left = n_rows - p * 256u;                      // rows of this pass and later ones
+      const u32 chunks = left >= 256u ? 16u : (left + 15u) / 16u;
+      F c[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) c[k] = part[k][f];
+      const F node = chunks == 16u ? tree_reduce<F, 16, true>(c, 1u, 16u) : tree_reduce<F, 16, false>(c, 1u, chunks);
+      stack[depth++][f] = node;
+      for (u32 m = p + 1u; (m & 1u) == 0u; m >>= 1) {  // p has a trailing one bit: its left neighbour of that level is on the stack
+        stack[depth - 2][f] = stack[depth - 2][f] + stack[depth - 1][f];
+        --depth;
+      }
     }
     __syncthreads();
   }
-  if (g == 0 && in_range)
+  if (g == 0 && in_range) {
+    // what is left are nodes of falling level, left to right: each passes through until it meets its left neighbour
+    F total = stack[depth - 1][f];
+    for (u32 d = depth - 1; d > 0; --d) total = stack[d - 1][f] + total;
     for (u32 c = 0; c < channels; ++c) {
       F* o = out + (long)c * out_stride + n;
       *o = accumulate ? *o + total : total;
     }
+  }
 }
 
 }  // namespace knh_dev

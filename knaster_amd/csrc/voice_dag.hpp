@@ -397,21 +397,7 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
                   const u32 n0 = a.frame_begin + q * TN;
                   if ((u32)lane < len) {
                     const F* row = my + (long)lane * TS;
-                    F acc;
-                    if (nv == 64u) {
-#pragma unroll
-                      for (int vb = 0; vb < 64; vb += 16) {
-                        F t[16];
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) t[k] = row[vb + k];
-                        if (vb == 0) acc = t[0];
-#pragma unroll
-                        for (int k = (vb == 0 ? 1 : 0); k < 16; ++k) acc = acc + t[k];
-                      }
-                    } else {
-                      acc = row[0];
-                      for (u32 v = 1; v < nv; ++v) acc = acc + row[v];
-                    }
+                    const F acc = fold_group<F, 16>(row, 1, nv);
                     a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
                   }
                   if (a.voices_out) {

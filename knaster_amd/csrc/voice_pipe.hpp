@@ -407,9 +407,9 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   return done_frame;
 }
 
-// Lane j folds frame j of a finished tile over the wave's voices, in voice order (a left fold, like the reference's
-// chain of Add nodes over those voices).  The tile is stored voice-major ([voice][T], the common edge format), so a
-// read of one voice's row by lanes 0..T-1 is conflict-free and the transposition costs nothing.
+// Lane j folds frame j of a finished tile over the wave's voices: the wavefront's subtree of the bank's pairwise sum
+// (tree_reduce in voice_chain.hpp).  The tile is stored voice-major ([voice][T], the common edge format), so a read of one
+// voice's row by lanes 0..T-1 is conflict-free and the transposition costs nothing; all reads go out before the first add.
 template <typename F, bool FMA, int T, bool PAN>
 __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 n_waves_total,
                                                int blk, u32 n0, u32 len, u32 v0, u32 nv) {
@@ -417,50 +417,16 @@ __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelA
   if ((u32)lane < len) {
     const F* col = tile + lane;
     if constexpr (!PAN) {
-      F acc;
-      if (nv == 64u) {
-        // all 64 reads go out before the first add: the LDS latency is paid once, not once per group of rows
-        // (the adds are one dependent chain whatever is done, in voice order)
-        F t[64];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) t[k] = col[k * ST];
-        acc = t[0];
-#pragma unroll
-        for (int k = 1; k < 64; ++k) acc = acc + t[k];
-      } else {
-        acc = col[0];
-        for (u32 v = 1; v < nv; ++v) acc = acc + col[v * ST];
-      }
-      a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = acc;
+      a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = fold_group<F, 64>(col, ST, nv);
       if (a.voices_out) {
         for (u32 v = 0; v < nv; ++v) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = col[v * ST];
       }
     } else {
-      // Pan2 (pan.rs:31-36): voice v contributes x * left_gain to channel 0 and x * right_gain to channel 1; each
-      // channel is the left fold of those products in voice order (its own chain of Add nodes, graph.rs:850-864).
+      // Pan2 (pan.rs:31-36): voice v contributes x * left_gain to channel 0 and x * right_gain to channel 1.
       // The gains sit in the padding of the voice's row: every lane reads the same word (a broadcast).
       const F* gain = tile + T;
       F accl, accr;
-      if (nv == 64u) {
-        F t[64];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) t[k] = col[k * ST];
-        accl = t[0] * gain[0];
-        accr = t[0] * gain[1];
-#pragma unroll
-        for (int k = 1; k < 64; ++k) {
-          accl = mad<FMA>(t[k], gain[k * ST], accl);
-          accr = mad<FMA>(t[k], gain[k * ST + 1], accr);
-        }
-      } else {
-        accl = col[0] * gain[0];
-        accr = col[0] * gain[1];
-        for (u32 v = 1; v < nv; ++v) {
-          const F t = col[v * ST];
-          accl = mad<FMA>(t, gain[v * ST], accl);
-          accr = mad<FMA>(t, gain[v * ST + 1], accr);
-        }
-      }
+      fold_group_pan<F, 64>(col, ST, gain, gain + 1, ST, nv, accl, accr);
       a.partials[(((long)blk * 2 + 0) * n_waves_total + wave_global) * a.block_size + n0 + lane] = accl;
       a.partials[(((long)blk * 2 + 1) * n_waves_total + wave_global) * a.block_size + n0 + lane] = accr;
       if (a.voices_out) {

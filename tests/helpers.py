@@ -54,3 +54,14 @@ def assert_bit_equal(a: np.ndarray, b: np.ndarray, what=""):
 def f64_mix(voices: np.ndarray) -> np.ndarray:
     """The mix accumulated in f64 (the tolerance reference of SURVEY.md hard part 3)."""
     return voices.astype(np.float64).sum(axis=0)
+
+
+def pairwise_sum(rows: np.ndarray) -> np.ndarray:
+    """KNH_MIX_TREE as the header defines it: neighbours are added in pairs, level by level, a row without a right neighbour
+    passes through -- in the rows' own precision (numpy adds elementwise with IEEE rounding, like the device)."""
+    level = np.ascontiguousarray(rows)
+    while level.shape[0] > 1:
+        even = level.shape[0] // 2 * 2
+        nxt = level[0:even:2] + level[1:even:2]
+        level = np.concatenate([nxt, level[even:]], axis=0) if even < level.shape[0] else nxt
+    return level[0]

@@ -625,3 +625,25 @@ def test_random_lin(knh, oracle, sample_type):
         if block == 4:
             bank.param_apply_many(v[::3], 0, 0, L.VALUE_FLOAT, np.full(len(v[::3]), 48000.0))  # a new value every sample
     run_pair(knh, oracle, w, 7, ev, L.MIX_TREE)
+
+
+@pytest.mark.parametrize("which", ["zero", "whole_ring"])
+def test_sample_delay_of_zero_or_the_whole_ring_in_every_voice(knh, oracle, which):
+    """delay.rs:29-43 with delay 0 or delay = ring length: the sample just written is the one read.  With EVERY voice of a
+    wavefront in that situation the tile-wise (16-byte) path of the device stage must not be taken (it reads before it
+    writes); in the ring test above some other voice of the wavefront always kept the wave on the per-sample path."""
+    n, bs = 70, 64
+    p = configs.voice_parameters(n)
+    v = np.arange(n, dtype=np.uint32)
+    w = configs.Workload("delay0", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SAMPLE_DELAY), Stage(L.STAGE_MUL_CONST)], n, bs, L.F32, 2)
+    max_delay = np.full(n, 0.004)  # 192 samples
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: max_delay.reshape(n, 1), 2: np.full((n, 1), 1.0 / n)}
+
+    def ev(block, bank):
+        if block == 0:
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, np.full(n, 0.0 if which == "zero" else 192.25 / 48000.0))
+        if block == 3:
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, np.full(n, 40.25 / 48000.0))
+        if block == 5:
+            bank.param_apply_many(v, 1, 0, L.VALUE_FLOAT, np.full(n, 0.0 if which == "zero" else 192.25 / 48000.0))
+    run_pair(knh, oracle, w, 8, ev, L.MIX_LEFT_FOLD)

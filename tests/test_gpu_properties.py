@@ -19,11 +19,9 @@ def left_fold(rows: np.ndarray) -> np.ndarray:
 
 
 def tree_mix(voices: np.ndarray) -> np.ndarray:
-    """The documented KNH_MIX_TREE order: fold 64 voices per wavefront, fold 16 wavefronts per group, fold groups."""
-    n = voices.shape[0]
-    waves = [left_fold(voices[i:i + 64]) for i in range(0, n, 64)]
-    groups = [left_fold(np.stack(waves[i:i + 16])) for i in range(0, len(waves), 16)]
-    return left_fold(np.stack(groups))
+    """The documented KNH_MIX_TREE order: the pairwise sum over the voice index (helpers.pairwise_sum)."""
+    from helpers import pairwise_sum
+    return pairwise_sum(voices)
 
 
 def c3_script(w, block, bank, offset=0):
@@ -168,8 +166,8 @@ def test_runs_are_deterministic(knh):
 
 
 def test_mix_is_linear_in_the_voice_set(knh):
-    """Voices are independent: a bank of voices A+B mixes to (mix A) + (mix B) up to f32 reassociation,
-    and exactly when A and B are whole 1024-voice fold groups."""
+    """Voices are independent: a bank of voices A+B mixes to (mix A) + (mix B) up to f32 reassociation, and exactly when
+    A is a power of two of voices and B no more than that (they are the two subtrees under the root of the pairwise sum)."""
     w = configs.config("C3", n_voices=2048, block_size=128)
     full = make_gpu(knh, w)
     halves = []
@@ -586,3 +584,46 @@ def test_pipelined_host_output_equals_blocking_calls(knh, kind):
     assert np.abs(want[1]).max() > 0
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("n_voices", [1, 3, 4, 5, 63, 64, 65, 100, 257, 1000, 4100, 16385])
+def test_tree_mix_is_the_pairwise_sum_of_the_voices(knh, monkeypatch, n_voices):
+    """KNH_MIX_TREE is a fixed order of additions (include/knaster_hip.h): the binary tree over the voice index, bit for bit
+    the same in every kernel form."""
+    from helpers import pairwise_sum
+    w = configs.config("C3", n_voices=n_voices, block_size=96)
+    for form in ({"KNH_PIPELINE": "0"}, {"KNH_PIPELINE": "1", "KNH_PIPE_BIG": "0"}, {"KNH_PIPELINE": "1", "KNH_PIPE_BIG": "1"},
+                 {"KNH_PIPELINE": "1", "KNH_PIPE_BIG": "2"}, {"KNH_PIPELINE": "0", "KNH_WIDE": "4"}, {"KNH_JIT": "1"}):
+        for k in ("KNH_PIPELINE", "KNH_PIPE_BIG", "KNH_WIDE", "KNH_JIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in form.items():
+            monkeypatch.setenv(k, val)
+        if n_voices > 5000 and "KNH_JIT" in form:
+            continue
+        w.block_size = 96 if form.get("KNH_PIPE_BIG", "0") == "0" else 128  # (the 64-sample-tile forms want whole tiles)
+        g = make_gpu(knh, w)
+        fire_all(g, n_voices, *w.restart)
+        for block in range(2):
+            out, voices, _ = g.process_block_voices()
+            assert_bit_equal(out[0], pairwise_sum(voices), f"{n_voices} voices, {form}, block {block}")
+        assert np.abs(out).max() > 0
+        g.close()
+
+
+@pytest.mark.parametrize("name,n_voices", [("C4", 333), ("P3", 150), ("P3", 1029), ("C2", 77), ("C5", 300)])
+def test_tree_mix_pairwise_other_chains(knh, name, n_voices):
+    """The same for f64 samples (C4), Pan2 chains (one tree per channel over the rounded products), the Fan pipeline (C2) and C5."""
+    from helpers import pairwise_sum
+    w = configs.config(name, n_voices=n_voices, block_size=64)
+    g = make_gpu(knh, w)
+    if w.restart:
+        fire_all(g, n_voices, *w.restart)
+    for block in range(2):
+        out, voices, _ = g.process_block_voices()
+        if voices.ndim == 3:
+            for ch in range(2):
+                assert_bit_equal(out[ch], pairwise_sum(voices[ch]), f"{name} channel {ch}")
+        else:
+            assert_bit_equal(out[0], pairwise_sum(voices), name)
+    assert np.abs(out).max() > 0
+    g.close()
