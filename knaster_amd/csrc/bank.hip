@@ -527,7 +527,7 @@ struct Bank final : knh_bank {
     if (desc.device >= 0) device = desc.device;
     else KNH_HIP(hipGetDevice(&device));
     KNH_HIP(hipSetDevice(device));
-    // Chains without a pre-built pipelined kernel are fused now (hiprtc).  Up to ~1.5 voice groups per CU the
+    // Chains without a pre-built pipelined kernel are fused now (hiprtc).  Up to two voice groups per CU the
     // pipelined form wins by a wide margin, so the chain is cut into at most three stage groups of similar cost
     // (estimated instructions per sample) and instantiated as voice_pipe_kernel; KNH_JIT_PIPE=0 keeps the
     // single-wave form.
@@ -538,7 +538,7 @@ struct Bank final : knh_bank {
     const char* jp = std::getenv("KNH_JIT_PIPE");
     // (a single voice group with a pre-built kernel stays on it: nothing to gain, and no compile at init)
     // (a voice that is a graph, not a chain, runs in the single-wave form: the pipeline's edges carry one signal)
-    const bool pipe_jit = !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 384 && !(jp && jp[0] == '0') &&
+    const bool pipe_jit = !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 512 && !(jp && jp[0] == '0') &&
                           !(entry && n_groups == 1) && !signature_is_dag(signature);
     if (pipe_jit) {
       std::string why;
@@ -1805,7 +1805,12 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
     b->wide = b->entry ? knh::find_wide(sig.c_str()) : nullptr;
     if (b->wide) {
       const unsigned groups = (d.n_voices + 63u) / 64u;
-      int ww = groups <= 384 && b->pipe ? 0 : (groups <= 1024 ? 4 : 8);
+      // The pipeline takes ceil(groups / 256 CUs) rounds of its one-group-per-CU time, the 4-group kernel one round of the
+      // whole chain's single-wavefront time up to 1 024 groups.  Measured on C3 / C4 (us per 512-frame block at 256, 384, 512,
+      // 768, 1 024 groups): f32 pipeline 13.9 26.3 27.0 39.8 52.5 against 41-42 flat; f64 24.6 47.4 47.8 70.7 94.0 against
+      // 55-57 flat.  So: three rounds of the pipeline in f32, two in f64.
+      const unsigned pipe_max = d.sample_type == KNH_F64 ? 512u : 768u;
+      int ww = groups <= pipe_max && b->pipe ? 0 : (groups <= 1024 ? 4 : 8);
       if (!b->pipe && groups <= 256) ww = 0;
       // a delay line wants the pipeline's 32-sample tiles (whole 128-byte lines per visit, reads one tile ahead):
       // measured 1.37e12 against 0.88e12 UGen-samples/s at 262 144 voices
