@@ -370,8 +370,10 @@ def main():
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": f"{traffic_src} (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes, per launch)" if traffic else None,
-                "kernel": ("voice_pipe_kernel<double,false,32,true,...>" if f64 else "voice_pipe_kernel<float,false,64,true,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>")
-                          if nv_rank <= 24576 else "voice_kernel<..., WAVES = 4 or 8, SinWt, MulVal, Svf, MulAsr>",
+                # (the library's choice, bank.hip make_bank: the pipeline up to 768 voice groups in f32, 512 in f64)
+                "kernel": ("voice_pipe_kernel<double,false,32,PIPE_INPLACE,...>" if f64 else
+                           "voice_pipe_kernel<float,false,64,PIPE_INPLACE,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>")
+                          if nv_rank <= (32768 if f64 else 49152) else "voice_kernel<..., WAVES = 4 or 8, SinWt, MulVal, Svf, MulAsr>",
                 "kernel_avg_ms": kernel_avg_ms, "launches": m["launches"], "blocks_per_launch": float(BLOCKS_PER_STEP),
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "note": "fused kernel moves 92 B (f64: 184 B) per voice per block; it is bound by the instruction issue of its "
@@ -402,8 +404,8 @@ def main():
                 "tile_samples": PIPE_TILE,
                 "note": "floor = the ten instructions of one filter step issued by a wavefront alone on its SIMD (44 cycles, "
                         "micro-benchmark) at 2.4 GHz; the rest of the kernel's time per sample is that wavefront's LDS hand-over, "
-                        "block/event bookkeeping and barrier once per 64-sample tile, and tiles in which the envelope "
-                        "wavefront (which also folds the voices) is the slower one",
+                        "block/event bookkeeping and the workgroup barrier once per 64-sample tile (the oscillator, envelope and "
+                        "mixer wavefronts on the other three SIMDs are all faster: profiles/r02_pipe_wave_busy_cycles.txt)",
             }
         if secondary is not None:
             s = secondary
