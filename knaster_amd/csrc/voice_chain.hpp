@@ -880,56 +880,60 @@ struct Svf : StageDefaults {
       return r.m0 * v0 + r.m1 * v1 + r.m2 * v2;
     }
   }
-  // f32, exact arithmetic: the same fifteen roundings as tick(), issued as ten instructions per sample.
+  // f32, exact arithmetic: the same fifteen roundings as tick(), issued as nine and a half instructions per sample.
   // Independent pairs share a packed instruction -- (a1*ic1, a2*ic1), (a2*v3, a3*v3), (v1, v2), (ic1', ic2'),
-  // (m1*v1, m2*v2) -- with the state kept in aligned register pairs so that no moves are needed.  A wavefront alone
+  // (m1*v1, m2*v2), and m0*x of two neighbouring samples (formed in front of each run of eight, outside the asm) -- with
+  // the state kept in aligned register pairs so that no moves are needed.  A wavefront alone
   // on its SIMD is issue-bound (tools/micro/valu_issue.hip: one instruction per ~5 cycles whatever it is, a packed
   // f32 op 1.2x that, an s_nop two thirds of it), so the instruction count of this loop IS the block time of the
-  // filter wave.  The order is fixed by hand: the two output adds of sample j-1 and the m0*x of sample j sit
-  // between the recurrence instructions of sample j, so no instruction reads the result of the packed
+  // filter wave.  The order is fixed by hand: the two output adds of sample j-1 sit between the recurrence instructions
+  // of sample j, so no instruction reads the result of the packed
   // instruction right before it (gfx950 needs one wait state there; the compiler cannot check inside asm, the
   // spacing below provides it).  Halves of a pair cannot be named through asm operands, hence the fixed registers:
   //   v[100:101] (ic1, ic2)   v[102:103] P1   v[104:105] P2   v[106:107] (v1, v2)   v[108:109] (m1*v1, m2*v2)
-  //   v112 running output sum   v114 v3
+  //   v112 m0*x + m1*v1 of the sample before   v114 v3
   template <int T>
   static __device__ __forceinline__ void tick_tile_packed(Regs<float>& r, float (&x)[T]) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 ic = {r.ic1, r.ic2};
-    const f2 a12 = {r.a1, r.a2}, a23 = {r.a2, r.a3}, m12 = {r.m1, r.m2};
-    const float m0 = r.m0;
+    const f2 a12 = {r.a1, r.a2}, a23 = {r.a2, r.a3}, m12 = {r.m1, r.m2}, m00 = {r.m0, r.m0};
     f2 q = {0.0f, 0.0f};
-    float o = 0.0f, first_prev;
+    float mprev = 0.0f, first_prev;
     static_assert(T % 8 == 0, "the filter tile is unrolled in blocks of eight samples");
-    // one sample: OUT receives the previous sample's output, IN is this sample's input (operand numbers)
-#define KNH_SVF_STEP(OUT, IN)                                                                                      \
+    // one sample: OUT receives the previous sample's output, IN is this sample's input, MP the previous sample's m0*x
+#define KNH_SVF_STEP(OUT, IN, MP)                                                                                  \
       "v_pk_mul_f32 v[102:103], %[a12], v[100:101] op_sel_hi:[1,0]\n\t"   /* (a1*ic1, a2*ic1)                 */   \
       "v_sub_f32 v114, %[x" #IN "], v101\n\t"                             /* v3 = x - ic2                     */   \
-      "v_add_f32 v112, v112, v108\n\t"                                    /* previous: m0*x + m1*v1           */   \
       "v_add_f32 v103, v101, v103\n\t"                                    /* ic2 + a2*ic1                     */   \
       "v_pk_mul_f32 v[104:105], %[a23], v[114:115] op_sel_hi:[1,0]\n\t"   /* (a2*v3, a3*v3)                   */   \
-      "v_add_f32 %[y" #OUT "], v112, v109\n\t"                            /* previous: ... + m2*v2 -> output  */   \
+      "v_add_f32 v112, %[" #MP "], v108\n\t"                              /* previous: m0*x + m1*v1           */   \
       "v_pk_add_f32 v[106:107], v[102:103], v[104:105]\n\t"               /* (v1, v2)                         */   \
-      "v_mul_f32 v112, %[m0], %[x" #IN "]\n\t"                            /* m0*x                             */   \
+      "v_add_f32 %[y" #OUT "], v112, v109\n\t"                            /* previous: ... + m2*v2 -> output  */   \
       "v_pk_fma_f32 v[100:101], v[106:107], 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"    \
       "v_pk_mul_f32 v[108:109], %[m12], v[106:107]\n\t"                   /* (m1*v1, m2*v2)                   */
 #pragma unroll
     for (int j = 0; j < T; j += 8) {
+      // m0*x of the eight samples, two to an instruction (plain C++: the halves are then ordinary operands)
+      const f2 p01 = m00 * f2{x[j], x[j + 1]}, p23 = m00 * f2{x[j + 2], x[j + 3]}, p45 = m00 * f2{x[j + 4], x[j + 5]},
+               p67 = m00 * f2{x[j + 6], x[j + 7]};
       // outputs y0..y7 = results of samples j-1 .. j+6 (early-clobber: they are written before later inputs are read)
       float y0, y1, y2, y3, y4, y5, y6, y7;
-      asm volatile(KNH_SVF_STEP(0, 0) KNH_SVF_STEP(1, 1) KNH_SVF_STEP(2, 2) KNH_SVF_STEP(3, 3)
-                   KNH_SVF_STEP(4, 4) KNH_SVF_STEP(5, 5) KNH_SVF_STEP(6, 6) KNH_SVF_STEP(7, 7)
+      asm volatile(KNH_SVF_STEP(0, 0, mp) KNH_SVF_STEP(1, 1, m0) KNH_SVF_STEP(2, 2, m1) KNH_SVF_STEP(3, 3, m2)
+                   KNH_SVF_STEP(4, 4, m3) KNH_SVF_STEP(5, 5, m4) KNH_SVF_STEP(6, 6, m5) KNH_SVF_STEP(7, 7, m6)
                    : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3), [y4] "=&v"(y4), [y5] "=&v"(y5),
-                     [y6] "=&v"(y6), [y7] "=&v"(y7), "+{v[100:101]}"(ic), "+{v[108:109]}"(q), "+{v112}"(o)
+                     [y6] "=&v"(y6), [y7] "=&v"(y7), "+{v[100:101]}"(ic), "+{v[108:109]}"(q)
                    : [x0] "v"(x[j]), [x1] "v"(x[j + 1]), [x2] "v"(x[j + 2]), [x3] "v"(x[j + 3]), [x4] "v"(x[j + 4]),
                      [x5] "v"(x[j + 5]), [x6] "v"(x[j + 6]), [x7] "v"(x[j + 7]), [a12] "v"(a12), [a23] "v"(a23),
-                     [m12] "v"(m12), [m0] "v"(m0)
-                   : "v102", "v103", "v104", "v105", "v106", "v107", "v114", "v115");
+                     [m12] "v"(m12), [mp] "v"(mprev), [m0] "v"(p01.x), [m1] "v"(p01.y), [m2] "v"(p23.x), [m3] "v"(p23.y),
+                     [m4] "v"(p45.x), [m5] "v"(p45.y), [m6] "v"(p67.x)
+                   : "v102", "v103", "v104", "v105", "v106", "v107", "v112", "v114", "v115");
+      mprev = p67.y;
       if (j > 0) x[j - 1] = y0; else first_prev = y0;  // nothing is pending before the first sample
       x[j] = y1; x[j + 1] = y2; x[j + 2] = y3; x[j + 3] = y4; x[j + 4] = y5; x[j + 5] = y6; x[j + 6] = y7;
     }
 #undef KNH_SVF_STEP
-    asm volatile("s_nop 0\n\tv_add_f32 v112, v112, v108\n\ts_nop 0\n\tv_add_f32 %[xout], v112, v109"
-                 : [xout] "=v"(x[T - 1]), "+{v112}"(o) : "{v[108:109]}"(q));
+    asm volatile("s_nop 0\n\tv_add_f32 v112, %[mp], v108\n\ts_nop 0\n\tv_add_f32 %[xout], v112, v109"
+                 : [xout] "=v"(x[T - 1]) : "{v[108:109]}"(q), [mp] "v"(mprev) : "v112");
     (void)first_prev;
     r.ic1 = ic.x; r.ic2 = ic.y;
   }
