@@ -395,6 +395,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
     a.flags[4 + I] = (u32)(busy / d);
     if (8 + 2 * I + 1 < 16) { a.flags[8 + 2 * I] = (u32)(busy_in / d); a.flags[9 + 2 * I] = (u32)(busy_out / d); }
     if (FOLDS) { a.flags[14] = (u32)(busy_tick / d); a.flags[15] = (u32)(busy_fold / d); }  // the folding group's stage arithmetic and fold
+    else if (MODE != PIPE_FOLD && I == 1) { a.flags[14] = (u32)(busy_tick / d); a.flags[15] = (u32)((busy - busy_in - busy_out - busy_tick) / d); }  // group 1: its arithmetic / its tile stores
   }
 #endif
   if (live) chain.store(a.state + voice, a.stride);
