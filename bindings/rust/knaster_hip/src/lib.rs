@@ -100,6 +100,9 @@ pub struct GpuVoiceBank<F: Float> {
     h: *mut knh_bank,
     n_stages: usize,
     n_voices: u32,
+    /// `UGen::init` returns nothing (ugen.rs:242-246): a failed `knh_bank_init` (no gfx950 device, out of device memory, a
+    /// chain that cannot be fused) is kept here; the node then renders silence and says so once per block on the RT logger.
+    init_error: Option<BankError>,
     _f: PhantomData<F>,
 }
 // knaster requires `Node: Send` (knaster_graph/src/node.rs:194).  The handle is single-caller: the graph moves
@@ -144,7 +147,7 @@ impl<F: Float> GpuVoiceBank<F> {
                 return Err(e);
             }
         }
-        Ok(Self { h, n_stages: stages.len(), n_voices, _f: PhantomData })
+        Ok(Self { h, n_stages: stages.len(), n_voices, init_error: None, _f: PhantomData })
     }
 
     /// `Buffer::from_vec(samples, sample_rate)` for the chain's `BufferReader` stage: one single-channel buffer shared
@@ -182,6 +185,10 @@ impl<F: Float> GpuVoiceBank<F> {
     pub fn raw(&self) -> *mut knh_bank {
         self.h
     }
+    /// What `UGen::init` could not report: `Some` if the device side of the bank was not set up (the node renders silence).
+    pub fn init_error(&self) -> Option<&BankError> {
+        self.init_error.as_ref()
+    }
     #[inline]
     fn split(&self, index: usize) -> (u32, u32, u32) {
         let (param, rest) = (index % MAX_PARAMS, index / MAX_PARAMS);
@@ -209,7 +216,9 @@ impl<F: Float> UGen for GpuVoiceBank<F> {
     // graph.rs:462-475 calls init on the control thread at push time; allocating is allowed (ugen.rs:242-246)
     fn init(&mut self, sample_rate: u32, block_size: usize) {
         if unsafe { knh_bank_init(self.h, sample_rate, block_size) } != KNH_OK {
-            log::error!("{}", last_error(self.h));
+            let e = last_error(self.h);
+            log::error!("{}", e);
+            self.init_error = Some(e);
         }
     }
 
@@ -227,6 +236,15 @@ impl<F: Float> UGen for GpuVoiceBank<F> {
         // RawContiguousBlock is channel-major and contiguous (knaster_graph/src/block.rs:19-78): the start of
         // channel 0 is the base of [2][block_size].  The library writes frames
         // [block_start_offset, block_start_offset + frames_to_process) of both channels.
+        if self.init_error.is_some() {
+            for ch in 0..2 {
+                for s in output.channel_as_slice_mut(ch).iter_mut() {
+                    *s = F::ZERO;
+                }
+            }
+            rt_log!(ctx.logger(); "knaster_hip: the bank failed to initialise (GpuVoiceBank::init_error): silence");
+            return;
+        }
         let out = output.channel_as_slice_mut(0).as_mut_ptr() as *mut c_void;
         let mut f = 0u32;
         let rc = unsafe {
