@@ -169,13 +169,16 @@ def c5_events(w: Workload, block: int):
     return voices, stages, params, kinds, fvalues.astype(np.float64), delays
 
 
-def fm_cascade(depth: int, n_voices: int = 1, block_size: int = 128, sample_type: int = L.F32, detune: float = 0.001) -> Workload:
+def fm_cascade(depth: int, n_voices: int = 1, block_size: int = 128, sample_type: int = L.F32, detune: float = 0.001,
+               add: float = 440.0, gain: float = 0.05) -> Workload:
     """knaster_benchmarks/benches/graph_dsp_performance.rs:37-72 ("256 FM cascade": depth = 256, one voice), as ONE voice that
     is a graph of `depth` oscillators:
          i = 0:  (c * s0).to_graph_out();  l = s0
          i > 0:  add = l * 440.0;  mul = s_i * l;  node = mul + add;  node.to_graph_out();  l = node * c
     The additive graph outputs are the reference's chain of Add nodes (graph.rs:850-864): acc = acc + node.  Voice v's
-    oscillators are detuned by (1 + detune * v) so that voices differ."""
+    oscillators are detuned by (1 + detune * v) so that voices differ.  With the reference's constants (add = 440, gain = 0.05) the
+    signal grows 22-fold per oscillator and is infinite, then NaN, from the 30th on (the bench measures time, not sound);
+    add = 19 keeps it of order one."""
     st, ctor = [], {}
 
     def push(stage, args=None):
@@ -184,15 +187,15 @@ def fm_cascade(depth: int, n_voices: int = 1, block_size: int = 128, sample_type
             ctor[len(st) - 1] = args
         return len(st)  # 1 + index: the value `input` takes to name this stage
     s0 = push(Stage(L.STAGE_SIN_WT), 220.0)
-    acc = push(Stage(L.STAGE_MUL_CONST, input=s0), 0.05)
+    acc = push(Stage(L.STAGE_MUL_CONST, input=s0), gain)
     last = s0
     for i in range(1, depth):
-        add = push(Stage(L.STAGE_MUL_CONST, input=last), 440.0)
+        add_ = push(Stage(L.STAGE_MUL_CONST, input=last), add)
         s = push(Stage(L.STAGE_SIN_WT), 220.0 + i)
         mul = push(Stage(L.STAGE_MATH_MUL, input=s, input2=last))
-        node = push(Stage(L.STAGE_MATH_ADD, input=mul, input2=add))
+        node = push(Stage(L.STAGE_MATH_ADD, input=mul, input2=add_))
         if i + 1 < depth:
-            last = push(Stage(L.STAGE_MUL_CONST, input=node), 0.05)
+            last = push(Stage(L.STAGE_MUL_CONST, input=node), gain)
         acc = push(Stage(L.STAGE_MATH_ADD, input=acc, input2=node))
     w = Workload("FMC", st, n_voices, block_size, sample_type, 1, description=f"FM cascade of {depth} oscillators per voice")
     scale = 1.0 + detune * np.arange(n_voices)

@@ -85,6 +85,15 @@ inline bool signature_is_dag(const std::string& sig) { return sig.find('@') != s
 inline bool is_wrapper_kind(uint16_t kind) {
   return kind == KNH_STAGE_WR_MUL || kind == KNH_STAGE_WR_ADD || kind == KNH_STAGE_WR_SUB || (kind >= KNH_STAGE_WR_VSUB && kind <= KNH_STAGE_WR_POWI);
 }
+// A graph-shaped voice the frame-parallel interpreter can run (kernels_interp.hip): free-running SinWt oscillators and
+// arithmetic only, nothing wrapped in WrPreciseTiming or WrSmoothParams.
+bool interp_can_run(const knh_stage_desc* st, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    if (st[i].flags != 0 || st[i].delayed_changes_per_block != 0) return false;
+    if (std::strchr("Wmasdvq*+-/", kKinds[st[i].kind].sig) == nullptr) return false;
+  }
+  return true;
+}
 
 // Rough instructions per sample of each stage (kernel_registry.hpp signature characters), used only to balance the
 // stage groups of a run-time-built pipeline.
@@ -328,6 +337,11 @@ struct Bank final : knh_bank {
   const knh::DagEntry* dag = nullptr;    // five-role variant (f32, source -> SVF -> x*env -> post chains)
   const knh::WideEntry* wide = nullptr;  // 4/8 voice groups per workgroup, for banks larger than the chip's SIMD count
   int wide_waves = 0;                    // 0 = not used, else 4 or 8
+  // a graph-shaped voice of SinWt oscillators and arithmetic run by the frame-parallel interpreter (kernels_interp.hip)
+  bool interp = false;
+  std::vector<knh_dev::InterpOp> h_prog;
+  knh_dev::InterpOp* d_prog = nullptr;
+  unsigned interp_sigs = 0, interp_out = 0;
   const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
   int pipeline_level = 1;                // KNH_PIPELINE
   std::string signature;
@@ -445,7 +459,7 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input, d_prog};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
     void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out, h_input};
@@ -535,10 +549,58 @@ struct Bank final : knh_bank {
     // and a 32- or 96-frame block would be half partial tiles (its 32-sample form has none).
     if (pipe && pipe->form != 0 && bs % (sizeof(F) == 4 ? 64u : 32u) != 0) pipe = knh::find_pipe(signature.c_str(), 1u);
     const unsigned n_groups = (nv + 63u) / 64u;
+    {  // Large graph-shaped voices made of SinWt oscillators and arithmetic: no fusion (hiprtc needs a minute for 380 stages
+       // and does not finish 1 500), a lane per frame instead.  KNH_INTERP=1 / 0: always (where it can) / never.
+      const char* ie = std::getenv("KNH_INTERP");
+      bool can = signature_is_dag(signature) && !entry && bs <= 1024 && stages.size() <= 4096;
+      for (const StageInfo& S : stages) can = can && S.flags == 0 && S.dcpb == 0 && std::strchr("Wmasdvq*+-/", kKinds[S.kind].sig) != nullptr;
+      if (can && !(ie && ie[0] == '0') && ((ie && ie[0] == '1') || stages.size() > 160)) {
+        h_prog.clear();
+        size_t si = 0;
+        const char* p = signature.c_str();
+        while (*p && *p != '#') {
+          knh_dev::InterpOp op{};
+          const char c = *p++;
+          int v[3] = {-1, -1, -1};
+          if (*p == '@') {
+            ++p;
+            for (int k = 0; k < 3; ++k) {
+              if (*p == '_') { ++p; } else { v[k] = 0; while (*p >= '0' && *p <= '9') v[k] = v[k] * 10 + (*p++ - '0'); }
+              if (*p == ',') ++p;
+            }
+          }
+          switch (c) {
+            case 'W': op.kind = knh_dev::INTERP_SIN_WT; break;
+            case 'm': op.kind = knh_dev::INTERP_VAL_MUL; break;
+            case 'a': op.kind = knh_dev::INTERP_VAL_ADD; break;
+            case 's': op.kind = knh_dev::INTERP_VAL_SUB; break;
+            case 'd': op.kind = knh_dev::INTERP_VAL_DIV; break;
+            case 'v': op.kind = knh_dev::INTERP_VAL_VSUB; break;
+            case 'q': op.kind = knh_dev::INTERP_VAL_VDIV; break;
+            case '*': op.kind = knh_dev::INTERP_MATH_MUL; break;
+            case '+': op.kind = knh_dev::INTERP_MATH_ADD; break;
+            case '-': op.kind = knh_dev::INTERP_MATH_SUB; break;
+            default: op.kind = knh_dev::INTERP_MATH_DIV; break;
+          }
+          if (si >= stages.size() || v[2] < 0 || (c != 'W' && v[0] < 0)) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "interpreter: malformed graph signature");
+          op.a = static_cast<unsigned short>(v[0] < 0 ? 0 : v[0]);
+          op.b = static_cast<unsigned short>(v[1] < 0 ? 0 : v[1]);
+          op.o = static_cast<unsigned short>(v[2]);
+          op.slot = static_cast<uint32_t>(stages[si].slot_base);
+          h_prog.push_back(op);
+          ++si;
+        }
+        interp_sigs = *p == '#' ? static_cast<unsigned>(std::atoi(p + 1)) : 0u;
+        interp_out = h_prog.empty() ? 0u : h_prog.back().o;
+        if (si != stages.size() || interp_sigs == 0) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "interpreter: malformed graph signature");
+        if (knh::interp_lds_bytes(static_cast<unsigned>(h_prog.size()), static_cast<unsigned>(n_slots), interp_sigs, static_cast<unsigned>(bs), sizeof(F) == 8) <= 158u * 1024u)
+          interp = true;
+      }
+    }
     const char* jp = std::getenv("KNH_JIT_PIPE");
     // (a single voice group with a pre-built kernel stays on it: nothing to gain, and no compile at init)
     // (a voice that is a graph, not a chain, runs in the single-wave form: the pipeline's edges carry one signal)
-    const bool pipe_jit = !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 512 && !(jp && jp[0] == '0') &&
+    const bool pipe_jit = !interp && !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 512 && !(jp && jp[0] == '0') &&
                           !(entry && n_groups == 1) && !signature_is_dag(signature);
     if (pipe_jit) {
       std::string why;
@@ -546,7 +608,7 @@ struct Bank final : knh_bank {
       const unsigned n_cuts = partition_chain(signature, cuts);
       jit = knh::jit_pipe_kernel(signature.c_str(), cuts, n_cuts, sizeof(F) == 8, desc.allow_fma != 0, &why);
       if (!jit) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' (pipelined) failed: " + why);
-    } else if (!entry) {  // no pre-built kernel at all
+    } else if (!entry && !interp) {  // no pre-built kernel at all
       std::string why;
       jit = knh::jit_voice_kernel(signature.c_str(), sizeof(F) == 8, desc.allow_fma != 0, &why);
       if (!jit) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' failed: " + why);
@@ -815,7 +877,11 @@ struct Bank final : knh_bank {
       KNH_HIP(hipMalloc(&d_seg_table, seg_rows.size() * sizeof(double)));
       KNH_HIP(hipMemcpy(d_seg_table, seg_rows.data(), seg_rows.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    const size_t n_waves = (nv + 63) / 64;
+    const size_t n_waves = interp ? nv : (nv + 63) / 64;  // rows the fold kernels take: one per wavefront, or (interpreter) one per voice
+    if (interp) {
+      KNH_HIP(hipMalloc(&d_prog, h_prog.size() * sizeof(knh_dev::InterpOp)));
+      KNH_HIP(hipMemcpy(d_prog, h_prog.data(), h_prog.size() * sizeof(knh_dev::InterpOp), hipMemcpyHostToDevice));
+    }
     pan = !signature.empty() && stages.back().kind == KNH_STAGE_PAN2;  // a Pan2 ends the chain: every voice has a left and a right signal
     fold_planes = pan ? 2u : 1u;
     KNH_HIP(hipMalloc(&d_partials, fold_planes * n_waves * bs * sizeof(F)));
@@ -1487,7 +1553,7 @@ struct Bank final : knh_bank {
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD && n_blocks > 1)
       return fail(KNH_ERR_INVALID_ARGUMENT, "KNH_MIX_LEFT_FOLD processes one block per call");
     if (want_voices) KNH_HIP(ensure_voices());
-    const unsigned n_waves = (nv + 63) / 64;
+    const unsigned n_waves = interp ? nv : (nv + 63) / 64;
     if (n_blocks > partials_blocks) {
       KNH_HIP(hipStreamSynchronize(s));
       KNH_HIP(hipFree(d_partials));
@@ -1566,7 +1632,8 @@ struct Bank final : knh_bank {
       tp = &timing_pool[timing_used++];
       KNH_HIP(hipEventRecord(tp->first, s));
     }
-    KNH_HIP(launch_voice(a, n_waves, s));
+    if (interp) KNH_HIP(launch_interp(a, s));
+    else KNH_HIP(launch_voice(a, n_waves, s));
     if (tp) KNH_HIP(hipEventRecord(tp->second, s));
     if (have_events && list_in_use >= 0) {
       KNH_HIP(hipEventRecord(list_done[list_in_use], s));
@@ -1578,8 +1645,9 @@ struct Bank final : knh_bank {
     // A Pan2 chain's row sets are [block][channel][rows][frame] and its output [block][channel][frame]: the fold sees
     // twice as many "blocks" of one channel each.
     const unsigned fold_channels = pan ? 1u : desc.out_channels;
+    // (the interpreter's rows ARE the voices' signals: one buffer serves both mix orders and the per-voice debug output)
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
-      KNH_HIP(launch_fold(false, d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), fold_planes, accumulate, flags_next, s));
+      KNH_HIP(launch_fold(false, interp ? d_partials : d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), fold_planes, accumulate, flags_next, s));
     else
       KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), n_blocks * fold_planes, accumulate, flags_next, s));
 
@@ -1590,7 +1658,7 @@ struct Bank final : knh_bank {
     if (out_host) KNH_HIP(hipMemcpyAsync(h_out, dst, out_bytes, hipMemcpyDeviceToHost, s));
     KNH_HIP(hipMemcpyAsync(h_flags, flags_now, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (voices_host)
-      KNH_HIP(hipMemcpyAsync(voices_host, d_voices, static_cast<size_t>(fold_planes) * nv * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
+      KNH_HIP(hipMemcpyAsync(voices_host, interp ? d_partials : d_voices, static_cast<size_t>(fold_planes) * nv * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
     KNH_HIP(hipStreamSynchronize(s));
     if (out_host) {
       if (n_blocks > 1) {
@@ -1612,6 +1680,12 @@ struct Bank final : knh_bank {
     return KNH_OK;
   }
   uint32_t partials_blocks = 1, out_blocks = 1;
+  hipError_t launch_interp(const VoiceKernelArgs<float>& a, hipStream_t s) {
+    return knh::launch_interp_f32(a, d_prog, static_cast<unsigned>(h_prog.size()), static_cast<unsigned>(n_slots), interp_sigs, interp_out, reinterpret_cast<float*>(d_partials), s);
+  }
+  hipError_t launch_interp(const VoiceKernelArgs<double>& a, hipStream_t s) {
+    return knh::launch_interp_f64(a, d_prog, static_cast<unsigned>(h_prog.size()), static_cast<unsigned>(n_slots), interp_sigs, interp_out, reinterpret_cast<double*>(d_partials), s);
+  }
   hipError_t launch_voice(const VoiceKernelArgs<float>& a, unsigned n_waves, hipStream_t s) {
     if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
     if (wide_waves == 4) return wide->f32_w4[desc.allow_fma ? 1 : 0](a, n_waves, s);
@@ -1736,10 +1810,11 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     }
     dag = dag || sources > 1;
   }
-  if (dag && n > 512) {
+  if (dag && n > 512 && !(interp_can_run(st, n) && n <= 4096)) {
     // every stage unrolls into the one kernel the voice is fused into: 91 stages build in 2 s, 379 in a minute, and the
     // time grows faster than the count (the reference's 256-oscillator FM cascade, 1 531 stages, does not finish)
-    *why = "a voice that is a graph may hold at most 512 stages";
+    // (graphs of SinWt oscillators and arithmetic alone are not fused at all: up to 4 096 stages run in kernels_interp.hip)
+    *why = "a voice that is a graph may hold at most 512 stages (4 096 if it is made of SinWt oscillators and arithmetic only)";
     return KNH_ERR_UNSUPPORTED_CHAIN;
   }
   if (dag) {

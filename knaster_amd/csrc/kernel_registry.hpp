@@ -11,6 +11,15 @@
 
 #include "voice_chain.hpp"
 
+namespace knh_dev {
+// One stage of a voice evaluated by the frame-parallel interpreter (kernels_interp.hip): what it computes, the signal
+// slots it reads and writes, and the first of its state words (the stage's slot base).
+enum { INTERP_VAL_MUL = 0, INTERP_VAL_ADD, INTERP_VAL_SUB, INTERP_VAL_DIV, INTERP_VAL_VSUB, INTERP_VAL_VDIV, INTERP_VAL_LAST = INTERP_VAL_VDIV,
+       INTERP_MATH_MUL, INTERP_MATH_ADD, INTERP_MATH_SUB, INTERP_MATH_DIV, INTERP_SIN_WT };
+struct InterpOp { u32 kind; unsigned short a, b, o, pad; u32 slot; };  // 16 bytes
+static_assert(sizeof(InterpOp) == 16, "one 16-byte LDS read per stage");
+}  // namespace knh_dev
+
 namespace knh {
 
 template <typename F>
@@ -45,6 +54,14 @@ struct WideEntry {
   VoiceLaunchFn<double> f64_w4[2], f64_w8[2];
 };
 const WideEntry* find_wide(const char* signature);
+
+// Voices that are large graphs of SinWt oscillators and arithmetic, a lane per frame (kernels_interp.hip).  rows:
+// [n_blocks][n_voices][block_size], every voice's signal (the fold kernels take it from there).
+size_t interp_lds_bytes(unsigned n_ops, unsigned n_state_words, unsigned n_sig, unsigned n_frames, bool f64, unsigned voices_per_workgroup = 1);
+hipError_t launch_interp_f32(const knh_dev::VoiceKernelArgs<float>& a, const knh_dev::InterpOp* prog, unsigned n_ops, unsigned n_state_words,
+                             unsigned n_sig, unsigned out_sig, float* rows, hipStream_t s);
+hipError_t launch_interp_f64(const knh_dev::VoiceKernelArgs<double>& a, const knh_dev::InterpOp* prog, unsigned n_ops, unsigned n_state_words,
+                             unsigned n_sig, unsigned out_sig, double* rows, hipStream_t s);
 
 const KernelEntry* find_kernel(const char* signature);
 int kernel_count();

@@ -158,10 +158,111 @@ def test_division_and_power_of_two_signals(knh, oracle):
 
 
 def test_graph_voices_have_a_stage_limit(knh):
-    """Every stage of a graph-shaped voice unrolls into its kernel: the build time grows faster than the stage count, so the
-    library refuses more than 512 stages (the reference's 256-oscillator cascade as one voice has 1 531) instead of hanging."""
-    w = configs.fm_cascade(256, 1, 128)
-    assert len(w.stages) == 1531
+    """Every stage of a FUSED graph-shaped voice unrolls into its kernel: the build time grows faster than the stage count, so
+    the library refuses more than 512 stages instead of hanging -- unless the voice is made of SinWt oscillators and arithmetic
+    only (the interpreter below takes up to 4 096 of those)."""
+    st = [Stage(L.STAGE_SIN_WT)]
+    for i in range(300):
+        st += [Stage(L.STAGE_ONEPOLE_LPF), Stage(L.STAGE_MUL_CONST)]
+    st += [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MATH_ADD, input=len(st), input2=len(st) + 1)]  # (a second source: a graph)
+    with pytest.raises(L.KnasterHipError) as e:
+        knh.VoiceBank(st, 1, L.F32, 1)
+    assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
+    w = configs.fm_cascade(700, 1, 128)
+    assert len(w.stages) > 4096
     with pytest.raises(L.KnasterHipError) as e:
         knh.VoiceBank(w.stages, 1, L.F32, 1)
     assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
+
+
+@pytest.mark.parametrize("n_voices,block_size,sample_type", [(1, 128, L.F32), (3, 32, L.F32), (2, 16, L.F64)])
+def test_the_reference_256_oscillator_fm_cascade(knh, oracle, n_voices, block_size, sample_type):
+    """knaster_benchmarks/benches/graph_dsp_performance.rs:37-72 as written: 256 SinWt and 1 275 math nodes in ONE voice (1 531
+    stages).  Run by the frame-parallel interpreter (kernels_interp.hip: a lane per frame, no fusion), bit-identical to the
+    oracle's node-by-node graph."""
+    w = configs.fm_cascade(256, n_voices, block_size, sample_type, add=19.0)  # (s + 19) * 0.05: the signal stays of order one
+    assert len(w.stages) == 1531
+    run_pair(knh, oracle, w, 3)
+    # the reference's own constants: the signal is infinite, then NaN, from the 30th oscillator on -- the same infinities and
+    # NaNs, bit for bit, on both sides
+    w = configs.fm_cascade(256, n_voices, block_size, sample_type)
+    g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    o = make_oracle(oracle, w)
+    for b in range(2):
+        _, gv, _ = g.process_block_voices()
+        _, ov, _, _ = o.process_block()
+        assert_bit_equal(gv, ov, f"reference constants, block {b}")
+    g.close()
+    o.close()
+
+
+def arithmetic_dag(rng, n_stages):
+    """A random feed-forward voice of what the interpreter runs: SinWt sources, x (op) value, a (op) b."""
+    st, ctor = [], {}
+    for i in range(n_stages):
+        have = len(st)
+        r = rng.random()
+        pick = lambda: int(rng.integers(1, have + 1))
+        if have == 0 or r < 0.3:
+            st.append(Stage(L.STAGE_SIN_WT))
+            ctor[have] = [float(rng.uniform(50, 3000))]
+        elif r < 0.6 and have >= 2:
+            kind = [L.STAGE_MATH_MUL, L.STAGE_MATH_ADD, L.STAGE_MATH_SUB][int(rng.integers(0, 3))]
+            st.append(Stage(kind, input=pick(), input2=pick()))
+        else:
+            kind = [L.STAGE_MUL_CONST, L.STAGE_ADD_CONST, L.STAGE_SUB_CONST, L.STAGE_WR_MUL, L.STAGE_WR_ADD][int(rng.integers(0, 5))]
+            wrapper = kind in (L.STAGE_WR_MUL, L.STAGE_WR_ADD)
+            st.append(Stage(kind, input=0 if wrapper or rng.random() < 0.5 else pick()))
+            ctor[have] = [float(rng.uniform(-1.2, 1.2))]
+    return st, ctor
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_interpreter_equals_the_fused_kernel_and_the_oracle(knh, oracle, monkeypatch, seed):
+    """KNH_INTERP=1 sends every graph-shaped voice the interpreter can run to it: random graphs, several blocks per launch,
+    parameter changes at block starts (a new frequency, a new constant), both sample types, both mix orders."""
+    rng = np.random.default_rng(4000 + seed)
+    st, ctor = arithmetic_dag(rng, int(rng.integers(5, 40)))
+    n = int(rng.integers(1, 70))
+    bs = int(rng.choice([16, 48, 64, 100, 256]))
+    w = configs.Workload(f"interp{seed}", st, n, bs, L.F32 if seed % 3 else L.F64, 1)
+    w.ctor = {s: np.tile(np.asarray(a, dtype=np.float64), (n, 1)) * (1.0 + 0.01 * np.arange(n)).reshape(n, 1) for s, a in ctor.items()}
+    if not any(x.kind in (L.STAGE_MATH_MUL, L.STAGE_MATH_ADD, L.STAGE_MATH_SUB) for x in st) and sum(x.kind == L.STAGE_SIN_WT for x in st) < 2:
+        st.append(Stage(L.STAGE_SIN_WT))  # (make it a graph, not a chain)
+        w.ctor[len(st) - 1] = np.full((n, 1), 333.0)
+        st.append(Stage(L.STAGE_MATH_ADD, input=len(st), input2=len(st) - 1))
+    sines = [i for i, x in enumerate(st) if x.kind == L.STAGE_SIN_WT]
+    consts = [i for i, x in enumerate(st) if x.kind in (L.STAGE_MUL_CONST, L.STAGE_ADD_CONST, L.STAGE_SUB_CONST, L.STAGE_WR_MUL)]  # (WrAdd has no parameter)
+    v = np.arange(n, dtype=np.uint32)
+
+    def ev(block, bank):
+        if block == 1:
+            bank.param_apply_many(v[::2], sines[0], 0, L.VALUE_FLOAT, 200.0 + 3.0 * v[::2])
+        if block == 2 and consts:
+            bank.param_apply_many(v, consts[-1], 0, L.VALUE_FLOAT, np.linspace(-0.5, 0.5, n))
+    outs = {}
+    for form in ("fused", "interp"):
+        monkeypatch.setenv("KNH_INTERP", "1" if form == "interp" else "0")
+        g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+        res = []
+        for b in range(4):
+            ev(b, g)
+            res.append(g.process_block_voices()[:2])
+        outs[form] = res
+        g.close()
+    o = make_oracle(oracle, w)
+    for b in range(4):
+        ev(b, o)
+        o_out, o_voices, _, _ = o.process_block()
+        for form in ("fused", "interp"):
+            assert_bit_equal(outs[form][b][1], o_voices, f"seed {seed} {form} block {b} per-voice")
+            assert_bit_equal(outs[form][b][0], o_out, f"seed {seed} {form} block {b} mix")
+    o.close()
+    # several blocks per launch, tree mix: the interpreter against itself block by block
+    monkeypatch.setenv("KNH_INTERP", "1")
+    a, b2 = make_gpu(knh, w), make_gpu(knh, w)
+    one = np.stack([a.process_block()[0] for _ in range(5)])
+    many = b2.process_blocks(5)[0]
+    assert_bit_equal(many, one, f"seed {seed}: 5 blocks in one launch")
+    a.close()
+    b2.close()

@@ -39,13 +39,17 @@ for nv in voices:
             "block_size": block, "init_s_incl_hiprtc": round(t_init, 2), "us_per_block_kernel": kms * 1e3 / (n * blocks),
             "ugen_samples_per_s_kernel": float(nv) * block * ugens * blocks * n / (kms * 1e-3),
             "ugen_samples_per_s_wall": float(nv) * block * ugens * blocks * n_launch / wall}
-    if nv <= 64 and depth <= 64:
+    if nv <= 64:
         from oracle import oracle_py
         o = oracle_py.OracleBank(w.stages, 1, w.sample_type, 1, True, False)
         for s, a in w.ctor.items():
             o.set_ctor_args(s, a[:1])
         o.init(48000, block)
         ref = np.stack([o.process_block()[0] for _ in range(2)])
+        t0 = time.perf_counter()
+        for _ in range(20):
+            o.process_block()
+        line["oracle_cpu_us_per_block_one_voice"] = (time.perf_counter() - t0) / 20 * 1e6  # the unfused node graph on one host core
         g1 = knaster_amd.VoiceBank(w.stages, 1, w.sample_type, 1, L.MIX_LEFT_FOLD)
         for s, a in w.ctor.items():
             g1.set_ctor_args(s, a[:1])
