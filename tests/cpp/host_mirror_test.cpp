@@ -577,8 +577,10 @@ static void gpu_many_sines_with_pan2() {
 // operators of graph_dsp_performance.rs:37-72 -- each cascade's additive outputs are separate to_graph_out() calls, i.e.
 // separate voices of the mirror that share nodes: that sharing across voices is what the planner refuses, so here every
 // cascade sums its nodes itself (acc = acc + node, the Add chain the reference inserts).
-static void gpu_voices_that_are_graphs() {
-  const int N = 70, B = 64, D = 8;
+// N voices, each the reference's "FM cascade" of D oscillators (graph_dsp_performance.rs:37-72); ADD = the constant the bench
+// multiplies `last` by (440 there: the signal then grows 22-fold per oscillator and is not finite for long)
+static void fm_cascade_voices(const int N, const int D, const float ADD) {
+  const int B = 64;
   auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
   kno::Graph<float> ref(0, 2, B, 48000);
   graph->edit([&](GraphEdit<float>& g) {
@@ -589,7 +591,7 @@ static void gpu_voices_that_are_graphs() {
       auto last = s0;
       for (int i = 1; i < D; ++i) {
         auto s = g.push(SinWt((220. + i) * det));
-        auto add = last * 440.0;
+        auto add = last * double(ADD);
         auto mul = s * last;
         auto node = mul + add;
         acc = acc + node;
@@ -607,7 +609,7 @@ static void gpu_voices_that_are_graphs() {
     auto last = s0;
     for (int i = 1; i < D; ++i) {
       auto s = ref.push(std::make_unique<kno::SinWt<float>>(float((220. + i) * double(det))));
-      auto k440 = ref.push(std::make_unique<kno::Constant<float>>(440.0f));
+      auto k440 = ref.push(std::make_unique<kno::Constant<float>>(ADD));
       auto add = ref.math_nodes(last, 0, kno::MathOp::Mul, k440, 0);
       auto mul = ref.math_nodes(s, 0, kno::MathOp::Mul, last, 0);
       auto node = ref.math_nodes(mul, 0, kno::MathOp::Add, add, 0);
@@ -635,9 +637,12 @@ static void gpu_voices_that_are_graphs() {
         peak = std::max(peak, std::fabs(double(want[c * B + i])));
       }
   }
-  std::printf("  FM cascades as graph voices: max |gpu - reference-shaped graph| = %.3g (peak %.3g)\n", worst, peak);
+  std::printf("  %d FM cascades of %d oscillators as graph voices: max |gpu - reference-shaped graph| = %.3g (peak %.3g)\n", N, D, worst, peak);
   CHECK(worst <= 1e-5 * std::max(1.0, peak) && peak > 1e-3);
 }
+static void gpu_voices_that_are_graphs() { fm_cascade_voices(70, 8, 440.0f); }
+// the bench's own depth: 256 oscillators in one voice (1 531 stages: run frame-parallel, not fused -- kernels_interp.hip)
+static void gpu_reference_fm_cascade_256() { fm_cascade_voices(2, 256, 19.0f); }
 
 int main(int argc, char** argv) {
   bool plan = false, gpu = false;
@@ -666,6 +671,7 @@ int main(int argc, char** argv) {
     RUN(gpu_polyblep_delay_limiter_voices);
     RUN(gpu_many_sines_with_pan2);
     RUN(gpu_voices_that_are_graphs);
+    RUN(gpu_reference_fm_cascade_256);
   }
   std::printf("%s (%d failures)\n", g_fail ? "HOST MIRROR FAILED" : "HOST MIRROR PASSED", g_fail);
   return g_fail ? 1 : 0;

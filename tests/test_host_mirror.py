@@ -29,7 +29,7 @@ def test_graph_api_end_to_end_on_gpu(knh):
     res = subprocess.run([BIN, "--gpu"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     for name in ("gpu_readme_example", "gpu_voice_graph_matches_reference_shaped_graph", "gpu_run_blocks_equals_block_by_block",
-                 "gpu_heterogeneous_voices_mix_on_device", "gpu_many_sines_with_pan2", "gpu_voices_that_are_graphs"):
+                 "gpu_heterogeneous_voices_mix_on_device", "gpu_many_sines_with_pan2", "gpu_voices_that_are_graphs", "gpu_reference_fm_cascade_256"):
         assert f"ok   {name}" in res.stdout
 
 
