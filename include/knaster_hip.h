@@ -146,10 +146,10 @@ typedef enum knh_value_kind {
  *     reference's "256 FM cascade" shape (knaster_benchmarks/benches/graph_dsp_performance.rs:37-72) is one.  Such voices
  *     run in the single-wave kernel form, fused at knh_bank_init time: every stage unrolls into the one kernel, so a fused
  *     voice may hold at most 512 stages (KNH_ERR_UNSUPPORTED_CHAIN beyond; 91 stages fuse in 2 s, 379 in a minute).
- *     A graph made of SIN_WT sources, the *_CONST / WR_* arithmetic and MATH_ADD/_SUB/_MUL/_DIV only (nothing wrapped in
- *     WrPreciseTiming or WrSmoothParams) is not fused at all when it is large (> 160 stages): it is parallel in time -- every
- *     such stage is a pure function of the frame index -- and runs a lane per frame, up to 4 096 stages, with the same
- *     results (the 256-oscillator cascade itself: 1 531 stages in ONE voice).
+ *     A voice made of SIN_WT sources, the *_CONST / WR_* arithmetic and MATH_ADD/_SUB/_MUL/_DIV only (nothing wrapped in
+ *     WrPreciseTiming or WrSmoothParams) is parallel in time -- every such stage is a pure function of the frame index --
+ *     and runs a lane per FRAME instead of a lane per voice, up to 4 096 stages, with the same results (the 256-oscillator
+ *     cascade itself: 1 531 stages in ONE voice, 11 us per 128-frame block).
  * KNH_STAGE_INPUT           (graph input) >> ...   the bank NODE's input channel `channel`: UGen::Inputs > 0,
  *                           `input.read(channel, frame)` in process_block (ugen.rs:263-284)               0    channel
  *     a source whose signal is the same for every voice: whatever the host graph connected to that input of the bank

@@ -342,6 +342,11 @@ struct Bank final : knh_bank {
   std::vector<knh_dev::InterpOp> h_prog;
   knh_dev::InterpOp* d_prog = nullptr;
   unsigned interp_sigs = 0, interp_out = 0;
+  // ... or, by default, as one frame-parallel kernel hiprtc builds from the stages written out as straight-line code
+  // (voice_frame.hpp, jit_frame_kernel); KNH_FRAME_JIT=0 keeps the interpreter
+  const knh::JitKernel* frame_jit = nullptr;
+  uint32_t* d_sin_slots = nullptr;
+  unsigned frame_vpw = 1, n_sin = 0;
   const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
   int pipeline_level = 1;                // KNH_PIPELINE
   std::string signature;
@@ -459,7 +464,7 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input, d_prog};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input, d_prog, d_sin_slots};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
     void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out, h_input};
@@ -549,12 +554,14 @@ struct Bank final : knh_bank {
     // and a 32- or 96-frame block would be half partial tiles (its 32-sample form has none).
     if (pipe && pipe->form != 0 && bs % (sizeof(F) == 4 ? 64u : 32u) != 0) pipe = knh::find_pipe(signature.c_str(), 1u);
     const unsigned n_groups = (nv + 63u) / 64u;
-    {  // Large graph-shaped voices made of SinWt oscillators and arithmetic: no fusion (hiprtc needs a minute for 380 stages
-       // and does not finish 1 500), a lane per frame instead.  KNH_INTERP=1 / 0: always (where it can) / never.
+    {  // Voices made of SinWt oscillators and arithmetic alone (graphs, or chains without a pre-built kernel) are not run a
+       // lane per voice at all: every stage is a pure function of the frame index, so a lane per FRAME it is (voice_frame.hpp)
+       // -- measured 10-27 times the lane-per-voice form from one voice to 65 536 (tools/bench_fm_cascade.py), and the only
+       // form that takes the reference's 1 531-stage cascade.  KNH_INTERP=0: never (the lane-per-voice form, A/B runs).
       const char* ie = std::getenv("KNH_INTERP");
-      bool can = signature_is_dag(signature) && !entry && bs <= 1024 && stages.size() <= 4096;
+      bool can = !entry && bs <= 1024 && stages.size() <= 4096;
       for (const StageInfo& S : stages) can = can && S.flags == 0 && S.dcpb == 0 && std::strchr("Wmasdvq*+-/", kKinds[S.kind].sig) != nullptr;
-      if (can && !(ie && ie[0] == '0') && ((ie && ie[0] == '1') || stages.size() > 160)) {
+      if (can && !(ie && ie[0] == '0')) {
         h_prog.clear();
         size_t si = 0;
         const char* p = signature.c_str();
@@ -582,6 +589,10 @@ struct Bank final : knh_bank {
             case '-': op.kind = knh_dev::INTERP_MATH_SUB; break;
             default: op.kind = knh_dev::INTERP_MATH_DIV; break;
           }
+          if (!signature_is_dag(signature)) {  // a plain chain: one signal, every stage works on it in place
+            v[0] = c == 'W' ? -1 : 0;
+            v[2] = 0;
+          }
           if (si >= stages.size() || v[2] < 0 || (c != 'W' && v[0] < 0)) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "interpreter: malformed graph signature");
           op.a = static_cast<unsigned short>(v[0] < 0 ? 0 : v[0]);
           op.b = static_cast<unsigned short>(v[1] < 0 ? 0 : v[1]);
@@ -590,11 +601,29 @@ struct Bank final : knh_bank {
           h_prog.push_back(op);
           ++si;
         }
-        interp_sigs = *p == '#' ? static_cast<unsigned>(std::atoi(p + 1)) : 0u;
+        interp_sigs = *p == '#' ? static_cast<unsigned>(std::atoi(p + 1)) : (signature_is_dag(signature) ? 0u : 1u);
         interp_out = h_prog.empty() ? 0u : h_prog.back().o;
         if (si != stages.size() || interp_sigs == 0) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "interpreter: malformed graph signature");
         if (knh::interp_lds_bytes(static_cast<unsigned>(h_prog.size()), static_cast<unsigned>(n_slots), interp_sigs, static_cast<unsigned>(bs), sizeof(F) == 8) <= 158u * 1024u)
           interp = true;
+        const char* fj = std::getenv("KNH_FRAME_JIT");
+        if (interp && !(fj && fj[0] == '0')) {
+          const unsigned tpv = ((static_cast<unsigned>(bs) + 63u) / 64u) * 64u;
+          const size_t nwp = (static_cast<size_t>(n_slots) + 3u) & ~size_t(3);
+          // voices per workgroup: as many as keep every CU busy, fit 1 024 threads and (beside the 64 KiB table) the LDS
+          unsigned vpw = std::max(1u, nv / 256u);
+          vpw = std::min(vpw, 1024u / tpv);
+          while (vpw > 1u && 65536u + vpw * nwp * sizeof(W) > 156u * 1024u) --vpw;
+          if (65536u + vpw * nwp * sizeof(W) <= 156u * 1024u) {
+            std::vector<knh::FrameOp> fops(h_prog.size());
+            for (size_t k = 0; k < h_prog.size(); ++k) fops[k] = knh::FrameOp{h_prog[k].kind, h_prog[k].a, h_prog[k].b, h_prog[k].o, h_prog[k].slot};
+            std::string why;
+            frame_jit = knh::jit_frame_kernel(fops.data(), static_cast<unsigned>(fops.size()), interp_sigs, interp_out, static_cast<unsigned>(n_slots), vpw, tpv,
+                                              sizeof(F) == 8, &why);
+            if (frame_jit) frame_vpw = vpw;
+            else warnings.push_back("frame-parallel kernel not built (" + why.substr(0, 300) + "): the interpreter runs the voice");
+          }
+        }
       }
     }
     const char* jp = std::getenv("KNH_JIT_PIPE");
@@ -881,6 +910,12 @@ struct Bank final : knh_bank {
     if (interp) {
       KNH_HIP(hipMalloc(&d_prog, h_prog.size() * sizeof(knh_dev::InterpOp)));
       KNH_HIP(hipMemcpy(d_prog, h_prog.data(), h_prog.size() * sizeof(knh_dev::InterpOp), hipMemcpyHostToDevice));
+      std::vector<uint32_t> sins;
+      for (const knh_dev::InterpOp& op : h_prog)
+        if (op.kind == knh_dev::INTERP_SIN_WT) sins.push_back(op.slot);
+      n_sin = static_cast<unsigned>(sins.size());
+      KNH_HIP(hipMalloc(&d_sin_slots, std::max<size_t>(1, sins.size()) * sizeof(uint32_t)));
+      if (!sins.empty()) KNH_HIP(hipMemcpy(d_sin_slots, sins.data(), sins.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     pan = !signature.empty() && stages.back().kind == KNH_STAGE_PAN2;  // a Pan2 ends the chain: every voice has a left and a right signal
     fold_planes = pan ? 2u : 1u;
@@ -1680,10 +1715,16 @@ struct Bank final : knh_bank {
     return KNH_OK;
   }
   uint32_t partials_blocks = 1, out_blocks = 1;
+  template <typename FF> hipError_t launch_frame(const VoiceKernelArgs<FF>& a, hipStream_t s) {
+    struct { VoiceKernelArgs<FF> a; FF* rows; const uint32_t* sin_slots; uint32_t n_sin; } args{a, reinterpret_cast<FF*>(d_partials), d_sin_slots, n_sin};
+    return knh::jit_frame_launch(frame_jit, &args, sizeof(args), (a.n_voices + frame_vpw - 1u) / frame_vpw, s);
+  }
   hipError_t launch_interp(const VoiceKernelArgs<float>& a, hipStream_t s) {
+    if (frame_jit) return launch_frame<float>(a, s);
     return knh::launch_interp_f32(a, d_prog, static_cast<unsigned>(h_prog.size()), static_cast<unsigned>(n_slots), interp_sigs, interp_out, reinterpret_cast<float*>(d_partials), s);
   }
   hipError_t launch_interp(const VoiceKernelArgs<double>& a, hipStream_t s) {
+    if (frame_jit) return launch_frame<double>(a, s);
     return knh::launch_interp_f64(a, d_prog, static_cast<unsigned>(h_prog.size()), static_cast<unsigned>(n_slots), interp_sigs, interp_out, reinterpret_cast<double*>(d_partials), s);
   }
   hipError_t launch_voice(const VoiceKernelArgs<float>& a, unsigned n_waves, hipStream_t s) {

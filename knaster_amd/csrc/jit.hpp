@@ -21,6 +21,15 @@ const JitKernel* jit_voice_kernel(const char* signature, bool f64, bool fma, std
 // (ascending, inside the signature), e.g. "WmSA" with cuts {2, 3} = Group<W,m>, Group<S>, Group<A>.
 const JitKernel* jit_pipe_kernel(const char* signature, const unsigned* cuts, unsigned n_cuts, bool f64, bool fma, std::string* error);
 
+// A graph-shaped voice of SinWt oscillators and arithmetic as ONE frame-parallel kernel (voice_frame.hpp): the stages written
+// out as straight-line code, a statement per stage (`ops`: kernel_registry.hpp's InterpOp list).  vpw voices per workgroup,
+// threads_per_voice lanes each (a multiple of 64 >= block_size); n_state_words per voice; n_sig signal slots; out_sig the
+// voice's signal.  block_threads of the result = vpw * threads_per_voice.
+struct FrameOp { unsigned kind, a, b, o, slot; };
+const JitKernel* jit_frame_kernel(const FrameOp* ops, unsigned n_ops, unsigned n_sig, unsigned out_sig, unsigned n_state_words, unsigned vpw,
+                                  unsigned threads_per_voice, bool f64, std::string* error);
+hipError_t jit_frame_launch(const JitKernel* k, const void* args, size_t args_size, unsigned n_workgroups, hipStream_t stream);
+
 // Launch helper: args points at a VoiceKernelArgs<F>.
 hipError_t jit_launch(const JitKernel* k, const void* args, size_t args_size, unsigned n_wavefronts, hipStream_t stream);
 

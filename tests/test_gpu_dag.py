@@ -175,11 +175,13 @@ def test_graph_voices_have_a_stage_limit(knh):
     assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
 
 
+@pytest.mark.parametrize("frame_jit", ["1", "0"])
 @pytest.mark.parametrize("n_voices,block_size,sample_type", [(1, 128, L.F32), (3, 32, L.F32), (2, 16, L.F64)])
-def test_the_reference_256_oscillator_fm_cascade(knh, oracle, n_voices, block_size, sample_type):
+def test_the_reference_256_oscillator_fm_cascade(knh, oracle, monkeypatch, n_voices, block_size, sample_type, frame_jit):
     """knaster_benchmarks/benches/graph_dsp_performance.rs:37-72 as written: 256 SinWt and 1 275 math nodes in ONE voice (1 531
-    stages).  Run by the frame-parallel interpreter (kernels_interp.hip: a lane per frame, no fusion), bit-identical to the
-    oracle's node-by-node graph."""
+    stages).  Run a lane per frame -- as one straight-line kernel hiprtc builds from the stage list (voice_frame.hpp; the
+    default) or by the interpreter (kernels_interp.hip; KNH_FRAME_JIT=0) -- bit-identical to the oracle's node-by-node graph."""
+    monkeypatch.setenv("KNH_FRAME_JIT", frame_jit)
     w = configs.fm_cascade(256, n_voices, block_size, sample_type, add=19.0)  # (s + 19) * 0.05: the signal stays of order one
     assert len(w.stages) == 1531
     run_pair(knh, oracle, w, 3)
@@ -241,8 +243,9 @@ def test_interpreter_equals_the_fused_kernel_and_the_oracle(knh, oracle, monkeyp
         if block == 2 and consts:
             bank.param_apply_many(v, consts[-1], 0, L.VALUE_FLOAT, np.linspace(-0.5, 0.5, n))
     outs = {}
-    for form in ("fused", "interp"):
-        monkeypatch.setenv("KNH_INTERP", "1" if form == "interp" else "0")
+    for form in ("fused", "interp", "frame"):
+        monkeypatch.setenv("KNH_INTERP", "0" if form == "fused" else "1")
+        monkeypatch.setenv("KNH_FRAME_JIT", "0" if form == "interp" else "1")
         g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
         res = []
         for b in range(4):
@@ -254,15 +257,17 @@ def test_interpreter_equals_the_fused_kernel_and_the_oracle(knh, oracle, monkeyp
     for b in range(4):
         ev(b, o)
         o_out, o_voices, _, _ = o.process_block()
-        for form in ("fused", "interp"):
+        for form in ("fused", "interp", "frame"):
             assert_bit_equal(outs[form][b][1], o_voices, f"seed {seed} {form} block {b} per-voice")
             assert_bit_equal(outs[form][b][0], o_out, f"seed {seed} {form} block {b} mix")
     o.close()
-    # several blocks per launch, tree mix: the interpreter against itself block by block
+    # several blocks per launch, tree mix: each frame-parallel form against itself block by block
     monkeypatch.setenv("KNH_INTERP", "1")
-    a, b2 = make_gpu(knh, w), make_gpu(knh, w)
-    one = np.stack([a.process_block()[0] for _ in range(5)])
-    many = b2.process_blocks(5)[0]
-    assert_bit_equal(many, one, f"seed {seed}: 5 blocks in one launch")
-    a.close()
-    b2.close()
+    for fj in ("0", "1"):
+        monkeypatch.setenv("KNH_FRAME_JIT", fj)
+        a, b2 = make_gpu(knh, w), make_gpu(knh, w)
+        one = np.stack([a.process_block()[0] for _ in range(5)])
+        many = b2.process_blocks(5)[0]
+        assert_bit_equal(many, one, f"seed {seed}: 5 blocks in one launch (KNH_FRAME_JIT={fj})")
+        a.close()
+        b2.close()
