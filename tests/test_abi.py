@@ -167,3 +167,22 @@ def test_rust_ffi_matches_header():
         r_body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, src, flags=re.S).group(1)
         r_fields = re.findall(r"pub ([a-z_]+):", r_body)
         assert c_fields == r_fields, struct
+
+
+def test_graph_voice_stage_limits_without_device(knh):
+    """Checked at knh_bank_create, before any device is touched: a fused graph-shaped voice holds at most 512 stages; one made of
+    SinWt oscillators and arithmetic alone (it runs a lane per frame) up to 4 096 -- the reference's
+    256-oscillator FM cascade is 1 531."""
+    w = configs.fm_cascade(256, 1, 128)
+    assert len(w.stages) == 1531
+    knh.VoiceBank(w.stages, 1, L.F32, 1).close()
+    assert knh.chain_ugen_count(w.stages) == 2041  # 256 SinWt + 510 Constants + 1 275 MathUGens (graph_dsp_performance.rs:37-72)
+    too_long = configs.fm_cascade(700, 1, 128)
+    with pytest.raises(L.KnasterHipError) as e:
+        knh.VoiceBank(too_long.stages, 1, L.F32, 1)
+    assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
+    st = [Stage(L.STAGE_SIN_WT)] + [Stage(L.STAGE_ONEPOLE_LPF), Stage(L.STAGE_MUL_CONST)] * 300
+    st += [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MATH_ADD, input=len(st), input2=len(st) + 1)]  # a filter in it: fused, and too long for that
+    with pytest.raises(L.KnasterHipError) as e:
+        knh.VoiceBank(st, 1, L.F32, 1)
+    assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
