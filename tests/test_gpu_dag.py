@@ -271,3 +271,21 @@ def test_interpreter_equals_the_fused_kernel_and_the_oracle(knh, oracle, monkeyp
         assert_bit_equal(many, one, f"seed {seed}: 5 blocks in one launch (KNH_FRAME_JIT={fj})")
         a.close()
         b2.close()
+
+
+def test_frame_parallel_voices_in_sharded_and_rank_banks(knh):
+    """A bank of frame-parallel voices cut into host shards, spread over "devices" (all device 0 here) and as a one-rank rank
+    bank: the same voices, mixed within the tolerance of the re-association (each range has a pairwise tree of its own)."""
+    w = configs.fm_cascade(12, 300, 64, add=19.0)
+    ref = make_gpu(knh, w)
+    want = np.stack([ref.process_block()[0] for _ in range(3)])
+    ref.close()
+    assert np.abs(want).max() > 1e-3
+    for kw in ({"host_threads": 3}, {"devices": [0, 0]}, {"rank": 0, "world": 1}):
+        b = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE, -1, False, **kw)
+        for s, a in w.ctor.items():
+            b.set_ctor_args(s, a)
+        b.init(configs.SAMPLE_RATE, w.block_size)
+        got = np.stack([b.process_block()[0] for _ in range(3)])
+        b.close()
+        assert np.max(np.abs(got - want)) <= 1e-5 * max(1.0, float(np.abs(want).max())), kw
