@@ -24,7 +24,12 @@ __device__ __forceinline__ void frame_parallel_run(const VoiceKernelArgs<F>& a, 
   const u32 voice_raw = blockIdx.x * vpw + vi;
   const bool have_voice = voice_raw < a.n_voices;
   const u32 voice = have_voice ? voice_raw : a.n_voices - 1;  // (spare threads of the last workgroup shadow the last voice and write nothing)
-  for (u32 i = threadIdx.x; i < 16384u; i += blockDim.x) sine[i] = a.sine_table[i];
+  {  // the table, 16 bytes per lane and step
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    const V4* src = reinterpret_cast<const V4*>(a.sine_table);
+    V4* dst = reinterpret_cast<V4*>(sine);
+    for (u32 i = threadIdx.x; i < 4096u; i += blockDim.x) dst[i] = src[i];
+  }
   for (u32 i = tid; i < n_state_words; i += nthreads) pw[i] = a.state[(long)i * a.stride + voice];
   u32 ev_i = 0, ev_end = 0;
   if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
