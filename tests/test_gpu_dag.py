@@ -266,7 +266,14 @@ def test_interpreter_equals_the_fused_kernel_and_the_oracle(knh, oracle, monkeyp
     for fj in ("0", "1"):
         monkeypatch.setenv("KNH_FRAME_JIT", fj)
         a, b2 = make_gpu(knh, w), make_gpu(knh, w)
-        one = np.stack([a.process_block()[0] for _ in range(5)])
+        one = []
+        for blk in range(5):  # the same changes, given block by block and scheduled ahead for blocks 1 and 2 of one launch
+            ev(blk, a)
+            one.append(a.process_block()[0])
+        one = np.stack(one)
+        b2.param_apply_many(v[::2], sines[0], 0, L.VALUE_FLOAT, 200.0 + 3.0 * v[::2], block_offset=1)
+        if consts:
+            b2.param_apply_many(v, consts[-1], 0, L.VALUE_FLOAT, np.linspace(-0.5, 0.5, n), block_offset=2)
         many = b2.process_blocks(5)[0]
         assert_bit_equal(many, one, f"seed {seed}: 5 blocks in one launch (KNH_FRAME_JIT={fj})")
         a.close()
