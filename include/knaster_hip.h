@@ -241,7 +241,9 @@ typedef struct knh_stage_desc {
    * chain on one running signal.  k > 0: the output of stage k - 1 of this list (an earlier one), so that a signal can feed
    * several stages and stages need not follow their input directly.  Source stages read nothing (except SIN_WT with
    * KNH_STAGE_FLAG_AR_FREQ, whose frequency this signal drives); wrapper stages (KNH_STAGE_WR_*) wrap the stage before
-   * them and keep 0.  `input2` is the second operand of the KNH_STAGE_MATH_* stages and 0 everywhere else. */
+   * them and keep 0.  `input2` is the second operand of the KNH_STAGE_MATH_* stages and 0 everywhere else.
+   * "The output of stage k - 1" is the output of the NODE that stage stands for: if wrapper stages follow it, what the
+   * reader gets is the last wrapper's output (the reference's wr_mul() etc. are part of the UGen they wrap). */
   uint16_t input;
   uint16_t input2;
 } knh_stage_desc;

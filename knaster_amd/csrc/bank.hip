@@ -1860,10 +1860,16 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
   }
   if (dag) {
     std::vector<int> a(n, -1), b(n, -1), last_use(n, -1);
+    // "the output of stage k" is the output of the NODE stage k stands for: if wrapper stages follow it (they wrap it: the
+    // reference's wr_mul() etc. are part of the UGen), what a reader gets is the last wrapper's output
+    auto node_output = [&](int k) {
+      while (k + 1 < static_cast<int>(n) && is_wrapper_kind(st[k + 1].kind)) ++k;
+      return k;
+    };
     for (uint32_t i = 0; i < n; ++i) {
       const bool reads = i > 0 && !(std::strchr("WNPUKOGBFI", (*sig)[i]) != nullptr);  // 'R' reads, the plain sources do not
-      if (is_math2_kind(st[i].kind)) { a[i] = st[i].input - 1; b[i] = st[i].input2 - 1; }
-      else if (reads) a[i] = st[i].input ? st[i].input - 1 : static_cast<int>(i) - 1;
+      if (is_math2_kind(st[i].kind)) { a[i] = node_output(st[i].input - 1); b[i] = node_output(st[i].input2 - 1); }
+      else if (reads) a[i] = st[i].input ? node_output(st[i].input - 1) : static_cast<int>(i) - 1;
       if (a[i] >= 0) last_use[a[i]] = static_cast<int>(i);
       if (b[i] >= 0) last_use[b[i]] = static_cast<int>(i);
     }

@@ -2,6 +2,8 @@
 that name the signal they read (knh_stage_desc.input), MathUGen<_, U1, Op> of two signals (KNH_STAGE_MATH_*).  The oracle
 builds the same voice as the reference's graph API would (one node per UGen, connect / math_nodes); bar: bit-identical per
 voice for everything built from + - * and table lookups."""
+import os
+
 import numpy as np
 import pytest
 
@@ -118,7 +120,7 @@ def random_dag(rng, n_stages):
     return st, ctor
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "12"))))
 def test_random_dag_voices_match_the_oracle(knh, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     st, ctor = random_dag(rng, int(rng.integers(4, 12)))
@@ -219,7 +221,7 @@ def arithmetic_dag(rng, n_stages):
     return st, ctor
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "8"))))
 def test_interpreter_equals_the_fused_kernel_and_the_oracle(knh, oracle, monkeypatch, seed):
     """KNH_INTERP=1 sends every graph-shaped voice the interpreter can run to it: random graphs, several blocks per launch,
     parameter changes at block starts (a new frequency, a new constant), both sample types, both mix orders."""

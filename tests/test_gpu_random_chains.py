@@ -1,6 +1,8 @@
 """Randomised chains: every feedback-free chain of supported stages is fused at run time (hiprtc) when no pre-built
 kernel exists, so the space of kernels is open-ended.  Seeded random chains with random constructor arguments and a
 few random parameter changes, each compared with the oracle bit for bit per voice (exact stages only)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -112,7 +114,8 @@ def random_chain(seed):
     return w, rng, changes, triggers
 
 
-@pytest.mark.parametrize("seed", range(40))
+# (KNH_TEST_SEEDS=400 python -m pytest tests/test_gpu_random_chains.py -m gpu: a soak run over more seeds)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "40"))))
 def test_random_chain_matches_oracle(knh, oracle, seed):
     w, rng, changes, triggers = random_chain(seed)
     n = w.n_voices
