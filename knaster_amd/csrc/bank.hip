@@ -1132,6 +1132,9 @@ struct Bank final : knh_bank {
                     kind_ok(stages[stgs[k]], params[k], kinds[k]) && direct_ok(stages[stgs[k]], params[k]);
       if (direct && delays)
         for (size_t q = k; q < e && direct; ++q) direct = delays[q] == 0;  // an armed delay on an unwrapped stage: the warning path
+      // Calls already kept for that block (they are replayed when the block is assembled) come first: a later call must not
+      // overtake them by being turned into its patches now (two changes of one parameter in one block: the last one holds).
+      if (direct && block_offset > 0 && block_offset < future.size() && !future[block_offset].empty()) direct = false;
       // (runs of any length: a host that addresses two parameters of alternate voices sends runs of one)
       const bool queued_run = !direct && stgs[k] < stages.size() && stages.size() <= 255 && params[k] < static_cast<uint32_t>(stages[stgs[k]].n_params) &&
                               fastq(stages[stgs[k]]) && kind_ok(stages[stgs[k]], params[k], kinds[k]) && kinds[k] != KNH_VALUE_SMOOTHING;
@@ -1343,6 +1346,8 @@ struct Bank final : knh_bank {
   // and process_block's change loop (:65-114) applies a node's queued changes first in, first out, each at
   // max(its delay, where the node's block has got to) -- a change behind one that is not due inside the processed range
   // is never reached.  A node's events come out in frame order by construction.
+  struct DueRec { uint32_t rec; uint32_t due; };
+  std::vector<DueRec> due_scratch;
   void resolve_qrecs(std::vector<QRec>& recs, uint32_t frame_begin, uint32_t frame_end) {
     if (recs.empty()) return;
     q_epoch += 1;
@@ -1351,7 +1356,14 @@ struct Bank final : knh_bank {
       q_epoch = 1;
     }
     pending.reserve(pending.size() + recs.size());
-    for (const QRec& r : recs) {
+    // Two passes, as the reference's time runs: a call without an armed delay goes straight through to the node when it is
+    // made -- between two blocks, so BEFORE every queued change of the block is applied (those are applied inside
+    // process_block) -- whatever the order the calls arrived in.  That order matters for setters that compute from what
+    // the other parameters are at that moment (SvfFilter's cutoff / q / gain, the envelope times): a cutoff set at once
+    // after a q change was queued is computed with the old q, and the q change, when due, with the new cutoff.
+    due_scratch.clear();
+    for (size_t ri = 0; ri < recs.size(); ++ri) {
+      const QRec& r = recs[ri];
       const StageInfo& S = stages[r.stage];
       uint16_t& armed = next_delay[static_cast<size_t>(S.param_base + r.param) * nv + r.voice];
       if (r.arm) armed = r.delay;
@@ -1373,6 +1385,14 @@ struct Bank final : knh_bank {
       const uint32_t due = std::max<uint32_t>(armed, q.at);
       if (due > frame_end) { q.blocked = 1; continue; }
       q.at = static_cast<uint16_t>(due);
+      due_scratch.push_back(DueRec{static_cast<uint32_t>(ri), due});
+    }
+    for (const auto& d : due_scratch) {  // (a node's queued changes: first in, first out, their due frames never decrease)
+      const QRec& r = recs[d.rec];
+      const StageInfo& S = stages[r.stage];
+      const double f = r.kind == KNH_VALUE_FLOAT ? r.v.f : 0.0;
+      const int64_t iv = r.kind == KNH_VALUE_FLOAT ? 0 : r.v.i;
+      const uint32_t due = d.due;
       const size_t first_ev = pending.size();
       apply_now(r.voice, r.stage, r.param, f, iv, frame_base + due, pending);
       if (due > frame_begin) {  // a split point: the node's block restarts here (precise_timing.rs:104-110)
