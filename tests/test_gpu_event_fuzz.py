@@ -26,7 +26,7 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
             {"KNH_JIT": "1", "KNH_JIT_PIPE": "0"}][(seed // 8) % 7]
     for k_, v_ in form.items():
         monkeypatch.setenv(k_, v_)
-    name = ["C5", "C3", "RANDOM", "D3", "P3", "C4", "M1", "DAG"][seed % 8]  # (B3's PolyBlep waveforms with a sin in them are tolerance-only)
+    name = ["C5", "C3", "RANDOM", "D3", "P3", "C4", "M1", "DAG", "SMOOTH", "C5", "RANDOM", "C3"][seed % 12]  # (B3's PolyBlep waveforms with a sin in them are tolerance-only)
     n = int(rng.integers(65, 260))
     bs = int(rng.choice([64, 128, 96]))
     first = []
@@ -45,9 +45,16 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         w.ctor = {s_: np.tile(np.asarray(a_, dtype=np.float64), (n, 1)) * ((1.0 + 0.01 * np.arange(n)).reshape(n, 1) if st[s_].kind == L.STAGE_SIN_WT else 1.0)
                   for s_, a_ in ctor.items()}
         first = [(i_, 2) for i_, x in enumerate(st) if x.kind == L.STAGE_MUL_ENV_AR]
+    elif name == "SMOOTH":  # WrSmoothParams (smooth_params.rs) on an oscillator, a filter (also precise-timed) and a constant
+        from knaster_amd.bank import Stage
+        SM = L.STAGE_FLAG_SMOOTH_PARAMS
+        p_ = configs.voice_parameters(n)
+        w = configs.Workload(f"smooth{seed}", [Stage(L.STAGE_SIN_WT, flags=SM), Stage(L.STAGE_SVF, flags=SM, delayed_changes_per_block=int(rng.integers(0, 4))),
+                                               Stage(L.STAGE_MUL_CONST, flags=SM)], n, bs, L.F32 if seed % 24 < 12 else L.F64, 2)
+        w.ctor = {0: p_["freq"].reshape(n, 1), 1: np.stack([np.zeros(n), p_["cutoff"], p_["q"], np.zeros(n)], axis=1), 2: np.full((n, 1), 1.0 / n)}
     else:
         w = configs.config(name, n_voices=n, block_size=bs, precise=int(rng.integers(0, 4)))
-    sharded = seed % 5 == 4                 # the scheduled-ahead bank with its host work on three threads (three voice ranges)
+    sharded = seed % 5 == 4 and os.environ.get("KNH_FUZZ_NO_SHARD") != "1"  # the scheduled-ahead bank with its host work on three threads (three voice ranges)
     a = make_gpu(knh, w, L.MIX_LEFT_FOLD)   # block by block, per-voice signals
     b = make_gpu(knh, w, host_threads=3 if sharded else 0)  # multi-block launches, changes scheduled ahead
     c = make_gpu(knh, w)                    # block by block, the same (tree) mix as b
@@ -57,7 +64,8 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         for p, pname in enumerate(a.stage_param_descriptions(s)):
             if pname in FLOATS or pname in TRIGGERS:
                 targets.append((s, p, pname))
-    assert targets
+    if not targets:
+        pytest.skip("a chain without a parameter this test knows how to set")
     # A delay armed on a wrapper's own parameter goes to the node it wraps (wrappers_core/math.rs:109-112), and if that node is a
     # WrPreciseTiming its next_delay array has no such index (precise_timing.rs:146-148: out of bounds): not a defined case.
     WRAPPERS = (L.STAGE_WR_MUL, L.STAGE_WR_ADD, L.STAGE_WR_SUB, L.STAGE_WR_VSUB, L.STAGE_WR_DIV, L.STAGE_WR_VDIV, L.STAGE_WR_POWF, L.STAGE_WR_POWI)
@@ -88,7 +96,12 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
             if rng.random() < 0.5:
                 v = np.sort(v)
             delays = rng.integers(0, bs, m).astype(np.uint16) if rng.random() < 0.8 and s not in no_delay else None
-            if pname in TRIGGERS:
+            if name == "SMOOTH" and pname not in TRIGGERS and rng.random() < 0.35:
+                # a Smoothing value for the parameter: off, or linear over a few milliseconds at block or audio rate
+                # (ParameterValue::Smoothing: seconds in the float, 0 none / 1 block rate / 2 audio rate in the integer)
+                mode = rng.integers(0, 3, m).astype(np.int64)
+                batches.append((v, s, p, L.VALUE_SMOOTHING, np.where(mode == 0, 0.0, rng.uniform(0.0005, 0.01, m)), delays, mode))
+            elif pname in TRIGGERS:
                 batches.append((v, s, p, L.VALUE_TRIGGER, None, delays))
             else:
                 lo, hi = FLOATS[pname]
@@ -97,9 +110,9 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
     # block by block
     mixes = []
     for blk in range(n_blocks):
-        for (v, s, p, kind, f, d) in plan[blk]:
+        for (v, s, p, kind, f, d, *iv) in plan[blk]:
             for bank in (a, c, o):
-                bank.param_apply_many(v, s, p, kind, f, None, d)
+                bank.param_apply_many(v, s, p, kind, f, iv[0] if iv else None, d)
         _, av, af = a.process_block_voices()
         _, ov, _of, od = o.process_block()
         assert_bit_equal(av, ov, f"seed {seed} {name} block {blk} per-voice")
@@ -117,12 +130,17 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
     while blk < n_blocks:
         k = min(int(rng.integers(1, 5)), n_blocks - blk)
         for i in range(k):
-            for (v, s, p, kind, f, d) in plan[blk + i]:
-                b.param_apply_many(v, s, p, kind, f, None, d, block_offset=i)
+            for (v, s, p, kind, f, d, *iv) in plan[blk + i]:
+                b.param_apply_many(v, s, p, kind, f, iv[0] if iv else None, d, block_offset=i)
         out = b.process_blocks(k)[0]
         for i in range(k):
             if sharded:  # (each voice range has a tree of its own: equal up to the re-association)
-                assert np.max(np.abs(out[i].astype(np.float64) - mixes[blk + i])) <= 1e-5 * max(1.0, float(np.abs(mixes[blk + i]).max())), (seed, blk + i)
+                want = mixes[blk + i].astype(np.float64)  # (a filter driven to NaN by the random settings is NaN on both sides)
+                assert np.array_equal(np.isfinite(out[i]), np.isfinite(want)), (seed, blk + i)
+                fin = np.isfinite(want)
+                if fin.any():
+                    err = float(np.max(np.abs(out[i].astype(np.float64)[fin] - want[fin])))
+                    assert err <= 1e-5 * max(1.0, float(np.abs(want[fin]).max())), (seed, blk + i, err)
             else:
                 assert_bit_equal(out[i], mixes[blk + i], f"seed {seed} {name}: block {blk + i} of a {k}-block launch")
         blk += k
