@@ -19,9 +19,10 @@ def make_oracle(oracle, w: configs.Workload, want_mix=True, want_voices=True):
     return b
 
 
-def make_gpu(knh, w: configs.Workload, mix_mode=L.MIX_TREE, allow_fma=False, host_threads=0):
+def make_gpu(knh, w: configs.Workload, mix_mode=L.MIX_TREE, allow_fma=False, host_threads=0, **kw):
+    """kw: devices=[..] (voice ranges on several GPUs) or rank=, world= (one rank's share), as VoiceBank takes them."""
     b = knh.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, mix_mode, -1, allow_fma, host_threads,
-                      in_channels=getattr(w, "in_channels", 0))
+                      in_channels=getattr(w, "in_channels", 0), **kw)
     for s, a in w.ctor.items():
         b.set_ctor_args(s, a)
     if w.buffer is not None:

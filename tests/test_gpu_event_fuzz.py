@@ -56,7 +56,10 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         w = configs.config(name, n_voices=n, block_size=bs, precise=int(rng.integers(0, 4)))
     sharded = seed % 5 == 4 and os.environ.get("KNH_FUZZ_NO_SHARD") != "1"  # the scheduled-ahead bank with its host work on three threads (three voice ranges)
     a = make_gpu(knh, w, L.MIX_LEFT_FOLD)   # block by block, per-voice signals
-    b = make_gpu(knh, w, host_threads=3 if sharded else 0)  # multi-block launches, changes scheduled ahead
+    # multi-block launches, changes scheduled ahead; for a fifth of the seeds the bank is cut into voice ranges: on three host
+    # threads, on three "GPUs" (all of them device 0 here), or as the one rank of a one-rank job
+    how = [{"host_threads": 3}, {"devices": [0, 0, 0]}, {"rank": 0, "world": 1}][(seed // 5) % 3] if sharded else {}
+    b = make_gpu(knh, w, **how)
     c = make_gpu(knh, w)                    # block by block, the same (tree) mix as b
     o = make_oracle(oracle, w)
     targets = []  # (stage, param, name)
