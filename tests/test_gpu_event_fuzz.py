@@ -26,7 +26,7 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
             {"KNH_JIT": "1", "KNH_JIT_PIPE": "0"}][(seed // 8) % 7]
     for k_, v_ in form.items():
         monkeypatch.setenv(k_, v_)
-    name = ["C5", "C3", "RANDOM", "D3", "P3", "C4", "M1", "DAG", "SMOOTH", "C5", "RANDOM", "C3"][seed % 12]  # (B3's PolyBlep waveforms with a sin in them are tolerance-only)
+    name = ["C5", "C3", "RANDOM", "D3", "P3", "C4", "M1", "DAG", "SMOOTH", "C5", "RANDOM", "INPUT"][seed % 12]  # (B3's PolyBlep waveforms with a sin in them are tolerance-only)
     n = int(rng.integers(65, 260))
     bs = int(rng.choice([64, 128, 96]))
     first = []
@@ -52,6 +52,17 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         w = configs.Workload(f"smooth{seed}", [Stage(L.STAGE_SIN_WT, flags=SM), Stage(L.STAGE_SVF, flags=SM, delayed_changes_per_block=int(rng.integers(0, 4))),
                                                Stage(L.STAGE_MUL_CONST, flags=SM)], n, bs, L.F32 if seed % 24 < 12 else L.F64, 2)
         w.ctor = {0: p_["freq"].reshape(n, 1), 1: np.stack([np.zeros(n), p_["cutoff"], p_["q"], np.zeros(n)], axis=1), 2: np.full((n, 1), 1.0 / n)}
+    elif name == "INPUT":  # a filter bank on the bank node's input 0, input 1 times a per-voice oscillator beside it
+        from knaster_amd.bank import Stage
+        p_ = configs.voice_parameters(n)
+        st = [Stage(L.STAGE_INPUT), Stage(L.STAGE_SVF, delayed_changes_per_block=int(rng.integers(0, 3))),
+              Stage(L.STAGE_MUL_ENV_ASR, delayed_changes_per_block=int(rng.integers(0, 3))),
+              Stage(L.STAGE_INPUT), Stage(L.STAGE_SIN_WT), Stage(L.STAGE_MATH_MUL, input=4, input2=5), Stage(L.STAGE_MATH_ADD, input=3, input2=6),
+              Stage(L.STAGE_MUL_CONST)]
+        w = configs.Workload(f"input{seed}", st, n, bs, L.F32 if seed % 24 < 12 else L.F64, 1, in_channels=2)
+        w.ctor = {0: np.zeros((n, 1)), 1: np.stack([np.full(n, 2.0), p_["cutoff"], p_["q"], np.zeros(n)], axis=1), 2: np.tile([0.002, 0.01], (n, 1)),
+                  3: np.ones((n, 1)), 4: p_["freq"].reshape(n, 1), 7: np.full((n, 1), 1.0 / n)}
+        first = [(2, 3)]
     else:
         w = configs.config(name, n_voices=n, block_size=bs, precise=int(rng.integers(0, 4)))
     sharded = seed % 5 == 4 and os.environ.get("KNH_FUZZ_NO_SHARD") != "1"  # the scheduled-ahead bank with its host work on three threads (three voice ranges)
@@ -83,6 +94,11 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
     envs = sum(x.kind in (L.STAGE_MUL_ENV_AR, L.STAGE_MUL_ENV_ASR, L.STAGE_MUL_ENVELOPE) for x in w.stages)
     several_envelopes_in_a_graph = name == "DAG" and envs > 1
     n_blocks = 12
+    ins = None
+    if getattr(w, "in_channels", 0):
+        t_ = np.arange(n_blocks * bs).reshape(n_blocks, 1, bs) / 48000.0
+        ins = np.concatenate([np.sin(2 * np.pi * 110.0 * (ch + 1) * t_) for ch in range(w.in_channels)], axis=1)
+        ins = (0.5 * ins + 0.05 * rng.standard_normal(ins.shape)).astype(np.float64 if w.sample_type == L.F64 else np.float32)
     plan = []
     for blk in range(n_blocks):
         batches = []
@@ -116,6 +132,9 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         for (v, s, p, kind, f, d, *iv) in plan[blk]:
             for bank in (a, c, o):
                 bank.param_apply_many(v, s, p, kind, f, iv[0] if iv else None, d)
+        if ins is not None:
+            for bank in (a, c, o):
+                bank.set_input(ins[blk])
         _, av, af = a.process_block_voices()
         _, ov, _of, od = o.process_block()
         assert_bit_equal(av, ov, f"seed {seed} {name} block {blk} per-voice")
@@ -135,6 +154,8 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         for i in range(k):
             for (v, s, p, kind, f, d, *iv) in plan[blk + i]:
                 b.param_apply_many(v, s, p, kind, f, iv[0] if iv else None, d, block_offset=i)
+        if ins is not None:
+            b.set_input(ins[blk:blk + k])
         out = b.process_blocks(k)[0]
         for i in range(k):
             if sharded:  # (each voice range has a tree of its own: equal up to the re-association)
