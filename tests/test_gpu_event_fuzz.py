@@ -26,7 +26,7 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
             {"KNH_JIT": "1", "KNH_JIT_PIPE": "0"}][(seed // 8) % 7]
     for k_, v_ in form.items():
         monkeypatch.setenv(k_, v_)
-    name = ["C5", "C3", "RANDOM", "D3", "P3", "C4", "M1", "DAG", "SMOOTH", "C5", "RANDOM", "INPUT"][seed % 12]  # (B3's PolyBlep waveforms with a sin in them are tolerance-only)
+    name = ["C5", "C3", "RANDOM", "D3", "P3", "C4", "M1", "DAG", "SMOOTH", "ARITH", "RANDOM", "INPUT"][seed % 12]  # (B3's PolyBlep waveforms with a sin in them are tolerance-only)
     n = int(rng.integers(65, 260))
     bs = int(rng.choice([64, 128, 96]))
     first = []
@@ -52,6 +52,17 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         w = configs.Workload(f"smooth{seed}", [Stage(L.STAGE_SIN_WT, flags=SM), Stage(L.STAGE_SVF, flags=SM, delayed_changes_per_block=int(rng.integers(0, 4))),
                                                Stage(L.STAGE_MUL_CONST, flags=SM)], n, bs, L.F32 if seed % 24 < 12 else L.F64, 2)
         w.ctor = {0: p_["freq"].reshape(n, 1), 1: np.stack([np.zeros(n), p_["cutoff"], p_["q"], np.zeros(n)], axis=1), 2: np.full((n, 1), 1.0 / n)}
+    elif name == "ARITH":  # oscillators and arithmetic only: the frame-parallel forms (voice_frame.hpp; the interpreter for every other seed of these)
+        from test_gpu_dag import arithmetic_dag
+        from knaster_amd.bank import Stage
+        st, ctor = arithmetic_dag(np.random.default_rng(900 + seed), int(rng.integers(5, 40)))
+        if sum(x.kind == L.STAGE_SIN_WT for x in st) < 2:
+            st.append(Stage(L.STAGE_SIN_WT))
+            ctor[len(st) - 1] = [333.0]
+            st.append(Stage(L.STAGE_MATH_ADD, input=len(st), input2=len(st) - 1))
+        w = configs.Workload(f"arith{seed}", st, n, bs, L.F32 if seed % 24 < 12 else L.F64, 1)
+        w.ctor = {s_: np.tile(np.asarray(a_, dtype=np.float64), (n, 1)) * (1.0 + 0.01 * np.arange(n)).reshape(n, 1) for s_, a_ in ctor.items()}
+        monkeypatch.setenv("KNH_FRAME_JIT", "1" if (seed // 12) % 2 else "0")
     elif name == "INPUT":  # a filter bank on the bank node's input 0, input 1 times a per-voice oscillator beside it
         from knaster_amd.bank import Stage
         p_ = configs.voice_parameters(n)
