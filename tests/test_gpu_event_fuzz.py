@@ -181,3 +181,44 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
         blk += k
     for bank in (a, b, c, o):
         bank.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "16"))))
+def test_changes_between_partial_blocks_equal_delayed_changes(knh, monkeypatch, seed):
+    """Two ways a host gets a change to land on frame k of a block, which the reference defines to be the same thing
+    (precise_timing.rs:65-114 is literally the first done by the wrapper): processing frames [0, k), applying the change,
+    processing [k, B) (BlockMetadata::make_partial, ugen.rs:87-93) -- or arming a delay of k on a WrPreciseTiming-wrapped
+    node and processing the whole block.  Every stage of the chain is wrapped, one change per voice and block."""
+    from knaster_amd.bank import Stage
+    rng = np.random.default_rng(9000 + seed)
+    form = [{}, {"KNH_PIPE_BIG": "0"}, {"KNH_PIPELINE": "0"}, {"KNH_PIPE_BIG": "1"}][seed % 4]
+    for k_, v_ in form.items():
+        monkeypatch.setenv(k_, v_)
+    n = int(rng.integers(65, 200))
+    bs = int(rng.choice([64, 128, 256]))
+    p_ = configs.voice_parameters(n)
+    st = [Stage(L.STAGE_SIN_WT, delayed_changes_per_block=1), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_SVF, delayed_changes_per_block=1),
+          Stage(L.STAGE_MUL_ENV_ASR, delayed_changes_per_block=1)]
+    w = configs.Workload(f"partial{seed}", st, n, bs, L.F32 if seed % 8 < 4 else L.F64, 2)
+    w.ctor = {0: p_["freq"].reshape(n, 1), 1: np.full((n, 1), 1.0 / n), 2: np.stack([np.zeros(n), p_["cutoff"], p_["q"], np.zeros(n)], axis=1),
+              3: np.stack([p_["attack"], p_["release"]], axis=1)}
+    whole, parts = make_gpu(knh, w), make_gpu(knh, w)
+    v_all = np.arange(n, dtype=np.uint32)
+    for bank in (whole, parts):
+        bank.param_apply_many(v_all, 3, 3, L.VALUE_TRIGGER)
+    targets = [(0, 0, "freq"), (0, 1, "phase_offset"), (2, 0, "cutoff_freq"), (2, 1, "q"), (3, 0, "attack_time"), (3, 1, "release_time"), (3, 2, "t_release"), (3, 3, "t_restart")]
+    for blk in range(10):
+        k = int(rng.integers(1, bs))
+        s, p, pname = targets[int(rng.integers(0, len(targets)))]
+        v = np.sort(rng.choice(n, int(rng.integers(1, n + 1)), replace=False)).astype(np.uint32)
+        kind = L.VALUE_TRIGGER if pname.startswith("t_") else L.VALUE_FLOAT
+        f = None if kind == L.VALUE_TRIGGER else rng.uniform(*FLOATS[pname], len(v))
+        whole.param_apply_many(v, s, p, kind, f, None, np.full(len(v), k, dtype=np.uint16))
+        ref, _ = whole.process_block()
+        out = np.zeros_like(ref)
+        parts.process_block(frames_to_process=k, block_start_offset=0, out=out)
+        parts.param_apply_many(v, s, p, kind, f)
+        parts.process_block(frames_to_process=bs - k, block_start_offset=k, out=out)
+        assert_bit_equal(out, ref, f"seed {seed} block {blk}: {pname} on {len(v)} voices at frame {k} of {bs}")
+    whole.close()
+    parts.close()
