@@ -242,9 +242,10 @@ typedef struct knh_stage_desc {
    * several stages and stages need not follow their input directly.  Source stages read nothing (except SIN_WT with
    * KNH_STAGE_FLAG_AR_FREQ, whose frequency this signal drives); wrapper stages (KNH_STAGE_WR_*) wrap the stage before
    * them and keep 0.  `input2` is the second operand of the KNH_STAGE_MATH_* stages and 0 everywhere else.
-   * (A voice with several envelope stages reports, as its done frame, the mark of the last of them IN LIST ORDER that
-   * finished in the block -- list order being the task order of a chain; a graph that wants another node's mark to win
-   * lists that node later.)
+   * (A voice with several envelope stages reports, as its done frame, the mark of the last of them in the reference's
+   * TASK order that finished in the block -- one UGenFlags for all tasks of a graph, graph_gen.rs:196-200.  For a chain
+   * that is list order; for a graph it is the order Graph::calculate_node_order gives: depth first from the voice's output,
+   * first operand first.)
    * "The output of stage k - 1" is the output of the NODE that stage stands for: if wrapper stages follow it, what the
    * reader gets is the last wrapper's output (the reference's wr_mul() etc. are part of the UGen they wrap). */
   uint16_t input;

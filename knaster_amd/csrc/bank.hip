@@ -230,6 +230,7 @@ struct StageInfo {
   uint16_t kind, flags, dcpb;
   int slot_base, n_slots, n_params, n_ctor;
   int param_base;  // index of this stage's first parameter in the flat per-voice parameter table
+  uint16_t input = 0, input2 = 0;  // knh_stage_desc: the stage(s) whose output this one reads (0: the one before it)
 };
 
 struct HostEvent {
@@ -347,6 +348,7 @@ struct Bank final : knh_bank {
   const knh::JitKernel* frame_jit = nullptr;
   uint32_t* d_sin_slots = nullptr;
   unsigned frame_vpw = 1, n_sin = 0;
+  uint64_t env_ranks = 0;  // VoiceKernelArgs::env_ranks (graph-shaped voices with several envelope stages)
   const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
   int pipeline_level = 1;                // KNH_PIPELINE
   std::string signature;
@@ -623,6 +625,45 @@ struct Bank final : knh_bank {
             if (frame_jit) frame_vpw = vpw;
             else warnings.push_back("frame-parallel kernel not built (" + why.substr(0, 300) + "): the interpreter runs the voice");
           }
+        }
+      }
+    }
+    env_ranks = 0;
+    if (signature_is_dag(signature)) {
+      // Which envelope's mark_done names the voice's done frame when several finish in one block: the last one in the
+      // reference's TASK order (graph_gen.rs:196-200), which for a graph is the order Graph::calculate_node_order sorts the
+      // nodes into (graph.rs:1938-2067): depth first from the output, a node's inputs in channel order, each node after
+      // everything it reads; nodes the output does not depend on come last, in the order they were pushed.
+      const int n = static_cast<int>(stages.size());
+      auto is_src = [&](int i) { return std::strchr("WNPUKOGBFI", kKinds[stages[i].kind].sig) != nullptr && !(stages[i].flags & KNH_STAGE_FLAG_AR_FREQ); };
+      auto node_output = [&](int k) { while (k + 1 < n && is_wrapper_kind(stages[k + 1].kind)) ++k; return k; };
+      std::vector<int> a(n, -1), b(n, -1);
+      for (int i = 0; i < n; ++i) {
+        if (is_math2_kind(stages[i].kind)) { a[i] = node_output(stages[i].input - 1); b[i] = node_output(stages[i].input2 - 1); }
+        else if (i > 0 && !is_src(i)) a[i] = stages[i].input ? node_output(stages[i].input - 1) : i - 1;
+      }
+      std::vector<int> order, state(n, 0), stack{n - 1};
+      while (!stack.empty()) {  // post-order, first operand first
+        const int k = stack.back();
+        if (state[k] == 0) { state[k] = 1; if (a[k] >= 0 && state[a[k]] == 0) { stack.push_back(a[k]); continue; } }
+        if (state[k] == 1) { state[k] = 2; if (b[k] >= 0 && state[b[k]] == 0) { stack.push_back(b[k]); continue; } }
+        if (state[k] == 2) { state[k] = 3; order.push_back(k); }
+        stack.pop_back();
+      }
+      for (int i = 0; i < n; ++i) if (state[i] == 0) order.push_back(i);
+      std::vector<int> rank(n, 0);
+      for (size_t r = 0; r < order.size(); ++r) rank[order[r]] = static_cast<int>(r);
+      std::vector<int> envs;
+      for (int i = 0; i < n; ++i)
+        if (stages[i].kind == KNH_STAGE_MUL_ENV_ASR || stages[i].kind == KNH_STAGE_MUL_ENV_AR || stages[i].kind == KNH_STAGE_MUL_ENVELOPE) envs.push_back(i);
+      bool in_list_order = true;
+      for (size_t j = 1; j < envs.size(); ++j) in_list_order = in_list_order && rank[envs[j - 1]] < rank[envs[j]];
+      if (!in_list_order && envs.size() <= 15) {
+        std::vector<int> by_rank(envs);
+        std::sort(by_rank.begin(), by_rank.end(), [&](int x, int y) { return rank[x] < rank[y]; });
+        for (size_t j = 0; j < envs.size(); ++j) {
+          const uint64_t place = 1 + static_cast<uint64_t>(std::find(by_rank.begin(), by_rank.end(), envs[j]) - by_rank.begin());
+          env_ranks |= place << (4 * j);
         }
       }
     }
@@ -1639,6 +1680,7 @@ struct Bank final : knh_bank {
     a.state = d_state;
     a.stride = stride;
     a.n_voices = nv;
+    a.env_ranks = env_ranks;
     a.block_size = static_cast<uint32_t>(block_size);
     a.n_blocks = n_blocks;
     a.frame_begin = fb;
@@ -1966,7 +2008,8 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
   int slot = 0, pbase = 0;
   for (uint32_t i = 0; i < d.n_stages; ++i) {
     const KindInfo& k = kKinds[d.stages[i].kind];
-    StageInfo s{d.stages[i].kind, d.stages[i].flags, d.stages[i].delayed_changes_per_block, slot, k.n_slots, k.n_params, k.n_ctor, pbase};
+    StageInfo s{d.stages[i].kind, d.stages[i].flags, d.stages[i].delayed_changes_per_block, slot, k.n_slots, k.n_params, k.n_ctor, pbase,
+                d.stages[i].input, d.stages[i].input2};
     b->stages.push_back(s);
     b->ctor.emplace_back(static_cast<size_t>(d.n_voices) * (k.n_ctor > 0 ? k.n_ctor : 0), 0.0);
     slot += k.n_slots;

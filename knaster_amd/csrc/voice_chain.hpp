@@ -1901,6 +1901,7 @@ struct DagChain<F, FMA, BASE, R, LAST, Slots<R2>> {
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
   __device__ __forceinline__ u32 collect_done(u32 acc) const { return acc; }
+  template <int J> __device__ __forceinline__ void collect_done_ranked(u64, u32&, u32&) const {}
   __device__ __forceinline__ void begin_block(u32, const Ctx&) {}
 };
 template <typename F, bool FMA, int BASE, int R, int LAST, typename N0, typename... Rest>
@@ -1959,6 +1960,17 @@ struct DagChain<F, FMA, BASE, R, LAST, N0, Rest...> {
     if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
     return rest.collect_done(acc);
   }
+  // The same with the envelopes taken in the reference's task order (one UGenFlags for all tasks of a graph: the last
+  // mark_done wins, graph_gen.rs:196-200): J = this stage's number among the envelope stages, ranks = VoiceKernelArgs::env_ranks.
+  template <int J> __device__ __forceinline__ void collect_done_ranked(u64 ranks, u32& best_rank, u32& best) const {
+    if constexpr (S0::kIsEnv) {
+      const u32 rk = J < 16 ? (u32)((ranks >> (4 * (J < 16 ? J : 0))) & 15ull) : 0u;
+      if (mark != 0xFFFFFFFFu && (best == 0xFFFFFFFFu || rk > best_rank)) { best = mark; best_rank = rk; }
+      rest.template collect_done_ranked<J + 1>(ranks, best_rank, best);
+    } else {
+      rest.template collect_done_ranked<J>(ranks, best_rank, best);
+    }
+  }
   __device__ __forceinline__ void pan_gains(F& l, F& rg) const {
     if constexpr (IsPan<S0>::value) { l = r.l; rg = r.r; }
     else rest.pan_gains(l, rg);
@@ -2011,6 +2023,8 @@ struct VoiceKernelArgs {
   F* partials;                      // [n_blocks][n_waves][block_size]: per-wavefront left-fold of its voices
                                     // (chains ending in Pan2: [n_blocks][2][n_waves][block_size], left and right)
   F* voices_out;                    // [n_voices][block_size] or null (n_blocks == 1 only); Pan2 chains: [2][n_voices][block_size]
+  u64 env_ranks;                    // a graph-shaped voice with several envelope stages: nibble j = the place of the j-th of them (list
+                                    // order) in the reference's task order (graph.rs calculate_node_order); 0: list order is task order
   u32* done_frames;                 // [n_voices]
   u32* flags;                       // [0] |= any-done, [1] += voices whose last envelope is not Stopped
 };
@@ -2229,7 +2243,17 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
     apply_events_upto(base + a.frame_end);
   }
 
-  const u32 done_frame = chain.collect_done(0xFFFFFFFFu);
+  u32 done_frame = 0xFFFFFFFFu;
+  if constexpr (SlotCount<S...>::value > 0) {  // a graph-shaped voice: its envelopes in the reference's task order, when that is not list order
+    if (a.env_ranks != 0ull) {
+      u32 best_rank = 0u;
+      chain.template collect_done_ranked<0>(a.env_ranks, best_rank, done_frame);
+    } else {
+      done_frame = chain.collect_done(0xFFFFFFFFu);
+    }
+  } else {
+    done_frame = chain.collect_done(0xFFFFFFFFu);
+  }
   if (live) {
     chain.store(a.state + voice, a.stride);
     a.done_frames[voice] = done_frame;
