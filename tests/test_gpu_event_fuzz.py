@@ -27,8 +27,8 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
     for k_, v_ in form.items():
         monkeypatch.setenv(k_, v_)
     name = ["C5", "C3", "RANDOM", "D3", "P3", "C4", "M1", "DAG", "SMOOTH", "ARITH", "RANDOM", "INPUT"][seed % 12]  # (B3's PolyBlep waveforms with a sin in them are tolerance-only)
-    n = int(rng.integers(65, 260))
-    bs = int(rng.choice([64, 128, 96]))
+    n = int(rng.integers(65, 260)) if seed % 3 else int(rng.integers(1, 140))
+    bs = int(rng.choice([64, 128, 96])) if seed % 2 else int(rng.choice([16, 17, 33, 40, 100, 200, 256]))  # (ragged tiles too)
     first = []
     if name == "RANDOM":  # a random chain of the run-time fused kind (delay lines, segment envelopes, wrappers ..), its own sizes
         from test_gpu_random_chains import random_chain
