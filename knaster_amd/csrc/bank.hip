@@ -286,6 +286,8 @@ struct knh_bank {
   virtual int set_delay(uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) = 0;
   virtual int call_at(uint32_t block_offset, bool is_delay, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f,
                       int64_t i, uint16_t delay) = 0;
+  // would a value of this kind for this parameter of this voice be accepted?  (no side effect)
+  virtual int check_call(uint32_t /*voice*/, uint32_t /*stage*/, uint32_t /*param*/, uint32_t /*kind*/) { return KNH_OK; }
   virtual int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t clock, void* out_host, void* out_device,
                       void* voices_host, uint32_t* out_flags, void* stream, bool sync, bool accumulate = false) = 0;
   // knh_bank_param_apply_many[_at]: the calls in array order (block_offset 0 = now); a host-sharded bank spreads them
@@ -295,7 +297,9 @@ struct knh_bank {
     int rc = KNH_OK;
     for (size_t k = 0; k < count; ++k) {
       if (delays && delays[k] > 0) {
-        int r = call_at(block_offset, true, voices[k], stgs[k], params[k], 0, 0.0, 0, delays[k]);
+        // (a call that is going to be refused -- a value of the wrong kind -- must not leave its delay armed for the next one)
+        int r = check_call(voices[k], stgs[k], params[k], kinds[k]);
+        if (r == KNH_OK) r = call_at(block_offset, true, voices[k], stgs[k], params[k], 0, 0.0, 0, delays[k]);
         if (r != KNH_OK) { rc = r; continue; }
       }
       int r = call_at(block_offset, false, voices[k], stgs[k], params[k], kinds[k], fvalues ? fvalues[k] : 0.0, ivalues ? ivalues[k] : 0, 0);
@@ -1123,6 +1127,12 @@ struct Bank final : knh_bank {
   }
   // The same two calls addressed to block `block_offset` of the next multi-block launch: validated now,
   // replayed in order when that block is assembled.
+  int check_call(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind) override {
+    int rc = check_target(voice, stage, param);
+    if (rc != KNH_OK) return rc;
+    if (!kind_ok(stages[stage], param, kind)) return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
+    return KNH_OK;
+  }
   int call_at(uint32_t block_offset, bool is_delay, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f,
               int64_t i, uint16_t delay) override {
     if (block_offset == 0) return is_delay ? set_delay(voice, stage, param, delay) : param_apply(voice, stage, param, kind, f, i);

@@ -221,3 +221,56 @@ def test_changes_between_partial_blocks_equal_delayed_changes(knh, monkeypatch, 
         assert_bit_equal(out, ref, f"seed {seed} block {blk}: {pname} on {len(v)} voices at frame {k} of {bs}")
     whole.close()
     parts.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "12"))))
+def test_bad_calls_are_refused_and_leave_no_trace(knh, seed):
+    """Batches with out-of-range voices, stages, parameter indices and wrong value kinds among good calls: the call reports an
+    error, the good calls of the batch take effect, the bad ones leave nothing behind -- the bank renders what a bank that
+    only ever saw the good calls renders (and no kernel ever sees an index the host did not check)."""
+    rng = np.random.default_rng(11000 + seed)
+    name = ["C3", "C5", "D3", "M1"][seed % 4]
+    n = int(rng.integers(10, 200))
+    bs = int(rng.choice([64, 100, 128]))
+    w = configs.config(name, n_voices=n, block_size=bs, precise=int(rng.integers(0, 3)))
+    clean, dirty = make_gpu(knh, w), make_gpu(knh, w)
+    targets = []
+    for s in range(len(w.stages)):
+        for p, pname in enumerate(clean.stage_param_descriptions(s)):
+            if pname in FLOATS or pname in TRIGGERS:
+                targets.append((s, p, pname))
+    v_all = np.arange(n, dtype=np.uint32)
+    if w.restart:
+        for bank in (clean, dirty):
+            bank.param_apply_many(v_all, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+    for blk in range(8):
+        for _ in range(int(rng.integers(1, 4))):
+            s, p, pname = targets[int(rng.integers(0, len(targets)))]
+            m = int(rng.integers(1, 3 * n))
+            v = rng.integers(0, n, m).astype(np.uint32)
+            st_ = np.full(m, s, dtype=np.uint32)
+            pa = np.full(m, p, dtype=np.uint32)
+            trig = pname in TRIGGERS
+            kinds = np.full(m, L.VALUE_TRIGGER if trig else L.VALUE_FLOAT, dtype=np.uint32)
+            f = np.zeros(m) if trig else rng.uniform(*FLOATS[pname], m)
+            d = rng.integers(0, bs, m).astype(np.uint16)
+            bad = rng.random(m) < 0.15
+            how = rng.integers(0, 4, m)
+            vb, sb, pb, kb = v.copy(), st_.copy(), pa.copy(), kinds.copy()
+            vb[bad & (how == 0)] = n + rng.integers(0, 1000)
+            sb[bad & (how == 1)] = len(w.stages) + rng.integers(0, 50)
+            pb[bad & (how == 2)] = 7 + rng.integers(0, 50)
+            kb[bad & (how == 3)] = L.VALUE_FLOAT if trig else L.VALUE_TRIGGER
+            off = int(rng.integers(0, 2))
+            good = ~bad
+            if good.any():
+                clean.param_apply_many(v[good], st_[good], pa[good], kinds[good], f[good], None, d[good], block_offset=off)
+            if bad.any():
+                with pytest.raises(L.KnasterHipError):
+                    dirty.param_apply_many(vb, sb, pb, kb, f, None, d, block_offset=off)
+            else:
+                dirty.param_apply_many(vb, sb, pb, kb, f, None, d, block_offset=off)
+        k = 2
+        assert_bit_equal(dirty.process_blocks(k)[0], clean.process_blocks(k)[0], f"seed {seed} {name} blocks {2 * blk}..")
+    clean.close()
+    dirty.close()
