@@ -119,7 +119,7 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
                 batches.append((np.arange(n, dtype=np.uint32), s0, p0, L.VALUE_TRIGGER, None, None))
         for _ in range(int(rng.integers(0, 6))):
             s, p, pname = targets[int(rng.integers(0, len(targets)))]
-            m = int(rng.integers(1, 2 * n))
+            m = int(rng.integers(1, 2 * n)) if rng.random() < 0.8 else int(rng.integers(1, 13))
             v = rng.integers(0, n, m).astype(np.uint32)          # repeats: several changes of one node in one block
             if rng.random() < 0.5:
                 v = np.sort(v)
@@ -143,6 +143,14 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
     for blk in range(n_blocks):
         for (v, s, p, kind, f, d, *iv) in plan[blk]:
             for bank in (a, c, o):
+                if bank is a and len(v) <= 12 and kind in (L.VALUE_FLOAT, L.VALUE_TRIGGER):
+                    # the UGen entry points themselves, call by call (set_delay_within_block_for_param, then param_apply)
+                    from knaster_amd.bank import TRIGGER
+                    for q in range(len(v)):
+                        if d is not None and d[q] > 0:
+                            bank.set_delay_within_block_for_param(int(v[q]), s, p, int(d[q]))
+                        bank.param_apply(int(v[q]), s, p, TRIGGER if kind == L.VALUE_TRIGGER else float(f[q]))
+                    continue
                 bank.param_apply_many(v, s, p, kind, f, iv[0] if iv else None, d)
         if ins is not None:
             for bank in (a, c, o):
