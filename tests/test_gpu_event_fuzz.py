@@ -14,8 +14,9 @@ from knaster_amd import configs
 pytestmark = pytest.mark.gpu
 
 FLOATS = {"freq": (50.0, 3000.0), "phase_offset": (0.0, 1.0), "wr_mul": (-1.0, 1.0), "cutoff_freq": (200.0, 6000.0), "q": (0.5, 4.0),
-          "attack_time": (0.001, 0.02), "release_time": (0.005, 0.1), "value": (-1.0, 1.0)}
-TRIGGERS = {"t_restart", "t_release", "reset_phase"}
+          "attack_time": (0.001, 0.02), "release_time": (0.005, 0.1), "value": (-1.0, 1.0), "pan": (-1.0, 1.0), "gain": (-6.0, 6.0),
+          "delay_time": (0.0, 0.0045), "feedback": (-0.8, 0.8), "time_scale": (0.5, 2.0), "pulse_width": (0.1, 0.9)}
+TRIGGERS = {"t_restart", "t_release", "reset_phase", "t_stop", "t_calculate_coefficients"}
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "32"))))
