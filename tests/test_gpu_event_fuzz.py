@@ -17,6 +17,8 @@ FLOATS = {"freq": (50.0, 3000.0), "phase_offset": (0.0, 1.0), "wr_mul": (-1.0, 1
           "attack_time": (0.001, 0.02), "release_time": (0.005, 0.1), "value": (-1.0, 1.0), "pan": (-1.0, 1.0), "gain": (-6.0, 6.0),
           "delay_time": (0.0, 0.0045), "feedback": (-0.8, 0.8), "time_scale": (0.5, 2.0), "pulse_width": (0.1, 0.9)}
 TRIGGERS = {"t_restart", "t_release", "reset_phase", "t_stop", "t_calculate_coefficients"}
+INTS = {"filter": (0, 9), "jump_to_segment": (0, 4)}   # PInteger parameters (SvfFilter's type, Envelope's segment)
+BOOLS = {"looping"}
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "32"))))
@@ -88,7 +90,7 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
     targets = []  # (stage, param, name)
     for s in range(len(w.stages)):
         for p, pname in enumerate(a.stage_param_descriptions(s)):
-            if pname in FLOATS or pname in TRIGGERS:
+            if pname in FLOATS or pname in TRIGGERS or pname in INTS or pname in BOOLS:
                 targets.append((s, p, pname))
     if not targets:
         pytest.skip("a chain without a parameter this test knows how to set")
@@ -128,11 +130,15 @@ def test_random_parameter_traffic(knh, oracle, monkeypatch, seed):
             # anything queued behind it on the same node -- precise_timing.rs:65-114)
             hi_delay = bs + bs // 2 if rng.random() < 0.2 else bs
             delays = rng.integers(0, hi_delay, m).astype(np.uint16) if rng.random() < 0.8 and s not in no_delay else None
-            if name == "SMOOTH" and pname not in TRIGGERS and rng.random() < 0.35:
+            if name == "SMOOTH" and pname in FLOATS and rng.random() < 0.35:
                 # a Smoothing value for the parameter: off, or linear over a few milliseconds at block or audio rate
                 # (ParameterValue::Smoothing: seconds in the float, 0 none / 1 block rate / 2 audio rate in the integer)
                 mode = rng.integers(0, 3, m).astype(np.int64)
                 batches.append((v, s, p, L.VALUE_SMOOTHING, np.where(mode == 0, 0.0, rng.uniform(0.0005, 0.01, m)), delays, mode))
+            elif pname in INTS:
+                batches.append((v, s, p, L.VALUE_INTEGER, None, delays, rng.integers(*INTS[pname], m).astype(np.int64)))
+            elif pname in BOOLS:
+                batches.append((v, s, p, L.VALUE_BOOL, None, delays, rng.integers(0, 2, m).astype(np.int64)))
             elif pname in TRIGGERS:
                 batches.append((v, s, p, L.VALUE_TRIGGER, None, delays))
             else:
