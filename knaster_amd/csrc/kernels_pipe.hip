@@ -84,7 +84,8 @@ static const PipeEntry kTable[] = {
     KNH_PIPE_BIG("WSA", 3, G_W, G_S, G_A)
     KNH_PIPE("WSA", 3, G_W, G_S, G_A)
     KNH_PIPE("WS", 2, G_W, G_S)
-    KNH_PIPE("WmaRm", 2, G_Wma, G_Rm)     // C5: modulator | carrier
+    KNH_PIPE_BIG("WmaRm", 2, G_Wma, G_Rm) // C5: modulator | carrier (in place) | mixer, 64-sample tiles
+    KNH_PIPE("WmaRm", 2, G_Wma, G_Rm)     // the same with 32-sample tiles
     KNH_PIPE_FAN_("Nm", 2, G_Np, F_Nm)    // C2: phase | sin * gain on eight wavefronts | mixer
     KNH_PIPE_FAN_("N", 2, G_Np, F_N)
     KNH_PIPE("NSAm", 3, G_N, G_S, G_Am)
