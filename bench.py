@@ -4,10 +4,16 @@
 Workload (`value`): BASELINE.json configs[2] ("C3"): 16384 voices per GPU, chain
 SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, block_size 512, f32, 48 kHz, synthetic per-voice parameters
 (xorshift32); weak scaling (voices per GPU fixed).  One *step* = one pass of the hot path over one
-batch: BLOCKS_PER_STEP (64) consecutive 512-frame blocks of every voice on every rank, rendered in ONE launch
+batch: LAUNCHES_PER_STEP (4) launches of BLOCKS_PER_LAUNCH (64) consecutive 512-frame blocks of every voice on every rank
 (knh_bank_process_blocks_device: voice state stays in registers across the blocks of a launch; results are
-bit-identical to one launch per block, tests/test_gpu_properties.py) -- the note cycle of SURVEY.md 8(d)
-(t_restart at block 0, t_release at block 32).  `value` counts every block of every step.
+bit-identical to one launch per block, tests/test_gpu_properties.py) -- four note cycles of SURVEY.md 8(d)
+(t_restart at block 0, t_release at block 32 of every 64).  `value` counts every block of every step.  (Four launches to
+a step so that the driver's 20 timed steps last ~70 ms, not 17.)
+
+Beside `value` the line carries: `host_output` -- the same path when the blocks are handed to the HOST, including
+`per_block_value`, the rate of the call the reference actually makes (UGen::process_block once per block through
+knh_bank_process_block, Task::run in knaster_graph/src/task.rs:25-31), for C3 and C1; and `configs` -- short legs of the
+other BASELINE.json configurations (C1, C2, C5; C4 is `c4_strong`), each kernel-only and wall.
 
 Several GPUs: one process per GPU; each rank creates its share of the bank with knh_bank_create_rank (contiguous
 voice ranges, global voice indices) and the LIBRARY sums each launch's stereo blocks to rank 0 with RCCL's ncclReduce
@@ -46,14 +52,16 @@ OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per
 SVF_STEP_CYCLES = 44.0
 SHADER_CLOCK_GHZ = 2.4
 PIPE_TILE = 64                 # samples per pipeline step of the shipped C3 kernel (voice_pipe.hpp)
-BLOCKS_PER_STEP = 64           # blocks per step = per launch = per RCCL reduce (one note cycle)
+BLOCKS_PER_LAUNCH = 64         # blocks per launch = per RCCL reduce (one note cycle)
+LAUNCHES_PER_STEP = 4          # a step = four such launches: the driver's 20 steps then time ~70 ms, not 17
+BLOCKS_PER_STEP = BLOCKS_PER_LAUNCH * LAUNCHES_PER_STEP
 PREWARM_MS = 150.0             # untimed launches before the warm-up steps: the shader clock needs a few ms of load to come up
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one 64-block launch per rank")
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = four 64-block launches per rank")
     ap.add_argument("--warmup", type=int, default=4, help="untimed steps before the timed ones")
     ap.add_argument("--config", choices=["C3", "C4"], default="C3", help="headline workload: C3 weak scaling (default) or C4 strong scaling")
     ap.add_argument("--voices-per-gpu", type=int, default=16384, help="C3: voices per GPU (weak scaling)")
@@ -62,6 +70,7 @@ def parse():
     ap.add_argument("--allow-fma", action="store_true", help="non-bit-exact FMA kernels (reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the secondary C4 strong-scaling measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short C1 / C2 / C5 legs and the per-block boundary legs")
     ap.add_argument("--cpu-baseline-blocks", type=int, default=0, help="0 = auto (about 10-20 s)")
     return ap.parse_args()
 
@@ -177,9 +186,9 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     w_all = configs.config(name, n_voices=total_voices, block_size=bs)
     lo, cnt = knaster_amd.shard_voice_range(total_voices, env.rank, env.world)
     tdtype = torch.float64 if w_all.sample_type == L.F64 else torch.float32
-    # the mixed stereo blocks of a launch: [BLOCKS_PER_STEP][channels][block_size], resident in HBM; two of them, used
+    # the mixed stereo blocks of a launch: [BLOCKS_PER_LAUNCH][channels][block_size], resident in HBM; two of them, used
     # alternately, so that the library's reduce of one launch overlaps the next launch's kernels
-    rings = [torch.zeros((BLOCKS_PER_STEP, w_all.out_channels, bs), dtype=tdtype, device=env.dev) for _ in range(2)]
+    rings = [torch.zeros((BLOCKS_PER_LAUNCH, w_all.out_channels, bs), dtype=tdtype, device=env.dev) for _ in range(2)]
 
     def make_bank(collective: str):
         kwargs = dict(rank=env.rank, world=env.world)
@@ -221,17 +230,20 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     launch_no = [0]
 
     def schedule():
-        """The parameter events of one step (a 64-block note cycle): t_restart at block 0, t_release at block 32."""
+        """The parameter events of one launch (a 64-block note cycle): t_restart at block 0, t_release at block 32."""
         if cnt:
             bank.param_apply_prepared(restart, 0)
-            bank.param_apply_prepared(release, BLOCKS_PER_STEP // 2)
+            bank.param_apply_prepared(release, BLOCKS_PER_LAUNCH // 2)
 
-    def run_steps(n: int):
+    def run_launches(n: int):
         for _ in range(n):
             half = launch_no[0] & 1
             launch_no[0] += 1
             schedule()
-            bank.process_blocks_device(BLOCKS_PER_STEP, rings[half].data_ptr(), env.stream.cuda_stream)
+            bank.process_blocks_device(BLOCKS_PER_LAUNCH, rings[half].data_ptr(), env.stream.cuda_stream)
+
+    def run_steps(n: int):
+        run_launches(n * LAUNCHES_PER_STEP)
 
     def fence():
         bank.synchronize()  # this rank's kernels and reduces
@@ -241,7 +253,7 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     # (every rank runs the same number of launches -- each launch holds a collective: the ranks agree after every pair)
     t_pre, n_pre = time.perf_counter(), 0
     while True:
-        run_steps(2)
+        run_launches(2)
         bank.synchronize()
         n_pre += 2
         if env.max_over_ranks((time.perf_counter() - t_pre) * 1e3) >= PREWARM_MS:
@@ -264,24 +276,24 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     if env.world == 1:
         n_host = 32
         schedule()
-        bank.process_blocks(BLOCKS_PER_STEP)
+        bank.process_blocks(BLOCKS_PER_LAUNCH)
         schedule()
-        bank.process_blocks_begin(BLOCKS_PER_STEP)  # untimed: the pipelined path's buffers and stream are made on first use
+        bank.process_blocks_begin(BLOCKS_PER_LAUNCH)  # untimed: the pipelined path's buffers and stream are made on first use
         bank.process_blocks_end()
         t1 = time.perf_counter()
         for _ in range(n_host):  # launch by launch: each call returns with its blocks in host memory
             schedule()
-            bank.process_blocks(BLOCKS_PER_STEP)
-        host_rate_blocking = float(total_voices) * bs * ugens * BLOCKS_PER_STEP * n_host / (time.perf_counter() - t1)
+            bank.process_blocks(BLOCKS_PER_LAUNCH)
+        host_rate_blocking = float(total_voices) * bs * ugens * BLOCKS_PER_LAUNCH * n_host / (time.perf_counter() - t1)
         t1 = time.perf_counter()
         schedule()
-        bank.process_blocks_begin(BLOCKS_PER_STEP)
+        bank.process_blocks_begin(BLOCKS_PER_LAUNCH)
         for i in range(n_host):  # two launches in flight: launch i + 1 is enqueued before launch i's blocks are fetched
             if i + 1 < n_host:
                 schedule()
-                bank.process_blocks_begin(BLOCKS_PER_STEP)
+                bank.process_blocks_begin(BLOCKS_PER_LAUNCH)
             host_blocks = bank.process_blocks_end()
-        host_rate = float(total_voices) * bs * ugens * BLOCKS_PER_STEP * n_host / (time.perf_counter() - t1)
+        host_rate = float(total_voices) * bs * ugens * BLOCKS_PER_LAUNCH * n_host / (time.perf_counter() - t1)
         host_sane = bool(np.isfinite(host_blocks).all())
     sane = bool(torch.isfinite(rings[0]).all().item() and torch.isfinite(rings[1]).all().item())
     peak = float(max(rings[0].abs().max().item(), rings[1].abs().max().item()))
@@ -294,6 +306,107 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     return out
 
 
+def per_block_boundary(name: str, blocks: int = 512):
+    """The call the reference makes: UGen::process_block once per block (Task::run, knaster_graph/src/task.rs:25-31, under
+    AudioProcessor::run_without_inputs, processor.rs:142-179) = one knh_bank_process_block per block, the mixed block in
+    HOST memory when it returns; the block's parameter events in front of it (graph_gen.rs:110-166) as one batched call per
+    trigger.  Driven from Python through ctypes with everything preallocated (tests/cpp/shim_twin_test --bench is the same
+    loop from C++ with one param_apply per event, profiles/).  Returns a dict."""
+    import ctypes as C
+
+    import knaster_amd
+    from knaster_amd import _lib as L
+    from knaster_amd import configs
+
+    w = configs.config(name)
+    bank = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE)
+    for s, a in w.ctor.items():
+        bank.set_ctor_args(s, a)
+    bank.init(configs.SAMPLE_RATE, w.block_size)
+    ugens = knaster_amd.chain_ugen_count(w.stages)
+    v = np.arange(w.n_voices, dtype=np.uint32)
+    restart = bank.prepare_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER) if w.restart else None
+    release = bank.prepare_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER) if w.release else None
+    out = np.zeros((w.out_channels, w.block_size), dtype=np.float32)
+    flags = C.c_uint32(0)
+    fn, h, outp, fp, bs = bank._lib.knh_bank_process_block, bank._h, out.ctypes.data_as(C.c_void_p), C.byref(flags), w.block_size
+
+    def run(n, clock0):
+        for blk in range(n):
+            if restart is not None and blk % 64 == 0:
+                bank.param_apply_prepared(restart, 0)
+            if release is not None and blk % 64 == 32:
+                bank.param_apply_prepared(release, 0)
+            if fn(h, bs, 0, clock0 + blk * bs, outp, fp) != 0:
+                raise RuntimeError("knh_bank_process_block failed")
+
+    run(128, 0)  # warm-up (clock, first-use allocations)
+    bank.timing_reset(True)
+    t0 = time.perf_counter()
+    run(blocks, 128 * bs)
+    dt = time.perf_counter() - t0
+    kms, n = bank.timing_read()
+    bank.timing_reset(False)
+    finite = bool(np.isfinite(out).all())
+    bank.close()
+    us_call, us_kernel = dt * 1e6 / blocks, kms * 1e3 / max(n, 1)
+    return {"config": name, "voices": w.n_voices, "block_size": bs, "blocks": blocks,
+            "per_block_value": float(w.n_voices) * bs * ugens * blocks / dt, "unit": "UGen-samples/s",
+            "us_per_call": us_call, "voice_kernel_us_per_call": us_kernel, "overhead_over_voice_kernel": us_call / us_kernel if us_kernel > 0 else None,
+            "output_finite": finite}
+
+
+def config_leg(name: str, launches: int = 8, blocks: int = 32):
+    """A short leg of another BASELINE.json configuration at its full size: `launches` launches of `blocks` blocks, outputs
+    left in HBM; wall and kernel-only.  UGens per voice as SURVEY.md 8(d) counts them."""
+    import knaster_amd
+    from knaster_amd import _lib as L
+    from knaster_amd import configs
+
+    w = configs.config(name)
+    b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE)
+    for s, a in w.ctor.items():
+        b.set_ctor_args(s, a)
+    b.init(configs.SAMPLE_RATE, w.block_size)
+    v = np.arange(w.n_voices, dtype=np.uint32)
+    if w.restart:
+        b.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+    # the application's own work of deciding what changes when is not the engine's: C5's event arrays are made up front
+    c5 = {}
+    if name == "C5":
+        for blk in range(blocks * (launches + 1)):
+            e = configs.c5_events(w, blk)
+            c5[blk] = None if e is None else b.prepare_many(e[0], e[1], e[2], e[3], e[4], None, e[5])
+    step = [0]
+
+    def events(k):
+        for i in range(k):
+            e = c5.get(step[0] + i)
+            if e is not None:
+                b.param_apply_prepared(e, block_offset=i)
+        step[0] += k
+    events(blocks)
+    b.process_blocks_device(blocks)
+    b.synchronize()
+    b.timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        events(blocks)
+        b.process_blocks_device(blocks)
+    b.synchronize()
+    dt = time.perf_counter() - t0
+    kms, n = b.timing_read()
+    ugens = {"C1": 3, "C2": 2, "C3": 4, "C4": 4, "C5": 3}[name]
+    work = float(w.n_voices) * w.block_size * ugens * blocks * launches
+    rd, wr = b.algorithmic_bytes_per_voice_block()
+    b.close()
+    return {"config": name, "workload": w.description, "voices": w.n_voices, "block_size": w.block_size, "dtype": "f64" if w.sample_type else "f32",
+            "ugens_per_voice": ugens, "blocks_per_launch": blocks, "launches": launches, "value": work / dt, "unit": "UGen-samples/s",
+            "kernel_only_value": work / (kms * 1e-3) if kms > 0 else None, "us_per_block_kernel": kms * 1e3 / (n * blocks) if n else None,
+            "algorithmic_bytes_per_voice_block": rd + wr,
+            "roofline_achieved_gbs": (rd + wr) * w.n_voices * blocks * n / (kms * 1e-3) / 1e9 if kms > 0 else None}
+
+
 def traffic_from_profiles(nv: int, bs: int, sample_type: str, kernel_key: str = "voice_pipe_kernel"):
     """HBM bytes per 64-block launch from the committed PMC passes (newest round first), scaled per block: the counters
     are per-launch totals of a launch of the same bank (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes)."""
@@ -303,7 +416,7 @@ def traffic_from_profiles(nv: int, bs: int, sample_type: str, kernel_key: str = 
                 prof = json.load(f)
             wl = prof.get("workload", {})
             if (wl.get("voices"), wl.get("block_size"), wl.get("sample_type", "f32")) == (nv, bs, sample_type):
-                return prof[kernel_key]["hbm_bytes_per_launch"] / float(wl["blocks_per_launch"]) * BLOCKS_PER_STEP, os.path.relpath(path, ROOT)
+                return prof[kernel_key]["hbm_bytes_per_launch"] / float(wl["blocks_per_launch"]) * BLOCKS_PER_LAUNCH, os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return None, None
@@ -331,11 +444,11 @@ def main():
         kernel_avg_ms = m["kernel_avg_ms"]
         # 92 B per voice per block for C3 (state read once + mutable state written once per block; f64: 184 B)
         # x the voice-blocks one launch of one rank processes
-        alg_bytes_per_launch = float(m["bytes_per_voice_block"]) * nv_rank * BLOCKS_PER_STEP
+        alg_bytes_per_launch = float(m["bytes_per_voice_block"]) * nv_rank * BLOCKS_PER_LAUNCH
         achieved_gbs = alg_bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
-        kernel_rate = float(nv_rank) * bs * ugens * BLOCKS_PER_STEP / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
+        kernel_rate = float(nv_rank) * bs * ugens * BLOCKS_PER_LAUNCH / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
         traffic, traffic_src = traffic_from_profiles(nv_rank, bs, "f64" if f64 else "f32")
-        ns_per_sample = kernel_avg_ms * 1e6 / (BLOCKS_PER_STEP * bs) if kernel_avg_ms > 0 else None
+        ns_per_sample = kernel_avg_ms * 1e6 / (BLOCKS_PER_LAUNCH * bs) if kernel_avg_ms > 0 else None
         line = {
             "metric": "UGen-samples/sec (voices x block_size x UGens / s)",
             "value": value,
@@ -353,15 +466,16 @@ def main():
                 "workload": ("C3" if headline == "C3" else "C4") + ": SinWt.wr_mul(1/N) -> SvfFilter(Low) -> * EnvAsr, stereo mix"
                             + (", f64 samples" if f64 else ""),
                 "voices_per_gpu": nv_rank, "voices_total": total_voices, "block_size": bs, "sample_rate": 48000,
-                "ugens_per_voice": ugens, "mix": "two-level left fold per GPU (deterministic), RCCL sum across GPUs",
-                "step": f"one launch per rank = {BLOCKS_PER_STEP} consecutive blocks of every voice (one note cycle); "
-                        f"{total_blocks} blocks timed", "blocks_per_step": BLOCKS_PER_STEP, "blocks_timed": total_blocks,
+                "ugens_per_voice": ugens, "mix": "pairwise tree over the voice index per GPU (KNH_MIX_TREE, deterministic), RCCL sum across GPUs",
+                "step": f"{LAUNCHES_PER_STEP} launches per rank of {BLOCKS_PER_LAUNCH} consecutive blocks of every voice each (one note cycle "
+                        f"per launch); {total_blocks} blocks timed", "blocks_per_step": BLOCKS_PER_STEP, "blocks_per_launch": BLOCKS_PER_LAUNCH,
+                "blocks_timed": total_blocks,
                 "residency": "value is measured with voice state, events and the mixed stereo blocks resident in HBM; the "
                              "PCIe-inclusive rate of the host-pointer boundary (knh_bank_process_blocks) is host_output",
                 "prewarm": f"{m['n_pre']} untimed launches (>= {PREWARM_MS:.0f} ms) before the warm-up steps, to bring the clock up",
                 "arithmetic": "fma" if args.allow_fma else "exact (bit-identical per voice to the CPU oracle)",
                 "parallelism": f"voices sharded over {world} rank(s), one process per GPU (knh_bank_create_rank); "
-                               f"{BLOCKS_PER_STEP} blocks per launch; the library's ncclReduce of the stereo blocks to rank 0 once per "
+                               f"{BLOCKS_PER_LAUNCH} blocks per launch; the library's ncclReduce of the stereo blocks to rank 0 once per "
                                f"launch, on its own stream",
                 "ranks_seen_by_rccl": m["ranks_seen"], "collective": m["collective"],
                 "events": "t_restart on every voice at block 0 and t_release at block 32 of every 64-block cycle",
@@ -374,7 +488,7 @@ def main():
                 "kernel": ("voice_pipe_kernel<double,false,32,PIPE_INPLACE,...>" if f64 else
                            "voice_pipe_kernel<float,false,64,PIPE_INPLACE,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>")
                           if nv_rank <= (32768 if f64 else 49152) else "voice_kernel<..., WAVES = 4 or 8, SinWt, MulVal, Svf, MulAsr>",
-                "kernel_avg_ms": kernel_avg_ms, "launches": m["launches"], "blocks_per_launch": float(BLOCKS_PER_STEP),
+                "kernel_avg_ms": kernel_avg_ms, "launches": m["launches"], "blocks_per_launch": float(BLOCKS_PER_LAUNCH),
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "note": "fused kernel moves 92 B (f64: 184 B) per voice per block; it is bound by the instruction issue of its "
                         "busiest wavefront, not by HBM (see valu and issue)",
@@ -407,17 +521,25 @@ def main():
                         "block/event bookkeeping and the workgroup barrier once per 64-sample tile (the oscillator, envelope and "
                         "mixer wavefronts on the other three SIMDs are all faster: profiles/r02_pipe_wave_busy_cycles.txt)",
             }
+        if world == 1 and not args.no_configs:
+            pb = [per_block_boundary("C3"), per_block_boundary("C1", 2048)]
+            if line["host_output"] is not None:
+                line["host_output"]["per_block_value"] = pb[0]["per_block_value"]
+                line["host_output"]["per_block"] = pb
+                line["host_output"]["note"] += ("; per_block_value: ONE knh_bank_process_block call per block (what the reference's Task::run "
+                                                "does, task.rs:25-31), the block in host memory when the call returns -- C3, and C1 beside it")
+            line["configs"] = [config_leg("C1"), config_leg("C2"), config_leg("C5")]
         if secondary is not None:
             s = secondary
             s_blocks = s["steps"] * BLOCKS_PER_STEP
-            s_kernel_rate = float(s["voices_rank0"]) * bs * s["ugens"] * BLOCKS_PER_STEP / (s["kernel_avg_ms"] * 1e-3) if s["kernel_avg_ms"] > 0 else 0.0
+            s_kernel_rate = float(s["voices_rank0"]) * bs * s["ugens"] * BLOCKS_PER_LAUNCH / (s["kernel_avg_ms"] * 1e-3) if s["kernel_avg_ms"] > 0 else 0.0
             line["c4_strong"] = {
                 "workload": "C4: the same chain, f64 samples, 65 536 voices IN ALL, split over the ranks (BASELINE.json configs[3])",
                 "value": float(s["total_voices"]) * bs * s["ugens"] * s_blocks / s["elapsed"], "unit": "UGen-samples/s",
                 "scaling": "strong", "dtype": "f64", "n_gpus": world, "voices_total": s["total_voices"], "voices_per_gpu": s["voices_rank0"],
                 "steps": s["steps"], "ms_per_step": s["elapsed"] / s["steps"] * 1e3, "kernel_avg_ms": s["kernel_avg_ms"],
                 "kernel_only_ugen_samples_per_s_per_gpu": s_kernel_rate,
-                "roofline_achieved_gbs": float(s["bytes_per_voice_block"]) * s["voices_rank0"] * BLOCKS_PER_STEP / (s["kernel_avg_ms"] * 1e-3) / 1e9
+                "roofline_achieved_gbs": float(s["bytes_per_voice_block"]) * s["voices_rank0"] * BLOCKS_PER_LAUNCH / (s["kernel_avg_ms"] * 1e-3) / 1e9
                 if s["kernel_avg_ms"] > 0 else 0.0,
                 "ranks_seen_by_rccl": s["ranks_seen"], "output_finite": s["sane"],
             }

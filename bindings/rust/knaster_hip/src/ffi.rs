@@ -55,6 +55,8 @@ pub const KNH_ERR_DEVICE: i32 = 4;
 pub const KNH_ERR_NOT_INITIALISED: i32 = 5;
 pub const KNH_ERR_NO_DEVICE: i32 = 6;
 pub const KNH_ERR_WRONG_VALUE_KIND: i32 = 7;
+pub const KNH_ERR_OUT_OF_MEMORY: i32 = 8;
+pub const KNH_ERR_INTERNAL: i32 = 9;
 
 // knh_sample_type
 pub const KNH_F32: u32 = 0;

@@ -1,5 +1,5 @@
-//! `GpuVoiceBank`: one Knaster node (`Inputs = U0`, `Outputs = U2`) that evaluates N independent voice
-//! chains on an MI355X through `libknaster_hip.so` (C ABI: `include/knaster_hip.h`).
+//! `GpuVoiceBank`: one Knaster node (`Inputs = I`, any typenum, `U0` by default; `Outputs = U2`) that evaluates N
+//! independent voice chains on an MI355X through `libknaster_hip.so` (C ABI: `include/knaster_hip.h`).
 //!
 //! It implements `knaster_core::UGen` (knaster_core/src/ugen.rs:232-369) by forwarding every call of the
 //! audio thread to one FFI call.  Pushed like any UGen:
@@ -31,9 +31,21 @@
 //! to `usize`, or let a UGen report its parameter count at run time (`DynUGen::parameters()` instead of the
 //! typenum).  Neither touches the audio path.
 //!
+//! ## Inputs and audio-rate parameters
+//! `GpuVoiceBank<F, I>` has `I::USIZE` audio inputs: `process_block` packs the `input` block it is handed
+//! (`input.channel_as_slice(ch)`, ugen.rs:263-284) and gives it to the library with `knh_bank_set_input` in front of
+//! `knh_bank_process_block`; the voices read channel `ch` through a `KNH_STAGE_INPUT` stage.  An audio-rate parameter edge
+//! (`bank.link(k, modulator)`, graph_edit.rs:735-754 -> `set_ar_param_buffer(ctx, k, ptr)`, task.rs:113-120) is one more
+//! such channel: a bank made `with_ar_slots(.., n)` has `n` of them behind its `I` inputs, `link`'s index `k` is the slot,
+//! and the chain routes slot `k` with `KNH_STAGE_INPUT` on channel `I::USIZE + k` (e.g. `INPUT -> MUL_CONST(depth) ->
+//! ADD_CONST(f0) -> SIN_WT` flagged `KNH_STAGE_FLAG_AR_FREQ`: the reference's `SinWt::new(f).ar_params()` with its `freq`
+//! linked).  The buffer drives that parameter of EVERY voice, as the one node it is linked to.  The pointer is read during
+//! `process_block` only (`ugen.rs:321-325`: valid until replaced or the node is dropped).
+//!
 //! ## Realtime
-//! `process_block` blocks on a stream sync and a 4-KiB device-to-host copy: use it under the non-realtime
-//! driver (`AudioProcessor::run_without_inputs` in a loop, processor.rs:142-179).  It never allocates.
+//! `process_block` waits for the GPU (two kernel launches, one 4-KiB write over PCIe, a poll on pinned memory: no copy
+//! command, no stream synchronisation): use it under the non-realtime driver (`AudioProcessor::run_without_inputs` in a
+//! loop, processor.rs:142-179).  It never allocates.
 //!
 //! NOT compiled in this repository's build image (no Rust toolchain); see bindings/rust/README.md.
 #![allow(clippy::missing_safety_doc)]
@@ -42,10 +54,10 @@ use core::ffi::c_void;
 use core::marker::PhantomData;
 
 use knaster_core::{
-    AudioCtx, Block, BlockRead, Float, Frame, ParameterHint, ParameterSmoothing, ParameterValue, Rate, UGen, UGenFlags,
+    AudioCtx, Block, BlockRead, Float, Frame, ParameterHint, ParameterSmoothing, ParameterValue, Rate, Size, UGen, UGenFlags,
     numeric_array::NumericArray,
     rt_log,
-    typenum::{U0, U2},
+    typenum::{U0, U2, Unsigned},
 };
 
 pub mod ffi;
@@ -96,33 +108,51 @@ fn last_error(h: *const knh_bank) -> BankError {
     BankError(unsafe { std::ffi::CStr::from_ptr(knh_last_error(h)) }.to_string_lossy().into_owned())
 }
 
-pub struct GpuVoiceBank<F: Float> {
+pub struct GpuVoiceBank<F: Float, I: Size = U0> {
     h: *mut knh_bank,
     n_stages: usize,
     n_voices: u32,
+    /// audio-rate parameter slots behind the `I` inputs (input channels `I::USIZE ..` of the library's bank)
+    n_ar: usize,
+    /// what `set_ar_param_buffer` handed over, per slot (null: nothing linked, the slot reads zeros)
+    ar_bufs: Vec<*const F>,
+    /// `[I::USIZE + n_ar][block_size]`, channel-major: the block `knh_bank_set_input` is given; sized in `init`
+    in_pack: Vec<F>,
+    block_size: usize,
     /// `UGen::init` returns nothing (ugen.rs:242-246): a failed `knh_bank_init` (no gfx950 device, out of device memory, a
     /// chain that cannot be fused) is kept here; the node then renders silence and says so once per block on the RT logger.
     init_error: Option<BankError>,
-    _f: PhantomData<F>,
+    _f: PhantomData<(F, I)>,
 }
 // knaster requires `Node: Send` (knaster_graph/src/node.rs:194).  The handle is single-caller: the graph moves
 // it between threads (control thread at push, audio thread afterwards, control thread again for the drop,
 // task.rs:105-130) but never shares it.
-unsafe impl<F: Float> Send for GpuVoiceBank<F> {}
+unsafe impl<F: Float, I: Size> Send for GpuVoiceBank<F, I> {}
 
-impl<F: Float> GpuVoiceBank<F> {
+impl<F: Float, I: Size> GpuVoiceBank<F, I> {
     /// `ctor[stage]` = row-major `[n_voices][n_args]` constructor arguments (`SinWt::new(freq)` → `[freq]`,
     /// `SvfFilter::new(ty, cutoff, q, gain)` → `[ty as f64, cutoff, q, gain]`, ...; table in knaster_hip.h).
     /// The randomness sources (`KNH_STAGE_WHITE_NOISE`, `_PINK_NOISE`, `_BROWN_NOISE`, `_RANDOM_LIN`) take as first argument
     /// the seed their reference constructor would have drawn: `knaster_core_dsp::noise::next_randomness_seed() as f64`,
     /// once per voice, in the order the voices would have been constructed.
     pub fn new(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>]) -> Result<Self, BankError> {
-        Self::with_host_threads(stages, n_voices, ctor, 0)
+        Self::with_options(stages, n_voices, ctor, 0, 0)
+    }
+    /// A bank that accepts `ar_slots` audio-rate parameter buffers (`handle.link(k, source)` for `k < ar_slots`): slot `k`
+    /// is input channel `I::USIZE + k` of the chain's `KNH_STAGE_INPUT` stages (module docs).
+    pub fn with_ar_slots(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>], ar_slots: usize) -> Result<Self, BankError> {
+        Self::with_options(stages, n_voices, ctor, 0, ar_slots)
     }
     /// The same bank with the host side of its sample-accurate parameter changes (the `WrPreciseTiming` queues of
     /// every voice and the per-block event lists built from them) spread over `host_threads` threads; worth it when
     /// every voice receives changes every block (`knh_bank_create_sharded` in knaster_hip.h).
     pub fn with_host_threads(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>], host_threads: u32) -> Result<Self, BankError> {
+        Self::with_options(stages, n_voices, ctor, host_threads, 0)
+    }
+    pub fn with_options(stages: &[Stage], n_voices: u32, ctor: &[Vec<f64>], host_threads: u32, ar_slots: usize) -> Result<Self, BankError> {
+        if I::USIZE + ar_slots > 16 {
+            return Err(BankError("a bank node has at most 16 input channels (inputs + audio-rate parameter slots)".into()));
+        }
         let desc = knh_bank_desc {
             abi_version: KNH_ABI_VERSION,
             n_voices,
@@ -133,7 +163,7 @@ impl<F: Float> GpuVoiceBank<F> {
             mix_mode: KNH_MIX_TREE,
             device: -1,
             allow_fma: 0,
-            in_channels: 0,
+            in_channels: (I::USIZE + ar_slots) as u32,
         };
         let mut h = core::ptr::null_mut();
         if unsafe { knh_bank_create_sharded(&desc, host_threads, &mut h) } != KNH_OK {
@@ -147,7 +177,17 @@ impl<F: Float> GpuVoiceBank<F> {
                 return Err(e);
             }
         }
-        Ok(Self { h, n_stages: stages.len(), n_voices, init_error: None, _f: PhantomData })
+        Ok(Self {
+            h,
+            n_stages: stages.len(),
+            n_voices,
+            n_ar: ar_slots,
+            ar_bufs: vec![core::ptr::null(); ar_slots],
+            in_pack: Vec::new(),
+            block_size: 0,
+            init_error: None,
+            _f: PhantomData,
+        })
     }
 
     /// `Buffer::from_vec(samples, sample_rate)` for the chain's `BufferReader` stage: one single-channel buffer shared
@@ -201,15 +241,15 @@ pub const fn flat_index(voice: usize, n_stages: usize, stage: usize, param: usiz
     (voice * n_stages + stage) * MAX_PARAMS + param
 }
 
-impl<F: Float> Drop for GpuVoiceBank<F> {
+impl<F: Float, I: Size> Drop for GpuVoiceBank<F, I> {
     fn drop(&mut self) {
         unsafe { knh_bank_destroy(self.h) }
     }
 }
 
-impl<F: Float> UGen for GpuVoiceBank<F> {
+impl<F: Float, I: Size> UGen for GpuVoiceBank<F, I> {
     type Sample = F;
-    type Inputs = U0;
+    type Inputs = I;
     type Outputs = U2;
     type Parameters = U0; // addressed through the flat index (module docs)
 
@@ -220,15 +260,18 @@ impl<F: Float> UGen for GpuVoiceBank<F> {
             log::error!("{}", e);
             self.init_error = Some(e);
         }
+        // the input block handed to the library once per process_block: allocated here, on the control thread
+        self.block_size = block_size;
+        self.in_pack = vec![F::ZERO; (I::USIZE + self.n_ar) * block_size];
     }
 
-    fn process(&mut self, ctx: &mut AudioCtx, _flags: &mut UGenFlags, _input: Frame<F, U0>) -> Frame<F, U2> {
+    fn process(&mut self, ctx: &mut AudioCtx, _flags: &mut UGenFlags, _input: Frame<F, I>) -> Frame<F, U2> {
         // A bank is only ever run block-wise (as GraphGen itself, graph_gen.rs:241-249).
         rt_log!(ctx.logger(); "knaster_hip: GpuVoiceBank::process called; only process_block is supported");
         Frame::default()
     }
 
-    fn process_block<InBlock, OutBlock>(&mut self, ctx: &mut AudioCtx, flags: &mut UGenFlags, _input: &InBlock, output: &mut OutBlock)
+    fn process_block<InBlock, OutBlock>(&mut self, ctx: &mut AudioCtx, flags: &mut UGenFlags, input: &InBlock, output: &mut OutBlock)
     where
         InBlock: BlockRead<Sample = F> + ?Sized,
         OutBlock: Block<Sample = F> + ?Sized,
@@ -244,6 +287,32 @@ impl<F: Float> UGen for GpuVoiceBank<F> {
             }
             rt_log!(ctx.logger(); "knaster_hip: the bank failed to initialise (GpuVoiceBank::init_error): silence");
             return;
+        }
+        // Inputs and audio-rate parameter buffers: one channel-major block [I + n_ar][block_size], handed over in front of
+        // the process call (knh_bank_set_input copies it into pinned memory; the upload rides in the launch's stream).
+        // A partial block (ctx.block_start_offset() > 0, e.g. under a splitting wrapper) hands over the frames it covers
+        // at their place in the block: `input` is already the partial view (knaster_primitives/src/block.rs:269-302).
+        let n_in = I::USIZE + self.n_ar;
+        if n_in > 0 {
+            let (bs, off, ftp) = (self.block_size, ctx.block_start_offset(), ctx.frames_to_process());
+            for ch in 0..I::USIZE {
+                let src = input.channel_as_slice(ch);
+                let n = src.len().min(ftp).min(bs - off);
+                self.in_pack[ch * bs + off..ch * bs + off + n].copy_from_slice(&src[..n]);
+            }
+            for k in 0..self.n_ar {
+                let dst = &mut self.in_pack[(I::USIZE + k) * bs..(I::USIZE + k + 1) * bs];
+                let p = self.ar_bufs[k];
+                if p.is_null() {
+                    dst.fill(F::ZERO);
+                } else {
+                    // ugen.rs:321-325: at least block_size contiguous samples until replaced or dropped
+                    dst.copy_from_slice(unsafe { core::slice::from_raw_parts(p, bs) });
+                }
+            }
+            if unsafe { knh_bank_set_input(self.h, 1, self.in_pack.as_ptr() as *const c_void) } != KNH_OK {
+                rt_log!(ctx.logger(); "knaster_hip: knh_bank_set_input failed");
+            }
         }
         let out = output.channel_as_slice_mut(0).as_mut_ptr() as *mut c_void;
         let mut f = 0u32;
@@ -276,6 +345,17 @@ impl<F: Float> UGen for GpuVoiceBank<F> {
         };
         if unsafe { knh_bank_param_apply(self.h, voice, stage, param, kind, f, i) } != KNH_OK {
             rt_log!(ctx.logger(); "knaster_hip: param_apply rejected, index ", index as f64);
+        }
+    }
+
+    // An audio-rate parameter edge (`handle.link(k, source)`, graph_edit.rs:735-754; resolved to a pointer into the source
+    // node's output block at commit, graph.rs:1532-1562; handed over when the new schedule is taken, task.rs:113-120).
+    // `index` is the bank's audio-rate slot: the samples are packed behind the `I` inputs in process_block (module docs).
+    unsafe fn set_ar_param_buffer(&mut self, ctx: &mut AudioCtx, index: usize, buffer: *const F) {
+        if index < self.n_ar {
+            self.ar_bufs[index] = buffer;
+        } else {
+            rt_log!(ctx.logger(); "knaster_hip: audio-rate parameter buffer for a slot the bank was not made with (with_ar_slots); ignored");
         }
     }
 

@@ -41,8 +41,10 @@ typedef enum knh_status {
   KNH_ERR_DEVICE = 4,            /* a HIP call failed; see knh_last_error          */
   KNH_ERR_NOT_INITIALISED = 5,   /* process/param before knh_bank_init             */
   KNH_ERR_NO_DEVICE = 6,         /* no gfx950 device visible: the product has no CPU path */
-  KNH_ERR_WRONG_VALUE_KIND = 7   /* e.g. Trigger sent to a Float parameter
+  KNH_ERR_WRONG_VALUE_KIND = 7,  /* e.g. Trigger sent to a Float parameter
                                     (reference panics: knaster_macros/src/lib.rs:601-606) */
+  KNH_ERR_OUT_OF_MEMORY = 8,     /* host memory ran out inside the library (std::bad_alloc caught at the boundary) */
+  KNH_ERR_INTERNAL = 9           /* any other C++ exception caught at the boundary: never unwinds into the caller */
 } knh_status;
 
 /* Sample type F of the bank: knaster_primitives/src/float.rs:97-175 */

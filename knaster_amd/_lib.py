@@ -15,7 +15,7 @@ KNH_ABI_VERSION = 2
 
 # knh_status
 OK, ERR_INVALID_ARGUMENT, ERR_OUT_OF_RANGE, ERR_UNSUPPORTED_CHAIN, ERR_DEVICE = 0, 1, 2, 3, 4
-ERR_NOT_INITIALISED, ERR_NO_DEVICE, ERR_WRONG_VALUE_KIND = 5, 6, 7
+ERR_NOT_INITIALISED, ERR_NO_DEVICE, ERR_WRONG_VALUE_KIND, ERR_OUT_OF_MEMORY, ERR_INTERNAL = 5, 6, 7, 8, 9
 # knh_sample_type
 F32, F64 = 0, 1
 # knh_value_kind

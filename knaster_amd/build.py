@@ -78,15 +78,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     procs = []
+    objs = []
+    # a translation unit is recompiled when its object is missing, older than its source or than any header, or was built
+    # with other flags (kept beside it): a change to bank.hip alone costs one compile, not nine
+    header_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+    header_time = max(header_time, os.path.getmtime(os.path.join(CSRC, "jit_source.inc")))
     for src, objname, unit_flags in UNITS:
         obj = os.path.join(objdir, objname)
+        objs.append(obj)
         cmd = [hipcc, *FLAGS, *extra, *unit_flags, "-c", src, "-o", obj]
+        stamp = obj + ".flags"
+        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+                 and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), header_time))
+        if fresh:
+            continue
+        if os.path.exists(stamp):
+            os.remove(stamp)
         if verbose:
             print("[knaster_amd.build]", " ".join(cmd), flush=True)
-        procs.append((src, obj, subprocess.Popen(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        procs.append((src, obj, subprocess.Popen(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), " ".join(cmd)))
     failed = False
-    for src, _obj, p in procs:
+    for src, obj, p, cmdline in procs:
         out, _ = p.communicate()
+        if p.returncode == 0:
+            with open(obj + ".flags", "w") as f:
+                f.write(cmdline)
         if p.returncode != 0:
             sys.stderr.write(out)
             failed = True
@@ -94,7 +110,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc failed building libknaster_hip.so")
-    cmd = [hipcc, *LINK_FLAGS, "-o", LIB + ".tmp", *[o for _s, o, _p in procs]]
+    cmd = [hipcc, *LINK_FLAGS, "-o", LIB + ".tmp", *objs]
     if verbose:
         print("[knaster_amd.build]", " ".join(cmd), flush=True)
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

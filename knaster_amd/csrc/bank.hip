@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -405,8 +407,9 @@ struct Bank final : knh_bank {
   struct QRec {
     uint32_t voice;
     uint16_t delay;     // set_delay_within_block_for_param value, when `arm` is set
-    uint8_t stage, param, kind;
-    uint8_t arm : 1, has_value : 1;
+    uint16_t stage;     // (graph-shaped voices hold up to 512 stages, frame-parallel ones 4 096)
+    uint8_t param;
+    uint8_t kind : 4, arm : 1, has_value : 1;
     union { double f; int64_t i; } v;
   };
   static_assert(sizeof(QRec) == 24, "QRec is 24 bytes");
@@ -460,6 +463,14 @@ struct Bank final : knh_bank {
   uint32_t* h_ev_start = nullptr;  // the buffer of the launch being assembled
   Event* h_events = nullptr;
   F* h_out = nullptr;  // [channels][block] then 2 x u32 flags
+  // Blocking calls with a host destination (knh_bank_process_block: the call the reference makes once per block) hand the
+  // mixed block over without a copy command: the fold kernel writes it into h_out -- mapped pinned host memory -- and then
+  // an epoch number into h_done, which the host polls (knh_dev::HostDone).  KNH_MAPPED_OUT=0: the copies and the stream
+  // wait of round 2 (A/B runs).
+  uint32_t* h_done = nullptr;        // pinned: [0] epoch, [1] flags[0], [2] flags[1]
+  uint32_t* d_fold_count = nullptr;  // device: workgroups of the fold kernel that are through
+  uint32_t done_epoch = 0;
+  bool mapped_out = true;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_pool;
@@ -470,14 +481,15 @@ struct Bank final : knh_bank {
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
-    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input, d_prog, d_sin_slots};
+    void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input, d_prog, d_sin_slots, d_fold_count};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
-    void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out, h_input};
+    void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out, h_input, h_done};
     for (void* p : host_ptrs)
       if (p) (void)hipHostFree(p);
     for (hipEvent_t e : list_done)
       if (e) (void)hipEventDestroy(e);
+    if (in_copied) (void)hipEventDestroy(in_copied);
     for (auto& p : timing_pool) {
       (void)hipEventDestroy(p.first);
       (void)hipEventDestroy(p.second);
@@ -516,6 +528,8 @@ struct Bank final : knh_bank {
   uint32_t in_blocks_cap = 0, in_blocks_set = 0;
   const void* in_device = nullptr;  // set_input_device: read where it is
   bool in_host_pending = false;
+  hipEvent_t in_copied = nullptr;   // recorded behind the upload of h_input, on the stream of that launch
+  bool in_copy_pending = false;
   bool uses_input = false;
   int set_input(uint32_t n_blocks, const void* host, const void* dev) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
@@ -535,8 +549,11 @@ struct Bank final : knh_bank {
       KNH_HIP(hipMalloc(&d_input, elems * sizeof(F)));
       KNH_HIP(hipHostMalloc(&h_input, elems * sizeof(F)));
       in_blocks_cap = n_blocks;
-    } else {
-      KNH_HIP(hipStreamSynchronize(own_stream));  // the copy of the launch before may still be reading the staging buffer
+    } else if (in_copy_pending) {
+      // the upload of the launch before may still be reading the staging buffer -- on whatever stream that launch was
+      // given (the caller's, the pipelined host output's, a rank bank's), hence an event and not a stream to wait for
+      KNH_HIP(hipEventSynchronize(in_copied));
+      in_copy_pending = false;
     }
     std::memcpy(h_input, host, elems * sizeof(F));
     in_host_pending = true;
@@ -976,7 +993,15 @@ struct Bank final : knh_bank {
       KNH_HIP(hipHostMalloc(&h_ev_start2[b], (static_cast<size_t>(nv) + 2) * sizeof(uint32_t)));
       KNH_HIP(hipEventCreateWithFlags(&list_done[b], hipEventDisableTiming));
     }
-    KNH_HIP(hipHostMalloc(&h_out, desc.out_channels * bs * sizeof(F) + 2 * sizeof(uint32_t)));
+    KNH_HIP(hipHostMalloc(&h_out, desc.out_channels * bs * sizeof(F) + 2 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    KNH_HIP(hipHostMalloc(&h_done, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h_done, 0, 64);
+    KNH_HIP(hipMalloc(&d_fold_count, sizeof(uint32_t)));
+    KNH_HIP(hipMemset(d_fold_count, 0, sizeof(uint32_t)));
+    {
+      const char* me = std::getenv("KNH_MAPPED_OUT");
+      mapped_out = !(me && me[0] == '0');
+    }
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD) KNH_HIP(ensure_voices());
     bool any_wrapped = false;
     for (auto& S : stages) any_wrapped = any_wrapped || S.dcpb > 0;
@@ -1021,7 +1046,7 @@ struct Bank final : knh_bank {
     }
     if (fastq(S)) {
       QRec r{};
-      r.voice = voice; r.delay = delay; r.stage = static_cast<uint8_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
+      r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
       qblock(0).push_back(r);
       return KNH_OK;
     }
@@ -1049,8 +1074,8 @@ struct Bank final : knh_bank {
   }
   static QRec make_qrec(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i, uint16_t delay, bool arm) {
     QRec r{};
-    r.voice = voice; r.delay = delay; r.stage = static_cast<uint8_t>(stage); r.param = static_cast<uint8_t>(param);
-    r.kind = static_cast<uint8_t>(kind); r.arm = arm ? 1 : 0; r.has_value = 1;
+    r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param);
+    r.kind = static_cast<uint8_t>(kind & 15u); r.arm = arm ? 1 : 0; r.has_value = 1;
     if (kind == KNH_VALUE_FLOAT) r.v.f = f; else r.v.i = i;
     return r;
   }
@@ -1144,7 +1169,7 @@ struct Bank final : knh_bank {
     if (fastq(stages[stage])) {
       if (is_delay) {
         QRec r{};
-        r.voice = voice; r.delay = delay; r.stage = static_cast<uint8_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
+        r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
         qblock(block_offset).push_back(r);
       } else {
         qblock(block_offset).push_back(make_qrec(voice, stage, param, kind, f, i, 0, false));
@@ -1187,7 +1212,7 @@ struct Bank final : knh_bank {
       // overtake them by being turned into its patches now (two changes of one parameter in one block: the last one holds).
       if (direct && block_offset > 0 && block_offset < future.size() && !future[block_offset].empty()) direct = false;
       // (runs of any length: a host that addresses two parameters of alternate voices sends runs of one)
-      const bool queued_run = !direct && stgs[k] < stages.size() && stages.size() <= 255 && params[k] < static_cast<uint32_t>(stages[stgs[k]].n_params) &&
+      const bool queued_run = !direct && stgs[k] < stages.size() && params[k] < static_cast<uint32_t>(stages[stgs[k]].n_params) &&
                               fastq(stages[stgs[k]]) && kind_ok(stages[stgs[k]], params[k], kinds[k]) && kinds[k] != KNH_VALUE_SMOOTHING;
       if (queued_run) {  // calls to a WrPreciseTiming-wrapped node: one record each (arm the delay, then the value)
         std::vector<QRec>& q = qblock(block_offset);
@@ -1675,7 +1700,8 @@ struct Bank final : knh_bank {
       KNH_HIP(hipMemsetAsync(d_out, 0, static_cast<size_t>(n_blocks) * desc.out_channels * block_size * sizeof(F), s));
       if (h_out) KNH_HIP(hipHostFree(h_out));
       h_out = nullptr;
-      KNH_HIP(hipHostMalloc(&h_out, static_cast<size_t>(n_blocks) * desc.out_channels * block_size * sizeof(F) + 2 * sizeof(uint32_t)));
+      KNH_HIP(hipHostMalloc(&h_out, static_cast<size_t>(n_blocks) * desc.out_channels * block_size * sizeof(F) + 2 * sizeof(uint32_t),
+                            hipHostMallocMapped | hipHostMallocCoherent));
       out_blocks = n_blocks;
     }
 
@@ -1710,8 +1736,12 @@ struct Bank final : knh_bank {
       if (in_device) {
         a.input = in_device;
       } else {
-        if (in_host_pending)
+        if (in_host_pending) {
           KNH_HIP(hipMemcpyAsync(d_input, h_input, static_cast<size_t>(n_blocks) * desc.in_channels * block_size * sizeof(F), hipMemcpyHostToDevice, s));
+          if (!in_copied) KNH_HIP(hipEventCreateWithFlags(&in_copied, hipEventDisableTiming));
+          KNH_HIP(hipEventRecord(in_copied, s));
+          in_copy_pending = true;
+        }
         in_host_pending = false;
         a.input = d_input;
       }
@@ -1748,25 +1778,57 @@ struct Bank final : knh_bank {
       list_in_use = -1;
     }
 
-    F* dst = out_device ? static_cast<F*>(out_device) : d_out;
+    // A blocking call for host memory: the fold kernel writes into the pinned block itself and tells the host when it is through
+    const bool hand_over = sync && out_host && !out_device && !voices_host && mapped_out && fe > fb;
+    F* dst = out_device ? static_cast<F*>(out_device) : (hand_over ? h_out : d_out);
+    knh_dev::HostDone hd{nullptr, nullptr, nullptr, 0u};
+    if (hand_over) {
+      done_epoch += 1;
+      if (done_epoch == 0) done_epoch = 1;
+      hd = knh_dev::HostDone{h_done, d_fold_count, flags_now, done_epoch};
+    }
     // A Pan2 chain's row sets are [block][channel][rows][frame] and its output [block][channel][frame]: the fold sees
     // twice as many "blocks" of one channel each.
     const unsigned fold_channels = pan ? 1u : desc.out_channels;
     // (the interpreter's rows ARE the voices' signals: one buffer serves both mix orders and the per-voice debug output)
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD)
-      KNH_HIP(launch_fold(false, interp ? d_partials : d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), fold_planes, accumulate, flags_next, s));
+      KNH_HIP(launch_fold(false, interp ? d_partials : d_voices, nv, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), fold_planes, accumulate, flags_next, s, hand_over ? &hd : nullptr));
     else
-      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), n_blocks * fold_planes, accumulate, flags_next, s));
+      KNH_HIP(launch_fold(true, d_partials, n_waves, static_cast<unsigned>(block_size), fb, fe, dst, fold_channels, static_cast<unsigned>(block_size), n_blocks * fold_planes, accumulate, flags_next, s, hand_over ? &hd : nullptr));
 
     if (!sync) return KNH_OK;
     const size_t blk_elems = desc.out_channels * block_size;
     const size_t out_bytes = static_cast<size_t>(n_blocks) * blk_elems * sizeof(F);
     uint32_t* h_flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h_out) + static_cast<size_t>(out_blocks) * blk_elems * sizeof(F));
-    if (out_host) KNH_HIP(hipMemcpyAsync(h_out, dst, out_bytes, hipMemcpyDeviceToHost, s));
-    KNH_HIP(hipMemcpyAsync(h_flags, flags_now, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (voices_host)
-      KNH_HIP(hipMemcpyAsync(voices_host, interp ? d_partials : d_voices, static_cast<size_t>(fold_planes) * nv * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
-    KNH_HIP(hipStreamSynchronize(s));
+    if (hand_over) {
+      // Poll the epoch word (the kernel's last store, a system-scope release).  A stream that has finished without the
+      // word having moved means the kernel failed: hipStreamQuery says how; it is asked rarely (it is a driver call).
+      volatile uint32_t* ep = h_done;
+      for (uint64_t spin = 1;; ++spin) {
+        if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == done_epoch) break;
+        if ((spin & 0x3FFFu) == 0) {
+          const hipError_t q = hipStreamQuery(s);
+          if (q == hipSuccess) {
+            if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == done_epoch) break;
+            KNH_HIP(hipStreamSynchronize(s));
+            if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) != done_epoch) return fail(KNH_ERR_DEVICE, "the fold kernel finished without handing its block over");
+            break;
+          }
+          if (q != hipErrorNotReady) return fail(KNH_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      h_flags[0] = h_done[1];
+      h_flags[1] = h_done[2];
+    } else {
+      if (out_host) KNH_HIP(hipMemcpyAsync(h_out, dst, out_bytes, hipMemcpyDeviceToHost, s));
+      KNH_HIP(hipMemcpyAsync(h_flags, flags_now, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      if (voices_host)
+        KNH_HIP(hipMemcpyAsync(voices_host, interp ? d_partials : d_voices, static_cast<size_t>(fold_planes) * nv * block_size * sizeof(F), hipMemcpyDeviceToHost, s));
+      KNH_HIP(hipStreamSynchronize(s));
+    }
     if (out_host) {
       if (n_blocks > 1) {
         std::memcpy(out_host, h_out, out_bytes);
@@ -1814,11 +1876,11 @@ struct Bank final : knh_bank {
     if (pipe) return pipe->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
-  static hipError_t launch_fold(bool tree, const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, unsigned nb, bool acc, uint32_t* zf, hipStream_t s) {
-    return knh::launch_fold_f32(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, zf, s);
+  static hipError_t launch_fold(bool tree, const float* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, float* out, unsigned ch, unsigned os, unsigned nb, bool acc, uint32_t* zf, hipStream_t s, const knh_dev::HostDone* hd) {
+    return knh::launch_fold_f32(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, zf, s, hd);
   }
-  static hipError_t launch_fold(bool tree, const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, unsigned nb, bool acc, uint32_t* zf, hipStream_t s) {
-    return knh::launch_fold_f64(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, zf, s);
+  static hipError_t launch_fold(bool tree, const double* rows, unsigned n, unsigned len, unsigned fb, unsigned fe, double* out, unsigned ch, unsigned os, unsigned nb, bool acc, uint32_t* zf, hipStream_t s, const knh_dev::HostDone* hd) {
+    return knh::launch_fold_f64(tree, rows, n, len, fb, fe, out, ch, os, nb, acc, zf, s, hd);
   }
 
   int read_done_frames(uint32_t* out) override {
@@ -1972,7 +2034,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
 
 template <typename F>
 knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const std::string& sig) {
-  auto* b = new Bank<F>();
+  std::unique_ptr<Bank<F>> b(new Bank<F>());
   b->desc = d;
   b->entry = entry;
   b->signature = sig;
@@ -2028,7 +2090,7 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
   b->n_slots = slot;
   b->n_params_total = pbase;
   b->desc.stages = nullptr;  // the caller's array is not retained
-  return b;
+  return b.release();
 }
 
 }  // namespace
@@ -2045,7 +2107,7 @@ knh_bank* make_sharded(const knh_bank_desc& d, const knh::KernelEntry* entry, co
   const uint32_t groups = (d.n_voices + 63u) / 64u;
   const uint32_t k = std::min(host_threads, groups);
   const uint32_t per = ((groups + k - 1) / k) * 64u;
-  auto* b = new ShardedBank<F>();
+  std::unique_ptr<ShardedBank<F>> b(new ShardedBank<F>());
   b->desc = d;
   b->nv = d.n_voices;
   b->per_shard = per;
@@ -2064,7 +2126,7 @@ knh_bank* make_sharded(const knh_bank_desc& d, const knh::KernelEntry* entry, co
   b->n_slots = b->shard[0]->n_slots;
   b->n_params_total = b->shard[0]->n_params_total;
   b->desc.stages = nullptr;
-  return b;
+  return b.release();
 }
 }  // namespace
 
@@ -2072,7 +2134,7 @@ namespace {
 template <typename F>
 knh_bank* make_rank_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const std::string& sig, uint32_t rank, uint32_t world,
                                 const uint8_t* comm_id, knh_reduce_fn reduce, void* user) {
-  auto* b = new RankBank<F>();
+  std::unique_ptr<RankBank<F>> b(new RankBank<F>());
   b->desc = d;
   b->total = d.n_voices;
   b->rank = rank;
@@ -2095,7 +2157,40 @@ knh_bank* make_rank_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, 
   b->n_params_total = proto->n_params_total;
   if (count) b->local = std::move(proto);
   b->desc.stages = nullptr;
-  return b;
+  return b.release();
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// No C++ exception crosses the C ABI (a Rust caller unwinding through foreign frames is undefined behaviour): every
+// entry point that can allocate runs inside guarded(), which turns std::bad_alloc and anything else into a status and a
+// message on the handle.  (Setting the message may itself fail for want of memory: then only the status is returned.)
+// ---------------------------------------------------------------------------
+namespace {
+template <typename Fn>
+int32_t guarded(knh_bank* bank, Fn&& fn) noexcept {
+  const char* what = nullptr;
+  int32_t code = KNH_ERR_INTERNAL;
+  try {
+    return fn();
+  } catch (const std::bad_alloc&) {
+    what = "out of host memory (std::bad_alloc)";
+    code = KNH_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    try {
+      (bank ? bank->err : g_create_error) = std::string("internal error: ") + e.what();
+      return KNH_ERR_INTERNAL;
+    } catch (...) {
+      what = "internal error";
+    }
+  } catch (...) {
+    what = "internal error (unknown exception)";
+  }
+  try {
+    (bank ? bank->err : g_create_error) = what;
+  } catch (...) {
+  }
+  return code;
 }
 }  // namespace
 
@@ -2127,6 +2222,8 @@ const char* knh_status_string(int32_t status) {
     case KNH_ERR_NOT_INITIALISED: return "bank not initialised";
     case KNH_ERR_NO_DEVICE: return "no gfx950 device";
     case KNH_ERR_WRONG_VALUE_KIND: return "wrong parameter value kind";
+    case KNH_ERR_OUT_OF_MEMORY: return "out of host memory";
+    case KNH_ERR_INTERNAL: return "internal error";
     default: return "unknown status";
   }
 }
@@ -2134,131 +2231,164 @@ const char* knh_status_string(int32_t status) {
 const char* knh_last_error(const knh_bank* bank) { return bank ? bank->err.c_str() : g_create_error.c_str(); }
 
 int32_t knh_chain_ugen_count(const knh_stage_desc* stages, uint32_t n_stages) {
-  if (!stages) return 0;
-  int n = 0;
-  for (uint32_t i = 0; i < n_stages; ++i)
-    if (stages[i].kind < KNH_STAGE_KIND_COUNT) n += kKinds[stages[i].kind].n_nodes;
-  return n;
+  return guarded(nullptr, [&]() -> int32_t {
+    if (!stages) return 0;
+    int n = 0;
+    for (uint32_t i = 0; i < n_stages; ++i)
+      if (stages[i].kind < KNH_STAGE_KIND_COUNT) n += kKinds[stages[i].kind].n_nodes;
+    return n;
+  });
 }
 
 static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank);
 
 // The checks every way of creating a bank shares; on success *sig is the chain's device signature.
 static int32_t check_desc(const knh_bank_desc* desc, knh_bank** out_bank, std::string* sig) {
-  if (out_bank) *out_bank = nullptr;
-  if (!desc || !out_bank) { g_create_error = "null argument"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->abi_version != KNH_ABI_VERSION) { g_create_error = "ABI version mismatch"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->n_voices == 0 || !desc->stages) { g_create_error = "n_voices must be > 0 and stages non-null"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->sample_type > KNH_F64) { g_create_error = "unknown sample type"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->out_channels < 1 || desc->out_channels > 2) { g_create_error = "out_channels must be 1 or 2"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->mix_mode > KNH_MIX_LEFT_FOLD) { g_create_error = "unknown mix mode"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->in_channels > 16) { g_create_error = "in_channels must be at most 16"; return KNH_ERR_INVALID_ARGUMENT; }
-  std::string why;
-  int rc = build_signature(desc->stages, desc->n_stages, sig, &why);
-  if (rc != KNH_OK) { g_create_error = why; return rc; }
-  if (desc->stages[desc->n_stages - 1].kind == KNH_STAGE_PAN2 && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
-  return KNH_OK;
+  return guarded(nullptr, [&]() -> int32_t {
+    if (out_bank) *out_bank = nullptr;
+    if (!desc || !out_bank) { g_create_error = "null argument"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->abi_version != KNH_ABI_VERSION) { g_create_error = "ABI version mismatch"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->n_voices == 0 || !desc->stages) { g_create_error = "n_voices must be > 0 and stages non-null"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->sample_type > KNH_F64) { g_create_error = "unknown sample type"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->out_channels < 1 || desc->out_channels > 2) { g_create_error = "out_channels must be 1 or 2"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->mix_mode > KNH_MIX_LEFT_FOLD) { g_create_error = "unknown mix mode"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->in_channels > 16) { g_create_error = "in_channels must be at most 16"; return KNH_ERR_INVALID_ARGUMENT; }
+    std::string why;
+    int rc = build_signature(desc->stages, desc->n_stages, sig, &why);
+    if (rc != KNH_OK) { g_create_error = why; return rc; }
+    if (desc->stages[desc->n_stages - 1].kind == KNH_STAGE_PAN2 && desc->out_channels != 2) { g_create_error = "a chain ending in Pan2 has two output channels (out_channels = 2)"; return KNH_ERR_INVALID_ARGUMENT; }
+    return KNH_OK;
+  });
 }
 
 int32_t knh_bank_create_multi_device(const knh_bank_desc* desc, const int32_t* devices, uint32_t n_devices, knh_bank** out_bank) {
-  std::string sig;
-  int rc = check_desc(desc, out_bank, &sig);
-  if (rc != KNH_OK) return rc;
-  if (!devices || n_devices == 0 || n_devices > 64) { g_create_error = "devices: 1 to 64 device ordinals"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->mix_mode != KNH_MIX_TREE) { g_create_error = "a bank sharded over several GPUs mixes with KNH_MIX_TREE (the sum over GPUs re-associates)"; return KNH_ERR_INVALID_ARGUMENT; }
-  int visible = 0;
-  (void)hipGetDeviceCount(&visible);
-  for (uint32_t k = 0; k < n_devices; ++k)
-    if (devices[k] < 0 || devices[k] >= std::max(visible, 1)) { g_create_error = "devices: ordinal out of range"; return KNH_ERR_INVALID_ARGUMENT; }
-  const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
-  *out_bank = desc->sample_type == KNH_F64 ? make_sharded<double>(*desc, entry, sig, n_devices, devices) : make_sharded<float>(*desc, entry, sig, n_devices, devices);
-  return KNH_OK;
+  return guarded(nullptr, [&]() -> int32_t {
+    std::string sig;
+    int rc = check_desc(desc, out_bank, &sig);
+    if (rc != KNH_OK) return rc;
+    if (!devices || n_devices == 0 || n_devices > 64) { g_create_error = "devices: 1 to 64 device ordinals"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->mix_mode != KNH_MIX_TREE) { g_create_error = "a bank sharded over several GPUs mixes with KNH_MIX_TREE (the sum over GPUs re-associates)"; return KNH_ERR_INVALID_ARGUMENT; }
+    int visible = 0;
+    (void)hipGetDeviceCount(&visible);
+    for (uint32_t k = 0; k < n_devices; ++k)
+      if (devices[k] < 0 || devices[k] >= std::max(visible, 1)) { g_create_error = "devices: ordinal out of range"; return KNH_ERR_INVALID_ARGUMENT; }
+    const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
+    *out_bank = desc->sample_type == KNH_F64 ? make_sharded<double>(*desc, entry, sig, n_devices, devices) : make_sharded<float>(*desc, entry, sig, n_devices, devices);
+    return KNH_OK;
+  });
 }
 
 int32_t knh_shard_voice_range(uint32_t n_voices, uint32_t rank, uint32_t world, uint32_t* first, uint32_t* count) {
-  if (world == 0 || rank >= world || !first || !count) return KNH_ERR_INVALID_ARGUMENT;
-  shard_voice_range(n_voices, rank, world, first, count);
-  return KNH_OK;
+  return guarded(nullptr, [&]() -> int32_t {
+    if (world == 0 || rank >= world || !first || !count) return KNH_ERR_INVALID_ARGUMENT;
+    shard_voice_range(n_voices, rank, world, first, count);
+    return KNH_OK;
+  });
 }
 
 static int32_t create_rank_bank(const knh_bank_desc* desc, uint32_t rank, uint32_t world, const uint8_t* comm_id, knh_reduce_fn reduce, void* user,
                                 knh_bank** out_bank) {
-  std::string sig;
-  int rc = check_desc(desc, out_bank, &sig);
-  if (rc != KNH_OK) return rc;
-  if (world == 0 || rank >= world) { g_create_error = "rank must be below world"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (world > 1 && !comm_id && !reduce) { g_create_error = "more than one rank needs a communicator id (knh_comm_unique_id) or a reduce function"; return KNH_ERR_INVALID_ARGUMENT; }
-  if (desc->mix_mode != KNH_MIX_TREE) { g_create_error = "a bank sharded over several GPUs mixes with KNH_MIX_TREE (the sum over GPUs re-associates)"; return KNH_ERR_INVALID_ARGUMENT; }
-  const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
-  *out_bank = desc->sample_type == KNH_F64 ? make_rank_bank<double>(*desc, entry, sig, rank, world, comm_id, reduce, user)
-                                          : make_rank_bank<float>(*desc, entry, sig, rank, world, comm_id, reduce, user);
-  return KNH_OK;
+  return guarded(nullptr, [&]() -> int32_t {
+    std::string sig;
+    int rc = check_desc(desc, out_bank, &sig);
+    if (rc != KNH_OK) return rc;
+    if (world == 0 || rank >= world) { g_create_error = "rank must be below world"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (world > 1 && !comm_id && !reduce) { g_create_error = "more than one rank needs a communicator id (knh_comm_unique_id) or a reduce function"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (desc->mix_mode != KNH_MIX_TREE) { g_create_error = "a bank sharded over several GPUs mixes with KNH_MIX_TREE (the sum over GPUs re-associates)"; return KNH_ERR_INVALID_ARGUMENT; }
+    const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
+    *out_bank = desc->sample_type == KNH_F64 ? make_rank_bank<double>(*desc, entry, sig, rank, world, comm_id, reduce, user)
+                                            : make_rank_bank<float>(*desc, entry, sig, rank, world, comm_id, reduce, user);
+    return KNH_OK;
+  });
 }
 int32_t knh_bank_create_rank(const knh_bank_desc* desc, uint32_t rank, uint32_t world, const uint8_t* comm_id, knh_bank** out_bank) {
-  return create_rank_bank(desc, rank, world, comm_id, nullptr, nullptr, out_bank);
+  return guarded(nullptr, [&]() -> int32_t {
+    return create_rank_bank(desc, rank, world, comm_id, nullptr, nullptr, out_bank);
+  });
 }
 int32_t knh_bank_create_rank_custom(const knh_bank_desc* desc, uint32_t rank, uint32_t world, knh_reduce_fn reduce, void* user, knh_bank** out_bank) {
-  if (world > 1 && !reduce) { g_create_error = "null reduce function"; if (out_bank) *out_bank = nullptr; return KNH_ERR_INVALID_ARGUMENT; }
-  return create_rank_bank(desc, rank, world, nullptr, reduce, user, out_bank);
+  return guarded(nullptr, [&]() -> int32_t {
+    if (world > 1 && !reduce) { g_create_error = "null reduce function"; if (out_bank) *out_bank = nullptr; return KNH_ERR_INVALID_ARGUMENT; }
+    return create_rank_bank(desc, rank, world, nullptr, reduce, user, out_bank);
+  });
 }
 uint32_t knh_bank_ranks(const knh_bank* bank) { return bank ? bank->ranks() : 0; }
 
 static int32_t create_bank(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank) {
-  std::string sig;
-  int rc = check_desc(desc, out_bank, &sig);
-  if (rc != KNH_OK) return rc;
-  if (host_threads > 64) { g_create_error = "host_threads must be at most 64"; return KNH_ERR_INVALID_ARGUMENT; }
-  // a chain without a pre-built kernel is fused at knh_bank_init time (hiprtc); entry == nullptr marks it
-  const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
-  // the reference's exact mix order (KNH_MIX_LEFT_FOLD) and banks of a single voice group keep one range
-  if (host_threads >= 2 && desc->mix_mode == KNH_MIX_TREE && desc->n_voices > 64)
-    *out_bank = desc->sample_type == KNH_F64 ? make_sharded<double>(*desc, entry, sig, host_threads) : make_sharded<float>(*desc, entry, sig, host_threads);
-  else
-    *out_bank = desc->sample_type == KNH_F64 ? make_bank<double>(*desc, entry, sig) : make_bank<float>(*desc, entry, sig);
-  return KNH_OK;
+  return guarded(nullptr, [&]() -> int32_t {
+    std::string sig;
+    int rc = check_desc(desc, out_bank, &sig);
+    if (rc != KNH_OK) return rc;
+    if (host_threads > 64) { g_create_error = "host_threads must be at most 64"; return KNH_ERR_INVALID_ARGUMENT; }
+    // a chain without a pre-built kernel is fused at knh_bank_init time (hiprtc); entry == nullptr marks it
+    const knh::KernelEntry* entry = knh::find_kernel(sig.c_str());
+    // the reference's exact mix order (KNH_MIX_LEFT_FOLD) and banks of a single voice group keep one range
+    if (host_threads >= 2 && desc->mix_mode == KNH_MIX_TREE && desc->n_voices > 64)
+      *out_bank = desc->sample_type == KNH_F64 ? make_sharded<double>(*desc, entry, sig, host_threads) : make_sharded<float>(*desc, entry, sig, host_threads);
+    else
+      *out_bank = desc->sample_type == KNH_F64 ? make_bank<double>(*desc, entry, sig) : make_bank<float>(*desc, entry, sig);
+    return KNH_OK;
+  });
 }
 
 int32_t knh_bank_create(const knh_bank_desc* desc, knh_bank** out_bank) {
-  // KNH_HOST_THREADS=K: every bank created through this entry point gets K host threads (A/B runs of existing programs)
-  const char* env = std::getenv("KNH_HOST_THREADS");
-  const long k = env ? std::strtol(env, nullptr, 10) : 0;
-  return create_bank(desc, k >= 2 && k <= 64 ? static_cast<uint32_t>(k) : 0u, out_bank);
+  return guarded(nullptr, [&]() -> int32_t {
+    // KNH_HOST_THREADS=K: every bank created through this entry point gets K host threads (A/B runs of existing programs)
+    const char* env = std::getenv("KNH_HOST_THREADS");
+    const long k = env ? std::strtol(env, nullptr, 10) : 0;
+    return create_bank(desc, k >= 2 && k <= 64 ? static_cast<uint32_t>(k) : 0u, out_bank);
+  });
 }
 
 int32_t knh_bank_create_sharded(const knh_bank_desc* desc, uint32_t host_threads, knh_bank** out_bank) {
-  return create_bank(desc, host_threads, out_bank);
+  return guarded(nullptr, [&]() -> int32_t {
+    return create_bank(desc, host_threads, out_bank);
+  });
 }
 
 void knh_bank_destroy(knh_bank* bank) {
-  if (bank && bank->pipe_stream) {  // launches begun and never fetched still hold the bank's buffers
-    (void)hipSetDevice(bank->device);
-    (void)hipStreamSynchronize(bank->pipe_stream);
+  try {
+    if (bank && bank->pipe_stream) {  // launches begun and never fetched still hold the bank's buffers
+      (void)hipSetDevice(bank->device);
+      (void)hipStreamSynchronize(bank->pipe_stream);
+    }
+    delete bank;
+  } catch (...) {
   }
-  delete bank;
 }
 
 int32_t knh_bank_set_ctor_args(knh_bank* bank, uint32_t stage, uint32_t first_voice, uint32_t count, const double* args, uint32_t n_args) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->set_ctor(stage, first_voice, count, args, n_args);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->set_ctor(stage, first_voice, count, args, n_args);
+  });
 }
 int32_t knh_bank_set_buffer(knh_bank* bank, uint32_t stage, const void* samples, size_t n_frames, double buffer_sample_rate) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->set_buffer(stage, samples, n_frames, buffer_sample_rate);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->set_buffer(stage, samples, n_frames, buffer_sample_rate);
+  });
 }
 int32_t knh_bank_init(knh_bank* bank, uint32_t sample_rate, size_t block_size) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->init(sample_rate, block_size);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->init(sample_rate, block_size);
+  });
 }
 uint16_t knh_bank_inputs(const knh_bank* bank) { return bank ? static_cast<uint16_t>(bank->desc.in_channels) : 0; }
 int32_t knh_bank_set_input(knh_bank* bank, uint32_t n_blocks, const void* in) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (!in) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null input");
-  return bank->set_input(n_blocks, in, nullptr);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!in) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null input");
+    return bank->set_input(n_blocks, in, nullptr);
+  });
 }
 int32_t knh_bank_set_input_device(knh_bank* bank, uint32_t n_blocks, const void* in_device) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (!in_device) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null input");
-  return bank->set_input(n_blocks, nullptr, in_device);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!in_device) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null input");
+    return bank->set_input(n_blocks, nullptr, in_device);
+  });
 }
 uint16_t knh_bank_outputs(const knh_bank* bank) { return bank ? static_cast<uint16_t>(bank->desc.out_channels) : 0; }
 uint16_t knh_bank_stage_parameters(const knh_bank* bank, uint32_t stage) {
@@ -2270,88 +2400,110 @@ const char* knh_bank_stage_param_description(const knh_bank* bank, uint32_t stag
   return kKinds[bank->stages[stage].kind].params[param];
 }
 int32_t knh_bank_param_apply(knh_bank* bank, uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double fvalue, int64_t ivalue) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->param_apply(voice, stage, param, kind, fvalue, ivalue);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->param_apply(voice, stage, param, kind, fvalue, ivalue);
+  });
 }
 int32_t knh_bank_set_delay_within_block_for_param(knh_bank* bank, uint32_t voice, uint32_t stage, uint32_t param, uint16_t delay) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->set_delay(voice, stage, param, delay);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->set_delay(voice, stage, param, delay);
+  });
 }
 int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* voices, const uint32_t* stages, const uint32_t* params,
                                   const uint32_t* kinds, const double* fvalues, const int64_t* ivalues, const uint16_t* delays) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
-  return bank->apply_many(0, count, voices, stages, params, kinds, fvalues, ivalues, delays);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
+    return bank->apply_many(0, count, voices, stages, params, kinds, fvalues, ivalues, delays);
+  });
 }
 int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, uint32_t* out_flags) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output block");
-  return bank->process(1, frames_to_process, block_start_offset, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output block");
+    return bank->process(1, frames_to_process, block_start_offset, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+  });
 }
 int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out_device, void* hip_stream) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->process(1, frames_to_process, block_start_offset, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->process(1, frames_to_process, block_start_offset, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+  });
 }
 int32_t knh_bank_process_block_voices(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, void* voices_out, uint32_t* out_flags) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (!voices_out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null voices_out");
-  return bank->process(1, frames_to_process, block_start_offset, frame_clock, out, nullptr, voices_out, out_flags, nullptr, true);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!voices_out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null voices_out");
+    return bank->process(1, frames_to_process, block_start_offset, frame_clock, out, nullptr, voices_out, out_flags, nullptr, true);
+  });
 }
 int32_t knh_bank_process_blocks(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out, uint32_t* out_flags) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output");
-  return bank->process(n_blocks, bank->block_size, 0, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output");
+    return bank->process(n_blocks, bank->block_size, 0, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+  });
 }
 int32_t knh_bank_process_blocks_device(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out_device, void* hip_stream) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false);
+  });
 }
 int32_t knh_bank_process_blocks_device_add(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock, void* out_device, void* hip_stream) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false, true);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, out_device, nullptr, nullptr, hip_stream, false, true);
+  });
 }
 int32_t knh_bank_process_blocks_begin(knh_bank* bank, uint32_t n_blocks, uint64_t frame_clock) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (!bank->initialised) return bank->fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
-  if (bank->pipe_count == 2) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "two launches are outstanding: fetch one with knh_bank_process_blocks_end first");
-  if (n_blocks == 0 || n_blocks > 4096) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "n_blocks must be in 1..4096");
-  auto hip = [&](hipError_t e, const char* what) { return e == hipSuccess ? KNH_OK : bank->fail(KNH_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
-  int rc = hip(hipSetDevice(bank->device), "hipSetDevice");
-  if (rc != KNH_OK) return rc;
-  if (!bank->pipe_stream && (rc = hip(hipStreamCreateWithFlags(&bank->pipe_stream, hipStreamNonBlocking), "hipStreamCreate")) != KNH_OK) return rc;
-  knh_bank::PipeSlot& p = bank->pipe[(bank->pipe_head + bank->pipe_count) % 2];
-  const size_t bytes = static_cast<size_t>(n_blocks) * bank->desc.out_channels * bank->block_size * (bank->desc.sample_type == KNH_F64 ? 8 : 4);
-  if (bytes > p.cap) {
-    if (p.dev) (void)hipFree(p.dev);
-    if (p.host) (void)hipHostFree(p.host);
-    p.dev = p.host = nullptr;
-    p.cap = 0;
-    if ((rc = hip(hipMalloc(&p.dev, bytes), "hipMalloc")) != KNH_OK) return rc;
-    if ((rc = hip(hipMemset(p.dev, 0, bytes), "hipMemset")) != KNH_OK) return rc;
-    if ((rc = hip(hipHostMalloc(&p.host, bytes), "hipHostMalloc")) != KNH_OK) return rc;
-    p.cap = bytes;
-  }
-  if (!p.done && (rc = hip(hipEventCreateWithFlags(&p.done, hipEventDisableTiming), "hipEventCreate")) != KNH_OK) return rc;
-  p.bytes = bytes;
-  rc = bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, p.dev, nullptr, nullptr, bank->pipe_stream, false);
-  if (rc != KNH_OK) return rc;
-  if ((rc = bank->order_after_collective(bank->pipe_stream)) != KNH_OK) return rc;
-  if ((rc = hip(hipSetDevice(bank->device), "hipSetDevice")) != KNH_OK) return rc;
-  if ((rc = hip(hipMemcpyAsync(p.host, p.dev, bytes, hipMemcpyDeviceToHost, bank->pipe_stream), "hipMemcpyAsync")) != KNH_OK) return rc;
-  if ((rc = hip(hipEventRecord(p.done, bank->pipe_stream), "hipEventRecord")) != KNH_OK) return rc;
-  bank->pipe_count += 1;
-  return KNH_OK;
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!bank->initialised) return bank->fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    if (bank->pipe_count == 2) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "two launches are outstanding: fetch one with knh_bank_process_blocks_end first");
+    if (n_blocks == 0 || n_blocks > 4096) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "n_blocks must be in 1..4096");
+    auto hip = [&](hipError_t e, const char* what) { return e == hipSuccess ? KNH_OK : bank->fail(KNH_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+    int rc = hip(hipSetDevice(bank->device), "hipSetDevice");
+    if (rc != KNH_OK) return rc;
+    if (!bank->pipe_stream && (rc = hip(hipStreamCreateWithFlags(&bank->pipe_stream, hipStreamNonBlocking), "hipStreamCreate")) != KNH_OK) return rc;
+    knh_bank::PipeSlot& p = bank->pipe[(bank->pipe_head + bank->pipe_count) % 2];
+    const size_t bytes = static_cast<size_t>(n_blocks) * bank->desc.out_channels * bank->block_size * (bank->desc.sample_type == KNH_F64 ? 8 : 4);
+    if (bytes > p.cap) {
+      if (p.dev) (void)hipFree(p.dev);
+      if (p.host) (void)hipHostFree(p.host);
+      p.dev = p.host = nullptr;
+      p.cap = 0;
+      if ((rc = hip(hipMalloc(&p.dev, bytes), "hipMalloc")) != KNH_OK) return rc;
+      if ((rc = hip(hipMemset(p.dev, 0, bytes), "hipMemset")) != KNH_OK) return rc;
+      if ((rc = hip(hipHostMalloc(&p.host, bytes), "hipHostMalloc")) != KNH_OK) return rc;
+      p.cap = bytes;
+    }
+    if (!p.done && (rc = hip(hipEventCreateWithFlags(&p.done, hipEventDisableTiming), "hipEventCreate")) != KNH_OK) return rc;
+    p.bytes = bytes;
+    rc = bank->process(n_blocks, bank->block_size, 0, frame_clock, nullptr, p.dev, nullptr, nullptr, bank->pipe_stream, false);
+    if (rc != KNH_OK) return rc;
+    if ((rc = bank->order_after_collective(bank->pipe_stream)) != KNH_OK) return rc;
+    if ((rc = hip(hipSetDevice(bank->device), "hipSetDevice")) != KNH_OK) return rc;
+    if ((rc = hip(hipMemcpyAsync(p.host, p.dev, bytes, hipMemcpyDeviceToHost, bank->pipe_stream), "hipMemcpyAsync")) != KNH_OK) return rc;
+    if ((rc = hip(hipEventRecord(p.done, bank->pipe_stream), "hipEventRecord")) != KNH_OK) return rc;
+    bank->pipe_count += 1;
+    return KNH_OK;
+  });
 }
 int32_t knh_bank_process_blocks_end(knh_bank* bank, void* out) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output");
-  if (bank->pipe_count == 0) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "no launch is outstanding (knh_bank_process_blocks_begin)");
-  knh_bank::PipeSlot& p = bank->pipe[bank->pipe_head];
-  if (hipSetDevice(bank->device) != hipSuccess || hipEventSynchronize(p.done) != hipSuccess) return bank->fail(KNH_ERR_DEVICE, "waiting for the launch failed");
-  std::memcpy(out, p.host, p.bytes);
-  bank->pipe_head = (bank->pipe_head + 1) % 2;
-  bank->pipe_count -= 1;
-  return KNH_OK;
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output");
+    if (bank->pipe_count == 0) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "no launch is outstanding (knh_bank_process_blocks_begin)");
+    knh_bank::PipeSlot& p = bank->pipe[bank->pipe_head];
+    if (hipSetDevice(bank->device) != hipSuccess || hipEventSynchronize(p.done) != hipSuccess) return bank->fail(KNH_ERR_DEVICE, "waiting for the launch failed");
+    std::memcpy(out, p.host, p.bytes);
+    bank->pipe_head = (bank->pipe_head + 1) % 2;
+    bank->pipe_count -= 1;
+    return KNH_OK;
+  });
 }
 void* knh_device_malloc(size_t bytes, int32_t device) {
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return nullptr;
@@ -2364,67 +2516,83 @@ void knh_device_free(void* p) {
   if (p) (void)hipFree(p);
 }
 int32_t knh_device_read(void* dst_host, const void* src_device, size_t bytes, void* hip_stream) {
-  // the banks enqueue on their own non-blocking streams unless told otherwise: wait for the device first
-  if (hipDeviceSynchronize() != hipSuccess) return KNH_ERR_DEVICE;
-  (void)hip_stream;
-  return hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost) == hipSuccess ? KNH_OK : KNH_ERR_DEVICE;
+  return guarded(nullptr, [&]() -> int32_t {
+    // the banks enqueue on their own non-blocking streams unless told otherwise: wait for the device first
+    if (hipDeviceSynchronize() != hipSuccess) return KNH_ERR_DEVICE;
+    (void)hip_stream;
+    return hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost) == hipSuccess ? KNH_OK : KNH_ERR_DEVICE;
+  });
 }
 int32_t knh_bank_param_apply_many_at(knh_bank* bank, uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stages,
                                      const uint32_t* params, const uint32_t* kinds, const double* fvalues, const int64_t* ivalues,
                                      const uint16_t* delays) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
-  return bank->apply_many(block_offset, count, voices, stages, params, kinds, fvalues, ivalues, delays);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (count && (!voices || !stages || !params || !kinds)) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null array");
+    return bank->apply_many(block_offset, count, voices, stages, params, kinds, fvalues, ivalues, delays);
+  });
 }
 int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->read_done_frames(done_frames);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->read_done_frames(done_frames);
+  });
 }
 int32_t knh_bank_debug_words(knh_bank* bank, uint32_t* out16) {
-  if (!bank || !out16) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->debug_read(out16);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank || !out16) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->debug_read(out16);
+  });
 }
 int32_t knh_bank_synchronize(knh_bank* bank) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->synchronize();
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->synchronize();
+  });
 }
 int32_t knh_bank_timing_reset(knh_bank* bank, int32_t enable) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->timing_reset(enable);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->timing_reset(enable);
+  });
 }
 int32_t knh_bank_timing_read(knh_bank* bank, double* kernel_ms, uint64_t* launches) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  return bank->timing_read(kernel_ms, launches);
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->timing_read(kernel_ms, launches);
+  });
 }
 int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_t* read_bytes, uint32_t* write_bytes) {
-  if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-  // every slot is read once; mutable slots are written once (masks mirror voice_chain.hpp kMutableMask)
-  uint32_t r = 0, w = 0;
-  const uint32_t word = bank->desc.sample_type == KNH_F64 ? 8 : 4;
-  for (const StageInfo& s : bank->stages) {
-    r += word * s.n_slots;
-    switch (s.kind) {
-      case KNH_STAGE_SIN_WT: w += word * ((s.flags & KNH_STAGE_FLAG_AR_FREQ) ? 2 : 1); break;
-      case KNH_STAGE_SIN_NUMERIC: w += word; break;
-      case KNH_STAGE_SVF: w += word * 2; break;
-      case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: w += word; break;
-      case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: w += word * 3; break;
-      case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
-      case KNH_STAGE_SAMPLE_DELAY: w += word; break;
-      case KNH_STAGE_PHASOR: w += word * 2; break;
-      case KNH_STAGE_WHITE_NOISE: w += word * 2; break;
-      case KNH_STAGE_PINK_NOISE: w += word * 14; break;
-      case KNH_STAGE_BROWN_NOISE: w += word * 3; break;
-      case KNH_STAGE_RANDOM_LIN: w += word * 5; break;
-      case KNH_STAGE_POLYBLEP: w += word; break;
-      case KNH_STAGE_BUFFER_READER: w += word * 3; break;  // + two Buffer samples read per frame
-      case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)
-      default: break;
+  return guarded(nullptr, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    // every slot is read once; mutable slots are written once (masks mirror voice_chain.hpp kMutableMask)
+    uint32_t r = 0, w = 0;
+    const uint32_t word = bank->desc.sample_type == KNH_F64 ? 8 : 4;
+    for (const StageInfo& s : bank->stages) {
+      r += word * s.n_slots;
+      switch (s.kind) {
+        case KNH_STAGE_SIN_WT: w += word * ((s.flags & KNH_STAGE_FLAG_AR_FREQ) ? 2 : 1); break;
+        case KNH_STAGE_SIN_NUMERIC: w += word; break;
+        case KNH_STAGE_SVF: w += word * 2; break;
+        case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: w += word; break;
+        case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: w += word * 3; break;
+        case KNH_STAGE_MUL_ENVELOPE: w += word * 6; break;
+        case KNH_STAGE_SAMPLE_DELAY: w += word; break;
+        case KNH_STAGE_PHASOR: w += word * 2; break;
+        case KNH_STAGE_WHITE_NOISE: w += word * 2; break;
+        case KNH_STAGE_PINK_NOISE: w += word * 14; break;
+        case KNH_STAGE_BROWN_NOISE: w += word * 3; break;
+        case KNH_STAGE_RANDOM_LIN: w += word * 5; break;
+        case KNH_STAGE_POLYBLEP: w += word; break;
+        case KNH_STAGE_BUFFER_READER: w += word * 3; break;  // + two Buffer samples read per frame
+        case KNH_STAGE_ALLPASS_DELAY: case KNH_STAGE_ALLPASS_FB_DELAY: w += word * 4; break;  // + one sample read and one written per frame (ring in HBM)  // + one sample read and one written per frame (ring in HBM)
+        default: break;
+      }
     }
-  }
-  if (read_bytes) *read_bytes = r;
-  if (write_bytes) *write_bytes = w;
-  return KNH_OK;
+    if (read_bytes) *read_bytes = r;
+    if (write_bytes) *write_bytes = w;
+    return KNH_OK;
+  });
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 
 #include "../../include/knaster_hip.h"
@@ -80,42 +81,62 @@ struct knh_comm {
   int fail(int code, const std::string& m) { err = m; return code; }
 };
 
+// no C++ exception crosses the C ABI (bank.hip has the same guard for the bank entry points)
+namespace {
+template <typename Fn>
+int32_t comm_guarded(knh_comm* c, Fn&& fn) noexcept {
+  try {
+    return fn();
+  } catch (const std::bad_alloc&) {
+    try { (c ? c->err : g_comm_create_error) = "out of host memory (std::bad_alloc)"; } catch (...) {}
+    return KNH_ERR_OUT_OF_MEMORY;
+  } catch (...) {
+    try { (c ? c->err : g_comm_create_error) = "internal error"; } catch (...) {}
+    return KNH_ERR_INTERNAL;
+  }
+}
+}  // namespace
+
 static_assert(sizeof(ncclUniqueId) == KNH_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
 
 extern "C" {
 
 int32_t knh_comm_unique_id(uint8_t* id) {
-  if (!id) { g_comm_create_error = "null id"; return KNH_ERR_INVALID_ARGUMENT; }
-  Rccl* r = rccl();
-  if (!r->error.empty()) { g_comm_create_error = r->error; return KNH_ERR_DEVICE; }
-  ncclUniqueId u;
-  ncclResult_t rc = r->GetUniqueId(&u);
-  if (rc != ncclSuccess) { g_comm_create_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(rc); return KNH_ERR_DEVICE; }
-  std::memcpy(id, &u, KNH_COMM_ID_BYTES);
-  return KNH_OK;
+  return comm_guarded(nullptr, [&]() -> int32_t {
+    if (!id) { g_comm_create_error = "null id"; return KNH_ERR_INVALID_ARGUMENT; }
+    Rccl* r = rccl();
+    if (!r->error.empty()) { g_comm_create_error = r->error; return KNH_ERR_DEVICE; }
+    ncclUniqueId u;
+    ncclResult_t rc = r->GetUniqueId(&u);
+    if (rc != ncclSuccess) { g_comm_create_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(rc); return KNH_ERR_DEVICE; }
+    std::memcpy(id, &u, KNH_COMM_ID_BYTES);
+    return KNH_OK;
+  });
 }
 
 int32_t knh_comm_create(uint32_t rank, uint32_t world, const uint8_t* id, int32_t device, knh_comm** out) {
-  if (out) *out = nullptr;
-  if (!out || !id || world == 0 || rank >= world) { g_comm_create_error = "bad rank/world/id"; return KNH_ERR_INVALID_ARGUMENT; }
-  Rccl* r = rccl();
-  if (!r->error.empty()) { g_comm_create_error = r->error; return KNH_ERR_DEVICE; }
-  auto c = new knh_comm();
-  auto bail = [&](const std::string& m) { g_comm_create_error = m; knh_comm_destroy(c); return KNH_ERR_DEVICE; };
-  if (device >= 0) c->device = device;
-  else if (hipGetDevice(&c->device) != hipSuccess) return bail("hipGetDevice failed");
-  if (hipSetDevice(c->device) != hipSuccess) return bail("hipSetDevice failed");
-  c->rank = rank;
-  c->world = world;
-  ncclUniqueId u;
-  std::memcpy(&u, id, KNH_COMM_ID_BYTES);
-  ncclResult_t rc = r->CommInitRank(&c->comm, static_cast<int>(world), u, static_cast<int>(rank));
-  if (rc != ncclSuccess) { c->comm = nullptr; return bail(std::string("ncclCommInitRank: ") + r->GetErrorString(rc)); }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
-  if (hipEventCreateWithFlags(&c->produced, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate failed");
-  if (hipEventCreateWithFlags(&c->reduced, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate failed");
-  *out = c;
-  return KNH_OK;
+  return comm_guarded(nullptr, [&]() -> int32_t {
+    if (out) *out = nullptr;
+    if (!out || !id || world == 0 || rank >= world) { g_comm_create_error = "bad rank/world/id"; return KNH_ERR_INVALID_ARGUMENT; }
+    Rccl* r = rccl();
+    if (!r->error.empty()) { g_comm_create_error = r->error; return KNH_ERR_DEVICE; }
+    auto c = new knh_comm();
+    auto bail = [&](const std::string& m) { g_comm_create_error = m; knh_comm_destroy(c); return KNH_ERR_DEVICE; };
+    if (device >= 0) c->device = device;
+    else if (hipGetDevice(&c->device) != hipSuccess) return bail("hipGetDevice failed");
+    if (hipSetDevice(c->device) != hipSuccess) return bail("hipSetDevice failed");
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId u;
+    std::memcpy(&u, id, KNH_COMM_ID_BYTES);
+    ncclResult_t rc = r->CommInitRank(&c->comm, static_cast<int>(world), u, static_cast<int>(rank));
+    if (rc != ncclSuccess) { c->comm = nullptr; return bail(std::string("ncclCommInitRank: ") + r->GetErrorString(rc)); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+    if (hipEventCreateWithFlags(&c->produced, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate failed");
+    if (hipEventCreateWithFlags(&c->reduced, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate failed");
+    *out = c;
+    return KNH_OK;
+  });
 }
 
 void knh_comm_destroy(knh_comm* c) {
@@ -148,57 +169,65 @@ int32_t knh_comm_rccl_version(void) {
 }
 
 int32_t knh_comm_reduce_sum(knh_comm* c, void* buf, size_t count, uint32_t sample_type, uint32_t root, void* after_stream) {
-  if (!c) return KNH_ERR_INVALID_ARGUMENT;
-  if (!buf || root >= c->world || sample_type > KNH_F64) return c->fail(KNH_ERR_INVALID_ARGUMENT, "knh_comm_reduce_sum: bad argument");
-  if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
-  // everything the producer stream has been given so far comes first
-  hipStream_t producer = static_cast<hipStream_t>(after_stream);
-  if (hipEventRecord(c->produced, producer) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
-  if (hipStreamWaitEvent(c->stream, c->produced, 0) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
-  ncclResult_t rc = rccl()->Reduce(buf, buf, count, sample_type == KNH_F64 ? ncclFloat64 : ncclFloat32, ncclSum, static_cast<int>(root), c->comm, c->stream);
-  if (rc != ncclSuccess) return c->fail(KNH_ERR_DEVICE, std::string("ncclReduce: ") + rccl()->GetErrorString(rc));
-  if (hipEventRecord(c->reduced, c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
-  c->pending = true;
-  knh_comm::Slot* slot = nullptr;
-  for (auto& sl : c->slots)
-    if (sl.buf == buf) slot = &sl;
-  if (!slot) {  // the least recently used one; an event recorded later on the same stream covers what it stood for
-    slot = &c->slots[0];
+  return comm_guarded(c, [&]() -> int32_t {
+    if (!c) return KNH_ERR_INVALID_ARGUMENT;
+    if (!buf || root >= c->world || sample_type > KNH_F64) return c->fail(KNH_ERR_INVALID_ARGUMENT, "knh_comm_reduce_sum: bad argument");
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
+    // everything the producer stream has been given so far comes first
+    hipStream_t producer = static_cast<hipStream_t>(after_stream);
+    if (hipEventRecord(c->produced, producer) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
+    if (hipStreamWaitEvent(c->stream, c->produced, 0) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
+    ncclResult_t rc = rccl()->Reduce(buf, buf, count, sample_type == KNH_F64 ? ncclFloat64 : ncclFloat32, ncclSum, static_cast<int>(root), c->comm, c->stream);
+    if (rc != ncclSuccess) return c->fail(KNH_ERR_DEVICE, std::string("ncclReduce: ") + rccl()->GetErrorString(rc));
+    if (hipEventRecord(c->reduced, c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
+    c->pending = true;
+    knh_comm::Slot* slot = nullptr;
     for (auto& sl : c->slots)
-      if (sl.stamp < slot->stamp) slot = &sl;
-  }
-  if (!slot->done && hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventCreate failed");
-  slot->buf = buf;
-  slot->stamp = ++c->clock;
-  if (hipEventRecord(slot->done, c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
-  return KNH_OK;
+      if (sl.buf == buf) slot = &sl;
+    if (!slot) {  // the least recently used one; an event recorded later on the same stream covers what it stood for
+      slot = &c->slots[0];
+      for (auto& sl : c->slots)
+        if (sl.stamp < slot->stamp) slot = &sl;
+    }
+    if (!slot->done && hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventCreate failed");
+    slot->buf = buf;
+    slot->stamp = ++c->clock;
+    if (hipEventRecord(slot->done, c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
+    return KNH_OK;
+  });
 }
 
 int32_t knh_comm_wait_buffer(knh_comm* c, const void* buf, void* stream) {
-  if (!c) return KNH_ERR_INVALID_ARGUMENT;
-  if (!c->pending) return KNH_OK;
-  if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
-  for (auto& sl : c->slots)
-    if (sl.buf == buf && sl.done)
-      return hipStreamWaitEvent(static_cast<hipStream_t>(stream), sl.done, 0) == hipSuccess ? KNH_OK : c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
-  // not among the recent ones: every reduce so far
-  return hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->reduced, 0) == hipSuccess ? KNH_OK : c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
+  return comm_guarded(c, [&]() -> int32_t {
+    if (!c) return KNH_ERR_INVALID_ARGUMENT;
+    if (!c->pending) return KNH_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
+    for (auto& sl : c->slots)
+      if (sl.buf == buf && sl.done)
+        return hipStreamWaitEvent(static_cast<hipStream_t>(stream), sl.done, 0) == hipSuccess ? KNH_OK : c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
+    // not among the recent ones: every reduce so far
+    return hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->reduced, 0) == hipSuccess ? KNH_OK : c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
+  });
 }
 
 int32_t knh_comm_wait(knh_comm* c, void* stream) {
-  if (!c) return KNH_ERR_INVALID_ARGUMENT;
-  if (!c->pending) return KNH_OK;
-  if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
-  if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->reduced, 0) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
-  return KNH_OK;
+  return comm_guarded(c, [&]() -> int32_t {
+    if (!c) return KNH_ERR_INVALID_ARGUMENT;
+    if (!c->pending) return KNH_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
+    if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->reduced, 0) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
+    return KNH_OK;
+  });
 }
 
 int32_t knh_comm_synchronize(knh_comm* c) {
-  if (!c) return KNH_ERR_INVALID_ARGUMENT;
-  if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamSynchronize failed");
-  c->pending = false;
-  return KNH_OK;
+  return comm_guarded(c, [&]() -> int32_t {
+    if (!c) return KNH_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamSynchronize failed");
+    c->pending = false;
+    return KNH_OK;
+  });
 }
 
 }  // extern "C"

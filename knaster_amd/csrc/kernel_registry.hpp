@@ -70,12 +70,13 @@ const KernelEntry* kernel_at(int i);
 // n_blocks consecutive [n_rows][row_len] row sets -> n_blocks consecutive [channels][out_stride] blocks.
 // tree = false: exact left fold of the rows in order; tree = true: 16-ary two-level fold (deterministic)
 // zero_flags (or null): two words the kernel also clears -- the flag set of the bank's next launch
+// host (or null): `out` is mapped pinned host memory and the kernel signals the host when it is written (knh_dev::HostDone)
 hipError_t launch_fold_f32(bool tree, const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
                            unsigned frame_end, float* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate,
-                           unsigned* zero_flags, hipStream_t s);
+                           unsigned* zero_flags, hipStream_t s, const knh_dev::HostDone* host = nullptr);
 hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
                            unsigned frame_end, double* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate,
-                           unsigned* zero_flags, hipStream_t s);
+                           unsigned* zero_flags, hipStream_t s, const knh_dev::HostDone* host = nullptr);
 
 // Host-sharded banks (host_shards.hpp): out[i] (+)= shards[0][i] + shards[1][i] + ... in shard order, for the frames
 // [frame_begin, frame_end) of every block of `block_size` frames; n = elements per shard, shard k starts at k * shard_stride.

@@ -42,29 +42,34 @@ const DagEntry* find_dag(const char*) { return nullptr; }
 
 template <typename F>
 static hipError_t launch_fold(bool tree, const F* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin, unsigned frame_end,
-                              F* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate, unsigned* zero_flags, hipStream_t s) {
-  if (frame_end <= frame_begin || n_rows == 0 || n_blocks == 0)  // nothing to fold: the flag words still have to be cleared
+                              F* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate, unsigned* zero_flags,
+                              const HostDone& host, hipStream_t s) {
+  if (frame_end <= frame_begin || n_rows == 0 || n_blocks == 0) {  // nothing to fold: the flag words still have to be cleared
+    if (host.words) return hipErrorInvalidValue;  // (the caller hands a launch over this way only when there is something to fold)
     return zero_flags ? hipMemsetAsync(zero_flags, 0, 2 * sizeof(unsigned), s) : hipSuccess;
+  }
   if (tree) {
     unsigned grid = (frame_end - frame_begin + 15u) / 16u;
     hipLaunchKernelGGL((fold_tree_kernel<F>), dim3(grid, n_blocks), dim3(256), 0, s, rows, n_rows, row_len, frame_begin, frame_end,
-                       out, channels, out_stride, accumulate ? 1u : 0u, zero_flags);
+                       out, channels, out_stride, accumulate ? 1u : 0u, zero_flags, host);
   } else {
     unsigned grid = (frame_end - frame_begin + 63u) / 64u;
     hipLaunchKernelGGL((fold_rows_kernel<F>), dim3(grid, n_blocks), dim3(64), 0, s, rows, n_rows, row_len, frame_begin, frame_end,
-                       out, channels, out_stride, accumulate ? 1u : 0u, zero_flags);
+                       out, channels, out_stride, accumulate ? 1u : 0u, zero_flags, host);
   }
   return hipGetLastError();
 }
 hipError_t launch_fold_f32(bool tree, const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
                            unsigned frame_end, float* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate,
-                           unsigned* zero_flags, hipStream_t s) {
-  return launch_fold<float>(tree, rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, n_blocks, accumulate, zero_flags, s);
+                           unsigned* zero_flags, hipStream_t s, const knh_dev::HostDone* host) {
+  return launch_fold<float>(tree, rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, n_blocks, accumulate, zero_flags,
+                            host ? *host : HostDone{nullptr, nullptr, nullptr, 0u}, s);
 }
 hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
                            unsigned frame_end, double* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate,
-                           unsigned* zero_flags, hipStream_t s) {
-  return launch_fold<double>(tree, rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, n_blocks, accumulate, zero_flags, s);
+                           unsigned* zero_flags, hipStream_t s, const knh_dev::HostDone* host) {
+  return launch_fold<double>(tree, rows, n_rows, row_len, frame_begin, frame_end, out, channels, out_stride, n_blocks, accumulate, zero_flags,
+                             host ? *host : HostDone{nullptr, nullptr, nullptr, 0u}, s);
 }
 
 

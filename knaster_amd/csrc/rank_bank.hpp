@@ -78,24 +78,46 @@ struct RankBank final : knh_bank {
   }
   int init(uint32_t sr, size_t bs) override {
     if (initialised) return fail(KNH_ERR_INVALID_ARGUMENT, "already initialised");
+    // A failed init leaves nothing half made that a second call could trip over: the communicator and the stream are
+    // taken down again, and a local bank that did come up is not initialised twice -- the handle then refuses every
+    // further init (the host creates a new bank, as bench.py's fallback does).
+    if (init_failed) return fail(KNH_ERR_INVALID_ARGUMENT, "an earlier knh_bank_init of this bank failed (" + init_error + "): create a new bank");
     if (knh_device_count() <= 0) return fail(KNH_ERR_NO_DEVICE, "no gfx950 device visible; this engine has no CPU path");
     if (desc.device >= 0) device = desc.device;
     else KNH_HIP(hipGetDevice(&device));
     KNH_HIP(hipSetDevice(device));
+    auto undo = [&](int rc) {
+      init_failed = true;
+      init_error = err;
+      if (comm) { knh_comm_destroy(comm); comm = nullptr; }
+      if (own_stream) { (void)hipStreamDestroy(own_stream); own_stream = nullptr; }
+      return rc;
+    };
+    // the communicator first: creating it is a collective of all ranks, and a rank whose own voices then fail to come up
+    // must not leave the others waiting in it
+    if (world > 1 && !custom) {
+      int rc = knh_comm_create(rank, world, comm_id, device, &comm);
+      if (rc != KNH_OK) return undo(fail(rc, std::string("knh_comm_create: ") + knh_comm_last_error(nullptr)));
+      if (knh_comm_world(comm) != world) return undo(fail(KNH_ERR_DEVICE, "RCCL reports a different number of ranks than the host asked for"));
+    }
     if (local) {
       int rc = local->init(sr, bs);
-      if (rc != KNH_OK) return adopt(rc);
+      if (rc != KNH_OK) return undo(adopt(rc));
     }
     sample_rate = sr;
     block_size = bs;
-    KNH_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-    if (world > 1 && !custom) {
-      int rc = knh_comm_create(rank, world, comm_id, device, &comm);
-      if (rc != KNH_OK) return fail(rc, std::string("knh_comm_create: ") + knh_comm_last_error(nullptr));
-      if (knh_comm_world(comm) != world) return fail(KNH_ERR_DEVICE, "RCCL reports a different number of ranks than the host asked for");
+    {
+      hipError_t e = hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return undo(fail(KNH_ERR_DEVICE, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e)));
     }
     initialised = true;
     return KNH_OK;
+  }
+  bool init_failed = false;
+  std::string init_error;
+  bool kind_ok(uint32_t stage, uint32_t param, uint32_t kind) const {
+    const int want = expected_value_kind(stages[stage].kind, param);
+    return static_cast<int>(kind) == want || (kind == KNH_VALUE_SMOOTHING && (stages[stage].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && want == KNH_VALUE_FLOAT);
   }
   int check_global(uint32_t voice, uint32_t stage, uint32_t param) {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
@@ -107,9 +129,7 @@ struct RankBank final : knh_bank {
   int param_apply(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i) override {
     int rc = check_global(voice, stage, param);
     if (rc != KNH_OK) return rc;
-    const int want = expected_value_kind(stages[stage].kind, param);
-    if (static_cast<int>(kind) != want && !(kind == KNH_VALUE_SMOOTHING && (stages[stage].flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) && want == KNH_VALUE_FLOAT))
-      return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
+    if (!kind_ok(stage, param, kind)) return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
     if (!mine(voice)) return KNH_OK;
     return adopt(local->param_apply(voice - lo, stage, param, kind, f, i));
   }
@@ -123,21 +143,27 @@ struct RankBank final : knh_bank {
               uint16_t delay) override {
     int rc = check_global(voice, stage, param);
     if (rc != KNH_OK) return rc;
+    if (block_offset >= 65536) return fail(KNH_ERR_OUT_OF_RANGE, "block_offset too large");
+    if (!is_delay && !kind_ok(stage, param, kind)) return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
     if (!mine(voice)) return KNH_OK;
     return adopt(local->call_at(block_offset, is_delay, voice - lo, stage, param, kind, f, i, delay));
   }
-  // a batch: the calls for this rank's voices, in array order, with local indices; the rest is checked and dropped
+  // a batch: the calls for this rank's voices, in array order, with local indices; the rest is checked -- voice, stage,
+  // parameter and value kind, exactly as the owning rank checks them, so that every rank returns the same code for the
+  // same batch -- and dropped
   int apply_many(uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stgs, const uint32_t* params,
                  const uint32_t* kinds, const double* fvalues, const int64_t* ivalues, const uint16_t* delays) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
     r_voices.clear(); r_stages.clear(); r_params.clear(); r_kinds.clear(); r_f.clear(); r_i.clear(); r_d.clear();
-    int rc = KNH_OK;
+    int rc = KNH_OK;  // the code of the last refused call, in array order: the same on every rank
     for (size_t k = 0; k < count; ++k) {
       const uint32_t v = voices[k];
-      if (!mine(v)) {
-        if (v >= total) rc = fail(KNH_ERR_OUT_OF_RANGE, "voice out of range");
-        continue;
-      }
+      if (v >= total) { rc = fail(KNH_ERR_OUT_OF_RANGE, "voice out of range"); continue; }
+      if (stgs[k] >= stages.size()) { rc = fail(KNH_ERR_OUT_OF_RANGE, "stage out of range"); continue; }
+      if (params[k] >= static_cast<uint32_t>(stages[stgs[k]].n_params)) { rc = fail(KNH_ERR_OUT_OF_RANGE, "parameter index out of range"); continue; }
+      if (block_offset >= 65536) { rc = fail(KNH_ERR_OUT_OF_RANGE, "block_offset too large"); continue; }
+      if (!kind_ok(stgs[k], params[k], kinds[k])) { rc = fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type"); continue; }
+      if (!mine(v)) continue;
       r_voices.push_back(v - lo); r_stages.push_back(stgs[k]); r_params.push_back(params[k]); r_kinds.push_back(kinds[k]);
       if (fvalues) r_f.push_back(fvalues[k]);
       if (ivalues) r_i.push_back(ivalues[k]);
@@ -146,7 +172,7 @@ struct RankBank final : knh_bank {
     if (!r_voices.empty()) {
       int r2 = adopt(local->apply_many(block_offset, r_voices.size(), r_voices.data(), r_stages.data(), r_params.data(), r_kinds.data(),
                                        fvalues ? r_f.data() : nullptr, ivalues ? r_i.data() : nullptr, delays ? r_d.data() : nullptr));
-      if (r2 != KNH_OK) rc = r2;
+      if (r2 != KNH_OK && rc == KNH_OK) rc = r2;  // (what is forwarded has passed the checks: only a device-side failure is left)
     }
     return rc;
   }

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -43,7 +44,16 @@ class ShardWorkers {
       }
       cv_job_.notify_all();
     }
-    fn(0);
+    // An exception (std::bad_alloc from a queue that grows) must neither end a worker thread -- std::terminate -- nor
+    // unwind the caller while workers still run a job that lives on the caller's stack: every thread catches its own,
+    // run() waits for all of them and then rethrows the first on the calling thread, where the C ABI's guard turns it
+    // into a status.
+    std::exception_ptr mine;
+    try {
+      fn(0);
+    } catch (...) {
+      mine = std::current_exception();
+    }
     if (n_ > 1) {
       for (int spin = 0; spin < 20000 && remaining_.load(std::memory_order_acquire) != 0; ++spin) cpu_relax();
       if (remaining_.load(std::memory_order_acquire) != 0) {
@@ -51,6 +61,14 @@ class ShardWorkers {
         cv_done_.wait(l, [this] { return remaining_.load(std::memory_order_acquire) == 0; });
       }
     }
+    std::exception_ptr theirs;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      theirs = failed_;
+      failed_ = nullptr;
+    }
+    if (mine) std::rethrow_exception(mine);
+    if (theirs) std::rethrow_exception(theirs);
   }
 
  private:
@@ -69,7 +87,12 @@ class ShardWorkers {
         if (stop_) return;
         job = job_;
       }
-      (*job)(k);
+      try {
+        (*job)(k);
+      } catch (...) {
+        std::lock_guard<std::mutex> l(m_);
+        if (!failed_) failed_ = std::current_exception();
+      }
       if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         std::lock_guard<std::mutex> l(m_);
         cv_done_.notify_one();
@@ -84,6 +107,7 @@ class ShardWorkers {
   std::atomic<uint64_t> epoch_{0};
   std::atomic<int> remaining_{0};
   bool stop_ = false;
+  std::exception_ptr failed_;  // the first exception a worker's job threw (under m_)
 };
 
 

@@ -2268,34 +2268,66 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   }
 }
 
+// Hand-over of a launch's mixed block(s) to the HOST with no copy command and no stream synchronisation behind it: the fold
+// kernel writes its output straight into mapped pinned host memory (`out` is then a host pointer) and, when the last of its
+// workgroups is through, the launch's two flag words and an epoch number the host polls.  What UGen::process_block costs per
+// call at the C ABI (knh_bank_process_block, one call per block as Task::run makes them, knaster_graph/src/task.rs:25-31) is
+// then two kernel launches and one PCIe write, not two launches, two copies and a stream wait.
+// Order: every thread that stored to host memory makes its stores visible system-wide (__threadfence_system: write-back and
+// a wait for the acknowledgements) before its workgroup counts itself in; the workgroup that counts last has therefore seen
+// every other one's fence, and its own epoch store is a system-scope release behind the flag words.
+struct HostDone {
+  u32* words;        // pinned host memory: [0] epoch of the last finished launch, [1] flags[0], [2] flags[1]; null: no hand-over
+  u32* counter;      // device word, zero between launches: workgroups of this fold kernel that are through
+  const u32* flags;  // the launch's flag words (written by the voice kernel, which has finished)
+  u32 epoch;
+};
+__device__ __forceinline__ void fold_signal_host(const HostDone& h) {
+  if (!h.words) return;  // uniform
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 total = gridDim.x * gridDim.y;
+    if (atomicAdd(h.counter, 1u) == total - 1u) {
+      *h.counter = 0u;  // for the next launch (stream order)
+      __hip_atomic_store(&h.words[1], h.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&h.words[2], h.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&h.words[0], h.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // Exact left fold of `n_rows` rows, row order = voice order: out[n] = ((r0+r1)+r2)+... in sample
 // precision (knaster_graph/src/graph.rs:827-872).  Serial in the row axis by definition; loads run
 // 16 rows ahead of the adds.  out: [channels][out_stride]; frames [frame_begin, frame_end) are written.
 template <typename F>
 __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
-                                                        u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate, u32* zero_flags) {
+                                                        u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate, u32* zero_flags,
+                                                        HostDone host) {
   // the flag words the NEXT launch's voice kernel accumulates into (two sets alternate; this spares a memset node)
   if (zero_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { zero_flags[0] = 0u; zero_flags[1] = 0u; }
   const u32 n = frame_begin + blockIdx.x * 64u + threadIdx.x;
-  if (n >= frame_end) return;
-  rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
-  out += (long)blockIdx.y * channels * out_stride;
-  const F* p = rows + n;
-  F acc = p[0];
-  u32 r = 1;
-  for (; r + 16 <= n_rows; r += 16) {
-    F v[16];
+  if (n < frame_end) {
+    rows += (long)blockIdx.y * n_rows * row_len;   // blockIdx.y = block of the launch
+    out += (long)blockIdx.y * channels * out_stride;
+    const F* p = rows + n;
+    F acc = p[0];
+    u32 r = 1;
+    for (; r + 16 <= n_rows; r += 16) {
+      F v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = p[(long)(r + k) * row_len];
+      for (int k = 0; k < 16; ++k) v[k] = p[(long)(r + k) * row_len];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc = acc + v[k];
+      for (int k = 0; k < 16; ++k) acc = acc + v[k];
+    }
+    for (; r < n_rows; ++r) acc = acc + p[(long)r * row_len];
+    // accumulate: this bank is a further additive source on the same output (existing + new, graph.rs:850-864)
+    for (u32 c = 0; c < channels; ++c) {
+      F* o = out + (long)c * out_stride + n;
+      *o = accumulate ? *o + acc : acc;
+    }
   }
-  for (; r < n_rows; ++r) acc = acc + p[(long)r * row_len];
-  // accumulate: this bank is a further additive source on the same output (existing + new, graph.rs:850-864)
-  for (u32 c = 0; c < channels; ++c) {
-    F* o = out + (long)c * out_stride + n;
-    *o = accumulate ? *o + acc : acc;
-  }
+  fold_signal_host(host);
 }
 
 // KNH_MIX_TREE, from the per-wavefront rows upwards: the rows are consecutive nodes of one level of the tree described at
@@ -2305,7 +2337,8 @@ __global__ void __launch_bounds__(64) fold_rows_kernel(const F* rows, u32 n_rows
 // LDS the way a binary counter carries (pass k merges with as many finished neighbours as k has trailing one bits).
 template <typename F>
 __global__ void __launch_bounds__(256) fold_tree_kernel(const F* rows, u32 n_rows, u32 row_len, u32 frame_begin,
-                                                         u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate, u32* zero_flags) {
+                                                         u32 frame_end, F* out, u32 channels, u32 out_stride, u32 accumulate, u32* zero_flags,
+                                                         HostDone host) {
   __shared__ F part[16][17];
   __shared__ F stack[32][16];
   if (zero_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { zero_flags[0] = 0u; zero_flags[1] = 0u; }  // see fold_rows_kernel
@@ -2353,6 +2386,7 @@ __global__ void __launch_bounds__(256) fold_tree_kernel(const F* rows, u32 n_row
       *o = accumulate ? *o + total : total;
     }
   }
+  fold_signal_host(host);
 }
 
 }  // namespace knh_dev

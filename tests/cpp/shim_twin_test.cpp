@@ -1,0 +1,296 @@
+// Tests and timing of the C ABI driven exactly as the Rust shim drives it (shim_twin.hpp = lib.rs in C++), one
+// process_block call per block, the way the reference runs a node (knaster_graph/src/task.rs:25-31,
+// processor.rs:142-179, graph_gen.rs:110-200).
+//   shim_twin_test --cpu                 : what needs no device (the exception guard of the ABI)
+//   shim_twin_test --gpu                 : the call sequences on a MI355X, checked against the oracle / against one launch
+//   shim_twin_test --bench C3|C1 [blocks]: the per-block boundary rate, one JSON line
+#include <sys/resource.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../oracle/knaster_oracle.hpp"  // test-side checker only
+#include "shim_twin.hpp"
+
+using namespace shim_twin;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                   \
+  do {                                                                \
+    if (!(cond)) {                                                    \
+      std::printf("  FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+      ++g_fail;                                                       \
+    }                                                                 \
+  } while (0)
+#define RUN(name)                                                         \
+  do {                                                                    \
+    int before = g_fail;                                                  \
+    try { name(); } catch (const std::exception& e) { std::printf("  EXCEPTION %s\n", e.what()); ++g_fail; } \
+    std::printf("%s %s\n", g_fail == before ? "ok  " : "FAIL", #name);    \
+  } while (0)
+
+struct C3Voice { double freq, gain, cutoff, q, atk, rel; };
+static std::vector<C3Voice> c3_voices(int n) {  // the reference's xorshift32, seven draws per voice
+  kno::XOrShift32Rng rng(0x9E3779B9u);
+  std::vector<C3Voice> v;
+  for (int i = 0; i < n; ++i) {
+    double u[7];
+    for (double& x : u) x = static_cast<double>(rng.gen_f32());
+    v.push_back({55.0 * std::exp2(6.0 * u[0]), 1.0 / n, 200.0 + 7800.0 * u[1], 0.5 + 3.5 * u[2], 0.002 + 0.02 * u[3], 0.05 + 0.25 * u[4]});
+  }
+  return v;
+}
+static std::vector<knh_stage_desc> c3_chain() {
+  return {stage(KNH_STAGE_SIN_WT), stage(KNH_STAGE_WR_MUL), stage(KNH_STAGE_SVF), stage(KNH_STAGE_MUL_ENV_ASR)};
+}
+static std::vector<std::vector<double>> c3_ctor(int n) {
+  auto v = c3_voices(n);
+  std::vector<std::vector<double>> c(4);
+  for (const auto& x : v) {
+    c[0].push_back(x.freq);
+    c[1].push_back(x.gain);
+    c[2].insert(c[2].end(), {double(KNH_SVF_LOW), x.cutoff, x.q, 0.0});
+    c[3].insert(c[3].end(), {x.atk, x.rel});
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// No C++ exception crosses the C ABI: with the address space capped, a bank whose constructor tables cannot be allocated
+// comes back as KNH_ERR_OUT_OF_MEMORY with a message -- not as a std::bad_alloc unwinding into the caller.
+static void cpu_no_exception_crosses_the_abi() {
+  rlimit old{};
+  getrlimit(RLIMIT_AS, &old);
+  rlimit cap = old;
+  cap.rlim_cur = 6ull << 30;
+  CHECK(setrlimit(RLIMIT_AS, &cap) == 0);
+  std::vector<knh_stage_desc> st = c3_chain();
+  knh_bank_desc desc{};
+  desc.abi_version = KNH_ABI_VERSION;
+  desc.n_voices = 0x7FFFFFFFu;  // x 4 constructor arguments x 8 bytes = 64 GiB for the SVF's table alone
+  desc.sample_type = KNH_F32;
+  desc.n_stages = static_cast<uint32_t>(st.size());
+  desc.stages = st.data();
+  desc.out_channels = 2;
+  desc.mix_mode = KNH_MIX_TREE;
+  desc.device = -1;
+  knh_bank* b = reinterpret_cast<knh_bank*>(1);
+  const int32_t rc = knh_bank_create(&desc, &b);
+  CHECK(rc == KNH_ERR_OUT_OF_MEMORY);
+  CHECK(b == nullptr);
+  CHECK(std::strstr(knh_last_error(nullptr), "memory") != nullptr);
+  CHECK(std::strcmp(knh_status_string(KNH_ERR_OUT_OF_MEMORY), "out of host memory") == 0);
+  setrlimit(RLIMIT_AS, &old);
+  // and the library is as usable as before
+  desc.n_voices = 64;
+  CHECK(knh_bank_create(&desc, &b) == KNH_OK && b != nullptr);
+  knh_bank_destroy(b);
+}
+
+// ---------------------------------------------------------------------------------------------------
+static void gpu_readme_example_block_by_block() {  // BASELINE.json configs[0]: README.md:34-51, block 64
+  GpuVoiceBank<float> bank({stage(KNH_STAGE_SIN_WT), stage(KNH_STAGE_MUL_CONST)}, 1, {{440.0}, {0.2}});
+  bank.init(48000, 64);
+  CHECK(bank.init_error().empty());
+  AudioCtx ctx;
+  UGenFlags flags;
+  const auto& table = kno::sine_wavetable_f32();
+  const uint32_t inc = kno::sat_u32(double(440.f) * (16384.0 * 65536.0 * (1.0 / 48000.0)));
+  uint32_t phase = 0;
+  std::vector<float> out(2 * 64);
+  for (int block = 0; block < 8; ++block) {  // AudioProcessor::run_without_inputs, processor.rs:142-179
+    CHECK(bank.process_block(ctx, flags, nullptr, out.data()) == KNH_OK);
+    ctx.frame_clock += 64;
+    for (size_t i = 0; i < 64; ++i) {
+      const float want = table[(phase >> 16) & 16383] * 0.2f;
+      CHECK(out[i] == want && out[64 + i] == want);
+      phase += inc;
+    }
+  }
+  CHECK(!flags.done);  // a chain without an envelope never finishes
+}
+
+// The note cycle of the bench through single calls, block by block, against ONE launch of the same blocks with the events
+// scheduled ahead: the two ways a host may drive a bank give the same samples, bit for bit.
+static void gpu_c3_block_by_block_equals_one_launch() {
+  const int N = 320, B = 128, BLOCKS = 8;
+  GpuVoiceBank<float> a(c3_chain(), N, c3_ctor(N)), b(c3_chain(), N, c3_ctor(N));
+  a.init(48000, B);
+  b.init(48000, B);
+  CHECK(a.init_error().empty() && b.init_error().empty());
+  AudioCtx ctx;
+  ctx.block_size = ctx.frames_to_process = B;
+  UGenFlags flags;
+  std::vector<float> blocks_a(size_t(BLOCKS) * 2 * B), blocks_b(blocks_a.size());
+  for (int blk = 0; blk < BLOCKS; ++blk) {
+    // graph_gen.rs:110-166: the block's events first (one SchedulingEvent per voice = one param_apply each) ...
+    if (blk == 0) for (int v = 0; v < N; ++v) CHECK(a.param_apply(ctx, a.index(v, 3, "t_restart"), Value::Trigger) == KNH_OK);
+    if (blk == 4) for (int v = 0; v < N; ++v) CHECK(a.param_apply(ctx, a.index(v, 3, "t_release"), Value::Trigger) == KNH_OK);
+    if (blk == 2) CHECK(a.param_apply(ctx, a.index(7, 2, "cutoff_freq"), Value::Float, 1234.5) == KNH_OK);
+    // ... then the task loop (:196-200)
+    CHECK(a.process_block(ctx, flags, nullptr, &blocks_a[size_t(blk) * 2 * B]) == KNH_OK);
+    ctx.frame_clock += B;
+  }
+  std::vector<uint32_t> voices(N), st(N, 3), pr(N), kinds(N, KNH_VALUE_TRIGGER);
+  for (int v = 0; v < N; ++v) voices[v] = v;
+  std::fill(pr.begin(), pr.end(), 3u);
+  CHECK(knh_bank_param_apply_many_at(b.raw(), 0, N, voices.data(), st.data(), pr.data(), kinds.data(), nullptr, nullptr, nullptr) == KNH_OK);
+  std::fill(pr.begin(), pr.end(), 2u);
+  CHECK(knh_bank_param_apply_many_at(b.raw(), 4, N, voices.data(), st.data(), pr.data(), kinds.data(), nullptr, nullptr, nullptr) == KNH_OK);
+  const uint32_t v7 = 7, s2 = 2, p0 = 0, kf = KNH_VALUE_FLOAT;
+  const double f = 1234.5;
+  CHECK(knh_bank_param_apply_many_at(b.raw(), 2, 1, &v7, &s2, &p0, &kf, &f, nullptr, nullptr) == KNH_OK);
+  uint32_t fl = 0;
+  CHECK(knh_bank_process_blocks(b.raw(), BLOCKS, 0, blocks_b.data(), &fl) == KNH_OK);
+  CHECK(std::memcmp(blocks_a.data(), blocks_b.data(), blocks_a.size() * sizeof(float)) == 0);
+  float peak = 0;
+  for (float x : blocks_a) peak = std::max(peak, std::fabs(x));
+  CHECK(peak > 1e-4f);
+}
+
+// A partial block, then the rest (what a splitting wrapper around the node would ask for, ugen.rs:87-93): same samples
+static void gpu_partial_blocks() {
+  const int N = 70, B = 64;
+  GpuVoiceBank<float> a(c3_chain(), N, c3_ctor(N)), b(c3_chain(), N, c3_ctor(N));
+  a.init(48000, B);
+  b.init(48000, B);
+  AudioCtx ctx;
+  UGenFlags flags;
+  for (int v = 0; v < N; ++v) {
+    a.param_apply(ctx, a.index(v, 3, "t_restart"), Value::Trigger);
+    b.param_apply(ctx, b.index(v, 3, "t_restart"), Value::Trigger);
+  }
+  std::vector<float> whole(2 * B), parts(2 * B, -7.f);
+  for (int blk = 0; blk < 3; ++blk) {
+    ctx.block_start_offset = 0; ctx.frames_to_process = B;
+    CHECK(a.process_block(ctx, flags, nullptr, whole.data()) == KNH_OK);
+    ctx.block_start_offset = 0; ctx.frames_to_process = 40;
+    CHECK(b.process_block(ctx, flags, nullptr, parts.data()) == KNH_OK);
+    ctx.block_start_offset = 40; ctx.frames_to_process = 24;
+    CHECK(b.process_block(ctx, flags, nullptr, parts.data()) == KNH_OK);
+    CHECK(std::memcmp(whole.data(), parts.data(), whole.size() * sizeof(float)) == 0);
+    ctx.frame_clock += B;
+  }
+}
+
+// UGen::Inputs = 1 and one audio-rate parameter slot: per voice  out = SinWt.ar_params(freq <- slot * depth + f0) * input0
+// (the modulator's block handed over by set_ar_param_buffer, the audio input by process_block's `input`).
+static void gpu_inputs_and_audio_rate_buffer() {
+  const int N = 2, B = 64;
+  // stages: 0 INPUT(ch 1 = slot 0)  1 * depth  2 + f0  3 SinWt (audio-rate freq)  4 INPUT(ch 0)  5 sine * input
+  std::vector<knh_stage_desc> st = {stage(KNH_STAGE_INPUT), stage(KNH_STAGE_MUL_CONST), stage(KNH_STAGE_ADD_CONST), stage(KNH_STAGE_SIN_WT),
+                                    stage(KNH_STAGE_INPUT), stage(KNH_STAGE_MATH_MUL)};
+  st[3].flags = KNH_STAGE_FLAG_AR_FREQ;
+  st[5].input = 4;   // the SinWt (stage 3)
+  st[5].input2 = 5;  // the audio input (stage 4)
+  const double depth[N] = {100.0, 250.0}, f0[N] = {440.0, 660.0};
+  GpuVoiceBank<float, 1> bank(st, N, {{1.0, 1.0}, {depth[0], depth[1]}, {f0[0], f0[1]}, {0.0, 0.0}, {0.0, 0.0}, {}}, 0, 1);
+  bank.init(48000, B);
+  CHECK(bank.init_error().empty());
+  if (!bank.init_error().empty()) { std::printf("  %s\n", bank.init_error().c_str()); return; }
+  AudioCtx ctx;
+  UGenFlags flags;
+  std::vector<float> mod(B), in0(B), out(2 * B);
+  bank.set_ar_param_buffer(ctx, 0, mod.data());  // task.rs:113-120: once, when the schedule is taken
+  const auto& table = kno::sine_wavetable_f32();
+  const double f2pi = 16384.0 * 65536.0 * (1.0 / 48000.0);
+  uint32_t phase[N] = {0, 0};
+  for (int blk = 0; blk < 4; ++blk) {
+    for (int i = 0; i < B; ++i) {  // the modulator node and the input node rendered this block
+      mod[i] = std::sin(0.05f * float(blk * B + i));
+      in0[i] = 0.5f + 0.001f * float(i);
+    }
+    const float* inputs[1] = {in0.data()};
+    CHECK(bank.process_block(ctx, flags, inputs, out.data()) == KNH_OK);
+    ctx.frame_clock += B;
+    for (int i = 0; i < B; ++i) {
+      float v[N];
+      for (int k = 0; k < N; ++k) {
+        const float freq = mod[i] * float(depth[k]) + float(f0[k]);
+        const uint32_t inc = kno::sat_u32(double(freq) * f2pi);  // WrArParams::process -> SinWt::freq, audio_rate.rs:42-57, osc.rs:127-130
+        const float s = table[(phase[k] >> 16) & 16383];
+        phase[k] += inc;
+        v[k] = s * in0[i];
+      }
+      const float want = v[0] + v[1];
+      CHECK(out[i] == want && out[B + i] == want);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int bench(const char* name, int blocks) {
+  const bool c1 = !std::strcmp(name, "C1");
+  const int N = c1 ? 1 : 16384, B = c1 ? 64 : 512, UGENS = c1 ? 3 : 4;
+  std::vector<knh_stage_desc> chain = c1 ? std::vector<knh_stage_desc>{stage(KNH_STAGE_SIN_WT), stage(KNH_STAGE_MUL_CONST)} : c3_chain();
+  std::vector<std::vector<double>> ctor = c1 ? std::vector<std::vector<double>>{{440.0}, {0.2}} : c3_ctor(N);
+  GpuVoiceBank<float> bank(chain, N, ctor);
+  bank.init(48000, B);
+  if (!bank.init_error().empty()) { std::fprintf(stderr, "%s\n", bank.init_error().c_str()); return 2; }
+  AudioCtx ctx;
+  ctx.block_size = ctx.frames_to_process = B;
+  UGenFlags flags;
+  std::vector<float> out(2 * B);
+  std::vector<size_t> i_restart, i_release;
+  if (!c1) for (int v = 0; v < N; ++v) { i_restart.push_back(bank.index(v, 3, "t_restart")); i_release.push_back(bank.index(v, 3, "t_release")); }
+  std::vector<double> us;
+  us.reserve(blocks);
+  double peak = 0;
+  auto run = [&](int n, bool timed) {
+    for (int blk = 0; blk < n; ++blk) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (!c1 && blk % 64 == 0) for (size_t i : i_restart) bank.param_apply(ctx, i, Value::Trigger);   // one SchedulingEvent per voice
+      if (!c1 && blk % 64 == 32) for (size_t i : i_release) bank.param_apply(ctx, i, Value::Trigger);
+      bank.process_block(ctx, flags, nullptr, out.data());
+      ctx.frame_clock += B;
+      const auto t1 = std::chrono::steady_clock::now();
+      if (timed) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+      for (float x : out) peak = std::max(peak, double(std::fabs(x)));
+    }
+  };
+  run(128, false);  // warm-up: clocks, first-use allocations
+  knh_bank_timing_reset(bank.raw(), 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  run(blocks, true);
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  double kms = 0;
+  uint64_t launches = 0;
+  knh_bank_timing_read(bank.raw(), &kms, &launches);
+  std::sort(us.begin(), us.end());
+  const double rate = double(N) * B * UGENS * blocks / secs;
+  std::printf("{\"config\": \"%s\", \"driver\": \"C++ twin of the Rust shim: one knh_bank_process_block per block, single-call param_apply per event\", "
+              "\"voices\": %d, \"block_size\": %d, \"blocks\": %d, \"ugen_samples_per_s\": %.6g, \"us_per_block_mean\": %.3f, \"us_per_block_p50\": %.3f, "
+              "\"us_per_block_p99\": %.3f, \"us_per_block_min\": %.3f, \"voice_kernel_us_per_block\": %.3f, \"output_peak\": %.4g}\n",
+              name, N, B, blocks, rate, secs * 1e6 / blocks, us[us.size() / 2], us[size_t(us.size() * 0.99)], us.front(),
+              launches ? kms * 1e3 / double(launches) : 0.0, peak);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  bool cpu = false, gpu = false;
+  for (int i = 1; i < argc; ++i) {
+    cpu = cpu || !std::strcmp(argv[i], "--cpu");
+    gpu = gpu || !std::strcmp(argv[i], "--gpu");
+    if (!std::strcmp(argv[i], "--bench")) {
+      if (knh_device_count() < 1) { std::printf("no gfx950 device\n"); return 2; }
+      return bench(i + 1 < argc ? argv[i + 1] : "C3", i + 2 < argc ? std::atoi(argv[i + 2]) : 1024);
+    }
+  }
+  if (!cpu && !gpu) cpu = true;
+  if (cpu) RUN(cpu_no_exception_crosses_the_abi);
+  if (gpu) {
+    if (knh_device_count() < 1) { std::printf("no gfx950 device\n"); return 2; }
+    RUN(gpu_readme_example_block_by_block);
+    RUN(gpu_c3_block_by_block_equals_one_launch);
+    RUN(gpu_partial_blocks);
+    RUN(gpu_inputs_and_audio_rate_buffer);
+  }
+  std::printf("%s (%d failures)\n", g_fail ? "SHIM TWIN FAILED" : "SHIM TWIN PASSED", g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -120,3 +120,38 @@ def test_input_rules(knh):
     with pytest.raises(L.KnasterHipError):  # two blocks set, one processed
         b.process_block()
     b.close()
+
+
+@pytest.mark.parametrize("kind", ["plain", "rank"])
+def test_inputs_through_asynchronous_launches(knh, kind):
+    """Two launches in flight (knh_bank_process_blocks_begin / _end), each with its own input blocks handed over right behind
+    the other: the staging buffer of a launch's input must not be rewritten while that launch's upload is still queued on
+    the stream it was given (an event, not the bank's own stream, says when).  Same samples as blocking calls; also for a
+    rank bank (whose launches run on a stream of its own)."""
+    n, bs, k = 130, 64, 16
+    p = configs.voice_parameters(n)
+    st = [Stage(L.STAGE_INPUT), Stage(L.STAGE_SVF), Stage(L.STAGE_MUL_CONST)]
+    w = configs.Workload("in_async", st, n, bs, L.F32, 2, in_channels=1)
+    w.ctor = {0: np.zeros((n, 1)), 1: np.stack([np.full(n, 2.0), p["cutoff"], p["q"], np.zeros(n)], axis=1), 2: np.full((n, 1), 1.0 / n)}
+    kw = dict(rank=0, world=1) if kind == "rank" else {}
+    a = make_gpu(knh, w, L.MIX_TREE, **kw)
+    b = make_gpu(knh, w, L.MIX_TREE, **kw)
+    rng = np.random.default_rng(11)
+    ins = [input_blocks(rng, k, 1, bs, np.float32) * (1.0 + i) for i in range(6)]
+    want = []
+    for x in ins:  # blocking calls
+        b.set_input(x)
+        want.append(b.process_blocks(k)[0])
+    got = []
+    a.set_input(ins[0])
+    a.process_blocks_begin(k)
+    for i in range(len(ins)):
+        if i + 1 < len(ins):
+            a.set_input(ins[i + 1])  # while launch i may still be waiting for its upload
+            a.process_blocks_begin(k)
+        got.append(a.process_blocks_end())
+    for i in range(len(ins)):
+        assert_bit_equal(got[i], want[i], f"launch {i}")
+    assert np.abs(want[-1]).max() > 1e-5
+    a.close()
+    b.close()

@@ -221,6 +221,37 @@ def test_precise_timing_semantics(knh, oracle):
     run_pair(knh, oracle, w, 10, ev)
 
 
+def test_precise_timing_on_a_stage_beyond_index_255(knh, oracle):
+    """A WrPreciseTiming-wrapped node far down a long voice (stage index 258): the host's compact record of a delayed call
+    carries the stage index in 16 bits (an 8-bit field once sent such a change to stage 258 & 0xFF = 2).  Single calls and
+    batched ones, against the oracle."""
+    n, n_pad = 96, 256
+    p = configs.voice_parameters(n)
+    st = [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL)] + [Stage(L.STAGE_ADD_CONST) for _ in range(n_pad)] + \
+         [Stage(L.STAGE_SVF, delayed_changes_per_block=4), Stage(L.STAGE_MUL_CONST, delayed_changes_per_block=2)]
+    svf, gain = 2 + n_pad, 3 + n_pad
+    assert svf == 258
+    w = configs.Workload("deep", st, n, 64, L.F32, 1)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.5), svf: np.stack([np.zeros(n), p["cutoff"], p["q"], np.zeros(n)], axis=1),
+              gain: np.full((n, 1), 1.0 / n)}
+    for k in range(n_pad):
+        w.ctor[2 + k] = np.full((n, 1), 0.0 if k % 2 else 1e-3 * (k % 5))
+    rng = np.random.default_rng(258)
+
+    def ev(block, bank):
+        if block % 2 == 0:  # single calls: arm, then the value
+            for voice in rng_voices[block]:
+                bank.set_delay_within_block_for_param(int(voice), svf, 0, int(5 + voice % 50))
+                bank.param_apply(int(voice), svf, 0, float(300.0 + 10.0 * voice + 100.0 * block))
+                bank.set_delay_within_block_for_param(int(voice), gain, 0, int(9 + voice % 40))
+                bank.param_apply(int(voice), gain, 0, float(0.5 / n + 1e-4 * block))
+        else:  # the batched entry point: every voice, delays from 1 to 63
+            v = np.arange(n, dtype=np.uint32)
+            bank.param_apply_many(v, svf, 1, L.VALUE_FLOAT, 0.6 + 0.01 * v + 0.1 * block, None, (1 + (7 * v) % 63).astype(np.uint16))
+    rng_voices = {b: rng.choice(n, size=20, replace=False) for b in range(0, 6, 2)}
+    run_pair(knh, oracle, w, 6, ev)
+
+
 def test_fma_variant_within_tolerance(knh, oracle):
     w = configs.config("C3", n_voices=256, block_size=512)
     run_pair(knh, oracle, w, 4, c3_events(w), allow_fma=True, voice_tol=1e-5 / 256 * 8)
