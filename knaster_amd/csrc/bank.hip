@@ -341,6 +341,7 @@ struct Bank final : knh_bank {
   typedef typename knh_dev::WordOf<F>::type W;
   const knh::KernelEntry* entry = nullptr;
   const knh::PipeEntry* pipe = nullptr;  // wave-specialised variant, used when built for this chain
+  bool pipe_pair = false;                // ... in its two-groups-per-workgroup form (banks of more groups than CUs)
   const knh::DagEntry* dag = nullptr;    // five-role variant (f32, source -> SVF -> x*env -> post chains)
   const knh::WideEntry* wide = nullptr;  // 4/8 voice groups per workgroup, for banks larger than the chip's SIMD count
   int wide_waves = 0;                    // 0 = not used, else 4 or 8
@@ -575,7 +576,7 @@ struct Bank final : knh_bank {
     // single-wave form.
     // The 64-sample-tile pipeline only where the block is made of whole tiles: a partial tile runs sample by sample,
     // and a 32- or 96-frame block would be half partial tiles (its 32-sample form has none).
-    if (pipe && pipe->form != 0 && bs % (sizeof(F) == 4 ? 64u : 32u) != 0) pipe = knh::find_pipe(signature.c_str(), 1u);
+    if (pipe && !pipe_pair && pipe->form != 0 && bs % (sizeof(F) == 4 ? 64u : 32u) != 0) pipe = knh::find_pipe(signature.c_str(), 1u);
     const unsigned n_groups = (nv + 63u) / 64u;
     {  // Voices made of SinWt oscillators and arithmetic alone (graphs, or chains without a pre-built kernel) are not run a
        // lane per voice at all: every stage is a pure function of the frame index, so a lane per FRAME it is (voice_frame.hpp)
@@ -2058,7 +2059,20 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
     // Occupancy regime: the wave pipeline minimises latency when every 64-voice group can have a CU to
     // itself (<= ~1.5 groups per CU); beyond that throughput wins and the groups are packed 4 or 8 to a
     // workgroup (one or two wavefronts per SIMD) sharing one staged sine table.  KNH_WIDE=0/4/8 overrides.
-    b->wide = b->entry ? knh::find_wide(sig.c_str()) : nullptr;
+    // Banks of more 64-voice groups than the chip has CUs: two groups per workgroup, each with its own pipeline, sharing the
+    // staged sine table -- two wavefronts per SIMD (voice_pipe.hpp, GPW).  One round of it renders 512 groups; KNH_PAIR=0
+    // keeps the forms of round 2 (A/B runs), KNH_PAIR=1 uses it for every bank it is built for.
+    {
+      const unsigned groups = (d.n_voices + 63u) / 64u;
+      const char* penv = std::getenv("KNH_PAIR");
+      const knh::PipeEntry* pair = b->entry && level >= 1 ? knh::find_pipe(sig.c_str(), 1u << 2 /* PIPE_INPLACE */, 2) : nullptr;
+      // Measured (us per 512-frame block; C3 f32 at 384 / 512 / 1 024 / 2 048 groups: 19.8 / 20.3 / 38.8 / 76.1 against 26.3 / 26.7 /
+      // 41.1 / 60.2 for the forms of round 2; C4 f64 at 512 / 1 024: 42.9 / 83.7 against 48.8 / 57.2 -- an f64 wavefront alone
+      // already keeps its SIMD's f64 pipe busy, so a second one beside it gains little): f32 up to 1 024 groups, f64 up to 512.
+      const bool want = penv ? penv[0] == '1' : (groups > 256u && groups <= (d.sample_type == KNH_F64 ? 512u : 1024u));
+      if (pair && want && !(penv && penv[0] == '0')) { b->pipe = pair; b->pipe_pair = true; }
+    }
+    b->wide = b->entry && !b->pipe_pair ? knh::find_wide(sig.c_str()) : nullptr;
     if (b->wide) {
       const unsigned groups = (d.n_voices + 63u) / 64u;
       // The pipeline takes ceil(groups / 256 CUs) rounds of its one-group-per-CU time, the 4-group kernel one round of the

@@ -36,11 +36,12 @@ struct PipeEntry {
   const char* signature;
   int n_groups;
   int form;  // knh_dev::PIPE_MIXER (32-sample tiles, f64: 16), PIPE_FOLD or PIPE_INPLACE (64-sample tiles, f64: 32): voice_pipe.hpp
+  int gpw;   // 64-voice groups per workgroup: 1, or 2 (PIPE_INPLACE with the short tiles; for banks of more groups than CUs)
   VoiceLaunchFn<float> f32[2];
   VoiceLaunchFn<double> f64[2];
 };
 // the first entry for the chain whose form is in `forms` (bit i = form i)
-const PipeEntry* find_pipe(const char* signature, unsigned forms = 7u);
+const PipeEntry* find_pipe(const char* signature, unsigned forms = 7u, int groups_per_workgroup = 1);
 // Five-role (dependence-cut) pipeline for source -> SVF -> x*envelope -> post chains, f32 banks (voice_dag.hpp).
 struct DagEntry {
   const char* signature;

@@ -937,10 +937,54 @@ struct Svf : StageDefaults {
     (void)first_prev;
     r.ic1 = ic.x; r.ic2 = ic.y;
   }
+  // f64, exact arithmetic: the same fifteen roundings per sample as tick(), in an order fixed by hand.  An f64 instruction
+  // occupies the SIMD for four cycles (half the f32 rate), so a wavefront alone on its SIMD could run the step in 15 x 4 = 60
+  // cycles -- unless an instruction reads the result of the one before it, which holds the issue for about twice that.  The
+  // compiler's own schedule has four such pairs per sample (q1 -> v1, p2 -> t, q2 -> v2, o2 -> out: 111 cycles per sample
+  // measured, profiles/r02).  Here the four output instructions of sample j - 1 are woven into the recurrence of sample j,
+  // and every instruction reads results that are at least three instructions old:
+  //    1 v3 = x - ic2      2 p1 = a1 ic1     3 p2 = a2 ic1     4 o1 = m1 v1'      5 q1 = a2 v3
+  //    6 q2 = a3 v3        7 t = ic2 + p2    8 o2 = m2 v2'     9 v1 = p1 + q1    10 v2 = t + q2
+  //   11 s = o0' + o1     12 ic1 = 2 v1 - ic1   13 ic2 = 2 v2 - ic2   14 out' = s + o2   15 o0 = m0 x      (' = of the sample before)
+  // Plain C++, one operation per statement, with a scheduling barrier behind each: the compiler keeps this order (and, unlike
+  // with inline asm, knows what the instructions are: it pads nothing).
+  template <int T>
+  static __device__ __forceinline__ void tick_tile_f64(Regs<double>& r, double (&x)[T]) {
+    double ic1 = r.ic1, ic2 = r.ic2;
+    const double a1 = r.a1, a2 = r.a2, a3 = r.a3, m0 = r.m0, m1 = r.m1, m2 = r.m2;
+    double v1p = 0.0, v2p = 0.0, o0p = 0.0;
+#define KNH_STEP(stmt) stmt; __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      double o1 = 0.0, o2 = 0.0, s = 0.0;
+      KNH_STEP(const double v3 = x[j] - ic2);
+      KNH_STEP(const double p1 = a1 * ic1);
+      KNH_STEP(const double p2 = a2 * ic1);
+      if (j > 0) { KNH_STEP(o1 = m1 * v1p); }
+      KNH_STEP(const double q1 = a2 * v3);
+      KNH_STEP(const double q2 = a3 * v3);
+      KNH_STEP(const double t = ic2 + p2);
+      if (j > 0) { KNH_STEP(o2 = m2 * v2p); }
+      KNH_STEP(const double v1 = p1 + q1);
+      KNH_STEP(const double v2 = t + q2);
+      if (j > 0) { KNH_STEP(s = o0p + o1); }
+      // 2*v is exact, so one FMA gives the reference's two roundings' result bit for bit (see tick())
+      KNH_STEP(ic1 = __builtin_fma(2.0, v1, -ic1));
+      KNH_STEP(ic2 = __builtin_fma(2.0, v2, -ic2));
+      KNH_STEP(const double o0 = m0 * x[j]);
+      if (j > 0) { KNH_STEP(x[j - 1] = s + o2); }
+      v1p = v1; v2p = v2; o0p = o0;
+    }
+    x[T - 1] = (o0p + m1 * v1p) + m2 * v2p;  // the last sample's output
+#undef KNH_STEP
+    r.ic1 = ic1; r.ic2 = ic2;
+  }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
     if constexpr (sizeof(F) == 4 && !FMA) {
       tick_tile_packed<T>(r, x);
+    } else if constexpr (sizeof(F) == 8 && !FMA) {
+      tick_tile_f64<T>(r, x);
     } else {
 #pragma unroll
       for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);

@@ -390,7 +390,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
     __syncthreads();
   }
 #ifdef KNH_DAG_STAMPS
-  if (blockIdx.x == 0 && lane == 0) {
+  if (wave_global == 0u && lane == 0) {
     const u64 d = (u64)(n_tiles > 0 ? n_tiles : 1);
     a.flags[4 + I] = (u32)(busy / d);
     if (8 + 2 * I + 1 < 16) { a.flags[8 + 2 * I] = (u32)(busy_in / d); a.flags[9 + 2 * I] = (u32)(busy_out / d); }
@@ -473,7 +473,7 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
     __syncthreads();
   }
 #ifdef KNH_DAG_STAMPS
-  if (blockIdx.x == 0 && lane == 0) a.flags[4 + NG] = (u32)(busy / (u64)(n_tiles > 0 ? n_tiles : 1));
+  if (wave_global == 0u && lane == 0) a.flags[4 + NG] = (u32)(busy / (u64)(n_tiles > 0 ? n_tiles : 1));
 #endif
 }
 
@@ -499,20 +499,29 @@ template <int I, typename G, typename... Rest> struct LastEnv<I, G, Rest...> {
   static constexpr int value = later >= 0 ? later : (GroupInfo<G>::has_env ? I : -1);
 };
 
-// One workgroup = 64 voices = one wavefront per stage group (K for a Fan group) + the mixer, or without it with PIPE_FOLD.
-template <typename F, bool FMA, int T, int MODE, typename... Gs>
-__global__ void __launch_bounds__((PipeWaves<T, MODE, Gs...>::value * 64)) voice_pipe_kernel(VoiceKernelArgs<F> a) {
+// One workgroup = GPW x 64 voices; per 64-voice group one wavefront per stage group (K for a Fan group) + the mixer, or
+// without it with PIPE_FOLD.
+// GPW = 2 (banks of more voice groups than the chip has CUs): two 64-voice groups share the workgroup's one copy of the sine
+// table, each with its own pipeline of wavefronts and its own edge tiles (the short tiles: 64 + 2 x 46 KiB of the 160).  A
+// workgroup's wavefronts are dealt round the CU's four SIMDs, so wavefront k of the second group sits beside wavefront k of
+// the first: two wavefronts per SIMD, the regime in which a SIMD issues an instruction every two cycles instead of one
+// every four (MI355X_MICROARCH.md, Wave scheduling; tools/micro/valu_issue.hip: a second wave on a SIMD runs at the first
+// one's rate).  The per-voice arithmetic and the partial rows are those of the one-group form: same bits.
+template <typename F, bool FMA, int T, int MODE, int GPW, typename... Gs>
+__global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64)) voice_pipe_kernel(VoiceKernelArgs<F> a) {
   constexpr int NG = (int)sizeof...(Gs);
   constexpr int CHAINW = PipeWaves<T, MODE, Gs...>::chain;  // wavefronts that run stage groups
-  constexpr int WAVES = PipeWaves<T, MODE, Gs...>::value;
+  constexpr int WAVES = PipeWaves<T, MODE, Gs...>::value;   // wavefronts of ONE 64-voice group
+  static_assert(GPW == 1 || GPW == 2, "one or two voice groups per workgroup");
   static_assert(T <= 64 && T % 8 == 0, "a tile column per lane of the folding wavefront");
   constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
   __shared__ float sine[kSine ? 16384 : 1];
   // the last edge feeds the mixer; with PIPE_FOLD it is one buffer private to the last group, with PIPE_INPLACE there is none
   // (the edge before it has three buffers instead)
-  __shared__ __attribute__((aligned(16))) F edge[EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile];
+  constexpr long kEdgeElems = (long)EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile;  // per voice group
+  __shared__ __attribute__((aligned(16))) F edge[GPW * kEdgeElems];
   // what is left of the CU's 160 KiB holds the workgroup's events (16 bytes each), up to 2 048 of them
-  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 1) - (long)sizeof(F) * EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile;
+  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 1) - (long)sizeof(F) * GPW * kEdgeElems;
 #ifndef KNH_EVCAP_MAX
 #define KNH_EVCAP_MAX 2048
 #endif
@@ -520,21 +529,27 @@ __global__ void __launch_bounds__((PipeWaves<T, MODE, Gs...>::value * 64)) voice
   __shared__ __attribute__((aligned(16))) Event ev_stage[kEvCap > 0 ? kEvCap : 1];
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave_all = threadIdx.x >> 6;               // wavefront of the workgroup
+  const int grp = GPW > 1 ? wave_all / WAVES : 0;      // its voice group ...
+  // ... and its role in that group's pipeline.  Wavefronts k and k + 4 of a workgroup share a SIMD (they are dealt round the
+  // four SIMDs in turn), so the second group takes its roles rotated by half a turn: its filter wavefront sits beside the
+  // first group's mixer, not beside its filter -- two filter wavefronts on one SIMD would halve each other's packed
+  // instructions (tools/micro/valu_issue.hip: with two waves on a SIMD scalar ops keep their rate, packed f32 ops do not).
+  const int wave = GPW > 1 ? (wave_all + (grp ? WAVES / 2 : 0)) % WAVES : wave_all;
   u32 ev_first = 0, ev_count = 0;
-  if (kEvCap > 0 && a.ev_start) {
-    const u32 gv0 = blockIdx.x * 64u;
-    const u32 gnv = a.n_voices - gv0 < 64u ? a.n_voices - gv0 : 64u;
+  if (kEvCap > 0 && a.ev_start) {  // (the groups' voices are neighbours: one contiguous piece of the list, which is sorted by voice)
+    const u32 gv0 = blockIdx.x * (u32)(GPW * 64);
+    const u32 gnv = a.n_voices - gv0 < (u32)(GPW * 64) ? a.n_voices - gv0 : (u32)(GPW * 64);
     ev_first = a.ev_start[gv0];
     ev_count = a.ev_start[gv0 + gnv] - ev_first;
     if (ev_count > (u32)kEvCap) ev_count = 0u;  // does not fit: the groups read the list where it is
-    for (u32 i = threadIdx.x; i < ev_count; i += WAVES * 64) ev_stage[i] = a.events[ev_first + i];
+    for (u32 i = threadIdx.x; i < ev_count; i += GPW * WAVES * 64) ev_stage[i] = a.events[ev_first + i];
   }
   if (kSine) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 #pragma unroll 4
-    for (int k = wave; k < 64; k += WAVES) {
+    for (int k = wave_all; k < 64; k += GPW * WAVES) {
       const float* g = a.sine_table + (k * 64 + lane) * 4;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sine + k * 256), 16, 0, 0);
     }
@@ -543,25 +558,34 @@ __global__ void __launch_bounds__((PipeWaves<T, MODE, Gs...>::value * 64)) voice
   __syncthreads();
   PipeShared<F> sh;
   sh.sine = sine;
-  sh.edge = edge;
+  sh.edge = edge + (long)grp * kEdgeElems;
   sh.ev_lds = ev_stage;
   sh.ev_lds_first = ev_first;
   sh.ev_lds_n = ev_count;
-  const u32 wave_global = blockIdx.x;  // one 64-voice wavefront-group per workgroup
+  const u32 wave_global = blockIdx.x * (u32)GPW + (u32)grp;  // the 64-voice group of the bank
   const u32 v0 = wave_global * 64u;
-  const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;
+  const bool dead = GPW > 1 && v0 >= a.n_voices;  // the last workgroup of a bank with an odd number of voice groups
+  const u32 nv = dead ? 0u : (a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u);
   u32 done_frame = 0xFFFFFFFFu;
   constexpr bool kPan = (false || ... || GroupInfo<Gs>::pan);
-  if (wave == CHAINW) pipe_run_mixer<F, FMA, T, MODE, NG, kPan>(sh, a, lane, wave_global, v0, nv);
-  else done_frame = pipe_dispatch<F, FMA, T, MODE, NG, 0, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
+  if (dead) {
+    // no voices: this group only keeps the workgroup's barriers company, step for step
+    const u32 n_frames = a.frame_end - a.frame_begin;
+    const int n_steps = (int)((n_frames + T - 1) / T) * (int)a.n_blocks + NG - (MODE == PIPE_FOLD ? 1 : 0);
+    for (int s = 0; s < n_steps; ++s) __syncthreads();
+  } else if (wave == CHAINW) {
+    pipe_run_mixer<F, FMA, T, MODE, NG, kPan>(sh, a, lane, wave_global, v0, nv);
+  } else {
+    done_frame = pipe_dispatch<F, FMA, T, MODE, NG, 0, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
+  }
   // mark_done of a voice = that of the last node in task order that set one: combine the groups in chain order
   constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);
   if constexpr (kAnyEnv) {
-    u32* marks = reinterpret_cast<u32*>(edge);  // the tiles are dead: every wavefront is past its last barrier-separated read
+    u32* marks = reinterpret_cast<u32*>(edge) + (long)grp * (CHAINW * 64);  // the tiles are dead: every wavefront is past its last barrier-separated read
     __syncthreads();
     if (wave < CHAINW) marks[wave * 64 + lane] = done_frame;
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && !dead) {
       u32 d = 0xFFFFFFFFu;
 #pragma unroll
       for (int g = 0; g < CHAINW; ++g) d = marks[g * 64 + lane] != 0xFFFFFFFFu ? marks[g * 64 + lane] : d;

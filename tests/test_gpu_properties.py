@@ -102,6 +102,36 @@ def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_vo
             assert f0 == f1 and np.array_equal(d0, d1)
 
 
+@pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C3", 129, 96), ("C4", 300, 100), ("C4", 449, 64)])
+def test_two_voice_groups_per_workgroup_equal_the_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
+    """The pipeline with two 64-voice groups per workgroup (banks of more groups than the chip has CUs; KNH_PAIR=1 forces it
+    for a small bank): per-voice signals, mix, flags and done frames are those of the one-wavefront-per-group kernel -- with
+    an even and an odd number of groups (the last workgroup then holds one live group and one that only keeps the barriers
+    company), a ragged last group, blocks that are not whole tiles, single blocks and several blocks per launch."""
+    w = configs.config(name, n_voices=n_voices, block_size=block_size)
+    outs = {}
+    for form in ("single", "pair"):
+        monkeypatch.setenv("KNH_PIPELINE", "0" if form == "single" else "1")
+        monkeypatch.setenv("KNH_PAIR", "1" if form == "pair" else "0")
+        g = make_gpu(knh, w)
+        res = []
+        for block in range(6):
+            c3_script(w, block, g)
+            out, voices, flags = g.process_block_voices()
+            res.append((out, voices, flags, g.read_done_frames()))
+        for block in range(6, 12):
+            c3_script(w, block - 6, g, block - 6)
+        many, _ = g.process_blocks(6)
+        outs[form] = (res, many)
+        g.close()
+    for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["single"][0], outs["pair"][0]):
+        assert_bit_equal(v0, v1, "per-voice")
+        assert_bit_equal(o0, o1, "mix")
+        assert f0 == f1 and np.array_equal(d0, d1)
+    assert_bit_equal(outs["single"][1], outs["pair"][1], "six blocks in one launch")
+    assert np.abs(outs["pair"][1]).max() > 1e-6
+
+
 @pytest.mark.parametrize("pipeline", ["0", "1", "2"])
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 700, 512), ("C3", 130, 100), ("C5", 200, 128)])
 def test_many_blocks_per_launch_equals_block_by_block(knh, monkeypatch, pipeline, name, n_voices, block_size):

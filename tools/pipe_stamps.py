@@ -10,7 +10,7 @@ import knaster_amd
 from knaster_amd import _lib as L, configs
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
-w = configs.config(name)
+w = configs.config(name, n_voices=int(sys.argv[2]) if len(sys.argv) > 2 else None)
 b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, 2, L.MIX_TREE)
 for s, a in w.ctor.items():
     b.set_ctor_args(s, a)
