@@ -1,4 +1,4 @@
-//! Raw declarations of include/knaster_hip.h (ABI version 1).  One `pub fn` per exported symbol, same order as
+//! Raw declarations of include/knaster_hip.h (ABI version 3).  One `pub fn` per exported symbol, same order as
 //! the header; tests/test_abi.py fails when the two drift apart.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_void};
@@ -22,7 +22,8 @@ pub struct knh_stage_desc {
     pub kind: u16,
     pub flags: u16,
     pub delayed_changes_per_block: u16,
-    pub reserved: u16,
+    /// 1 + the float parameter that the signal `input2` drives at audio rate (`.ar_params()` + `link`), 0: none
+    pub ar_param: u16,
     /// 0: the stage reads the output of the stage before it; k > 0: the output of stage k - 1
     pub input: u16,
     /// second operand of the KNH_STAGE_MATH_* stages (same numbering), 0 elsewhere
@@ -44,7 +45,7 @@ pub struct knh_bank_desc {
     pub in_channels: u32,
 }
 
-pub const KNH_ABI_VERSION: u32 = 2;
+pub const KNH_ABI_VERSION: u32 = 3;
 
 // knh_status
 pub const KNH_OK: i32 = 0;

@@ -70,7 +70,7 @@ pub const MAX_PARAMS: usize = 6;
 pub type Stage = knh_stage_desc;
 
 pub fn stage(kind: u16) -> Stage {
-    Stage { kind, flags: 0, delayed_changes_per_block: 0, reserved: 0, input: 0, input2: 0 }
+    Stage { kind, flags: 0, delayed_changes_per_block: 0, ar_param: 0, input: 0, input2: 0 }
 }
 pub trait StageExt {
     /// `.precise_timing::<N>()` on the stage's node (wrappers_core.rs:106-111)
@@ -79,6 +79,9 @@ pub trait StageExt {
     fn ar_freq(self) -> Self;
     /// `.smooth_params()` (wrappers_core.rs:63-65)
     fn smooth_params(self) -> Self;
+    /// `.ar_params()` with the float parameter `param` linked to the output of stage `driver` of the same voice
+    /// (`node.link(param, signal)`, graph_edit.rs:735-754; audio_rate.rs:11-85): `knh_stage_desc.ar_param` / `.input2`
+    fn ar_param(self, param: u16, driver_stage: u16) -> Self;
 }
 impl StageExt for Stage {
     fn precise_timing(mut self, n: u16) -> Self {
@@ -91,6 +94,11 @@ impl StageExt for Stage {
     }
     fn smooth_params(mut self) -> Self {
         self.flags |= KNH_STAGE_FLAG_SMOOTH_PARAMS;
+        self
+    }
+    fn ar_param(mut self, param: u16, driver_stage: u16) -> Self {
+        self.ar_param = param + 1;
+        self.input2 = driver_stage + 1;
         self
     }
 }

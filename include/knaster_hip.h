@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KNH_ABI_VERSION 2
+#define KNH_ABI_VERSION 3
 
 typedef enum knh_status {
   KNH_OK = 0,
@@ -238,7 +238,19 @@ typedef struct knh_stage_desc {
    * takes effect (precise_timing.rs:14-149).  0: delays are ignored with a
    * warning, exactly like an unwrapped reference UGen (ugen.rs:339-341). */
   uint16_t delayed_changes_per_block;
-  uint16_t reserved;
+  /* Audio-rate parameter (WrArParams, knaster_core_dsp/src/wrappers_core/audio_rate.rs:11-85; graph_edit.rs:735-754 `link`):
+   * 0 = none; k > 0: the stage's parameterised node is pushed as `.ar_params()` and its FLOAT parameter k - 1 is linked to
+   * the signal `input2` names (required then): every sample the node's setter for that parameter runs with the driving
+   * signal's sample, then the node renders one sample (the wrapper forces frame-by-frame processing, as in the reference);
+   * an ordinary param_apply to that parameter is ignored while the link stands (audio_rate.rs:70-74).  Supported:
+   *     SIN_WT 0 freq, 1 phase_offset      SIN_NUMERIC 0 freq, 1 phase_offset      *_CONST / POW_CONST 0 value
+   *     WR_MUL 0 "wr_mul"                  MUL_ENV_ASR / MUL_ENV_AR 0 attack_time, 1 release_time      -- all bit-exact --
+   *     SVF 0 cutoff_freq, 1 q, 2 gain     ONEPOLE_LPF / _HPF 0 cutoff_freq      -- the setter's tan / pow / sqrt / exp run in
+   *     the device library: within a tolerance of the reference, not bit for bit.
+   * A voice with such a stage is a graph (explicit operands): it runs in the single-wave kernel form, fused at init.
+   * (KNH_STAGE_FLAG_AR_FREQ is the older spelling of "SIN_WT, ar_param = 1, driven by the running signal".)
+   * An envelope under the wrapper marks done at frame 0, as the reference's does (envelopes.rs:153-156). */
+  uint16_t ar_param;
   /* Which signal the stage reads.  0 (what a zero-initialised descriptor says): the output of the stage before it -- a
    * chain on one running signal.  k > 0: the output of stage k - 1 of this list (an earlier one), so that a signal can feed
    * several stages and stages need not follow their input directly.  Source stages read nothing (except SIN_WT with

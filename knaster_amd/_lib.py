@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libknaster_hip.so")
 
-KNH_ABI_VERSION = 2
+KNH_ABI_VERSION = 3
 
 # knh_status
 OK, ERR_INVALID_ARGUMENT, ERR_OUT_OF_RANGE, ERR_UNSUPPORTED_CHAIN, ERR_DEVICE = 0, 1, 2, 3, 4
@@ -48,7 +48,7 @@ STAGE_CTOR_ARGS = {  # STAGE_MUL_ENVELOPE takes 4 + 2 * n_max (variable)
 
 class StageDesc(C.Structure):
     _fields_ = [("kind", C.c_uint16), ("flags", C.c_uint16), ("delayed_changes_per_block", C.c_uint16),
-                ("reserved", C.c_uint16), ("input", C.c_uint16), ("input2", C.c_uint16)]
+                ("ar_param", C.c_uint16), ("input", C.c_uint16), ("input2", C.c_uint16)]
 
 
 class BankDesc(C.Structure):

@@ -23,7 +23,8 @@ class Stage:
     flags: int = 0
     delayed_changes_per_block: int = 0  # > 0: wrapped in WrPreciseTiming<N, _>
     input: int = 0   # 0: reads the stage before it; k > 0: reads the output of stage k - 1 (knh_stage_desc.input)
-    input2: int = 0  # second operand of the STAGE_MATH_* stages, same numbering
+    input2: int = 0  # second operand of the STAGE_MATH_* stages, or the driver of an audio-rate parameter; same numbering
+    ar_param: int = 0  # 1 + the float parameter that the signal `input2` drives at audio rate (.ar_params() + link), 0: none
 
 
 def _stage_array(stages: Sequence[Stage]):
@@ -34,6 +35,7 @@ def _stage_array(stages: Sequence[Stage]):
         arr[i].delayed_changes_per_block = s.delayed_changes_per_block
         arr[i].input = s.input
         arr[i].input2 = s.input2
+        arr[i].ar_param = s.ar_param
     return arr
 
 

@@ -91,7 +91,7 @@ inline bool is_wrapper_kind(uint16_t kind) {
 // arithmetic only, nothing wrapped in WrPreciseTiming or WrSmoothParams.
 bool interp_can_run(const knh_stage_desc* st, uint32_t n) {
   for (uint32_t i = 0; i < n; ++i) {
-    if (st[i].flags != 0 || st[i].delayed_changes_per_block != 0) return false;
+    if (st[i].flags != 0 || st[i].delayed_changes_per_block != 0 || st[i].ar_param != 0) return false;
     if (std::strchr("Wmasdvq*+-/", kKinds[st[i].kind].sig) == nullptr) return false;
   }
   return true;
@@ -233,7 +233,22 @@ struct StageInfo {
   int slot_base, n_slots, n_params, n_ctor;
   int param_base;  // index of this stage's first parameter in the flat per-voice parameter table
   uint16_t input = 0, input2 = 0;  // knh_stage_desc: the stage(s) whose output this one reads (0: the one before it)
+  uint16_t ar_param = 0;           // knh_stage_desc: 1 + the float parameter a second signal (input2) drives at audio rate, 0: none
 };
+
+// Which (stage kind, float parameter) pairs can be driven at audio rate (knh_stage_desc.ar_param): the setters restated on
+// the device (voice_chain.hpp, ar_set).
+inline bool ar_param_supported(uint16_t kind, uint32_t param) {
+  switch (kind) {
+    case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: return param <= 1;
+    case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: case KNH_STAGE_POW_CONST:
+    case KNH_STAGE_WR_MUL: return param == 0;
+    case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR: return param <= 1;
+    case KNH_STAGE_SVF: return param <= 2;
+    case KNH_STAGE_ONEPOLE_LPF: case KNH_STAGE_ONEPOLE_HPF: return param == 0;
+    default: return false;
+  }
+}
 
 struct HostEvent {
   uint32_t voice;
@@ -584,7 +599,7 @@ struct Bank final : knh_bank {
        // form that takes the reference's 1 531-stage cascade.  KNH_INTERP=0: never (the lane-per-voice form, A/B runs).
       const char* ie = std::getenv("KNH_INTERP");
       bool can = !entry && bs <= 1024 && stages.size() <= 4096;
-      for (const StageInfo& S : stages) can = can && S.flags == 0 && S.dcpb == 0 && std::strchr("Wmasdvq*+-/", kKinds[S.kind].sig) != nullptr;
+      for (const StageInfo& S : stages) can = can && S.flags == 0 && S.dcpb == 0 && S.ar_param == 0 && std::strchr("Wmasdvq*+-/", kKinds[S.kind].sig) != nullptr;
       if (can && !(ie && ie[0] == '0')) {
         h_prog.clear();
         size_t si = 0;
@@ -663,6 +678,8 @@ struct Bank final : knh_bank {
       for (int i = 0; i < n; ++i) {
         if (is_math2_kind(stages[i].kind)) { a[i] = node_output(stages[i].input - 1); b[i] = node_output(stages[i].input2 - 1); }
         else if (i > 0 && !is_src(i)) a[i] = stages[i].input ? node_output(stages[i].input - 1) : i - 1;
+        // an audio-rate parameter edge: followed after the node's input edges (graph.rs:1938-1980)
+        if (stages[i].ar_param && !is_math2_kind(stages[i].kind)) b[i] = node_output(stages[i].input2 - 1);
       }
       std::vector<int> order, state(n, 0), stack{n - 1};
       while (!stack.empty()) {  // post-order, first operand first
@@ -749,6 +766,10 @@ struct Bank final : knh_bank {
             slot(S.slot_base + 0, v) = fw(F(0));
             slot(S.slot_base + 1, v) = fw(F(0));
             for (int k = 0; k < 6; ++k) slot(S.slot_base + 2 + k, v) = fw(co[k]);
+            if (S.n_slots == 12) {  // a parameter driven at audio rate: the setter runs on the device and needs the other values
+              slot(S.slot_base + 8, v) = fw(sh.a[v]); slot(S.slot_base + 9, v) = fw(sh.b[v]); slot(S.slot_base + 10, v) = fw(sh.c[v]);
+              slot(S.slot_base + 11, v) = ty;
+            }
           } break;
           case KNH_STAGE_ONEPOLE_LPF:    // onepole.rs:118-129
           case KNH_STAGE_ONEPOLE_HPF: {  // onepole.rs:157-167 (b1 = 0 -> exp(0) = 1)
@@ -1255,6 +1276,8 @@ struct Bank final : knh_bank {
   void apply_now(uint32_t v, uint32_t stage, uint32_t param, double f, int64_t iv, uint32_t frame, std::vector<HostEvent>& out) {
     const StageInfo& S = stages[stage];
     Shadow& sh = shadow[stage];
+    // a parameter a signal drives at audio rate ignores ordinary changes while the link stands (audio_rate.rs:70-74)
+    if (S.ar_param != 0 && param + 1u == S.ar_param) return;
     note_frame(frame);
     auto set = [&](int rel, uint64_t bits) { out.push_back(HostEvent{v, frame, knh_dev::EV_SET, static_cast<uint32_t>(S.slot_base + rel), bits}); };
     const F sr_as_f32 = static_cast<F>(static_cast<float>(sample_rate));
@@ -1284,6 +1307,12 @@ struct Bank final : knh_bank {
         F co[6];
         svf_coeffs<F>(sh.ty[v], sh.a[v], sh.b[v], sh.c[v], sr_as_f32, co);
         for (int k = 0; k < 6; ++k) set(2 + k, to_bits(co[k]));
+        if (S.n_slots == 12) {  // the values the device-side setter reads (another parameter of this filter is driven at audio rate)
+          if (param == 0) set(8, to_bits(sh.a[v]));
+          else if (param == 1) set(9, to_bits(sh.b[v]));
+          else if (param == 2) set(10, to_bits(sh.c[v]));
+          else if (param == 3) set(11, sh.ty[v]);
+        }
       } break;
       case KNH_STAGE_ONEPOLE_LPF:
       case KNH_STAGE_ONEPOLE_HPF: {  // onepole.rs:135-139,172-176 -> :35-46
@@ -1724,6 +1753,7 @@ struct Bank final : knh_bank {
     a.frame_end = fe;
     a.sine_table = d_sine;
     a.f2pi = f2pi;
+    a.sample_rate = sample_rate;
     a.seg_table = d_seg_table;
     a.seg_max = seg_max;
     a.delay_ring = d_delay;
@@ -1957,7 +1987,8 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     // operands: `input` / `input2` name the stage whose output is read (1 + its index), 0 = the stage before this one
     if (st[i].input > i || st[i].input2 > i) { *why = "a stage reads the output of an earlier stage"; return KNH_ERR_INVALID_ARGUMENT; }
     if (math2 && (st[i].input == 0 || st[i].input2 == 0)) { *why = "a KNH_STAGE_MATH_* stage names both of its operands (input, input2)"; return KNH_ERR_INVALID_ARGUMENT; }
-    if (!math2 && st[i].input2 != 0) { *why = "input2 is the second operand of the KNH_STAGE_MATH_* stages only"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (!math2 && st[i].input2 != 0 && st[i].ar_param == 0) { *why = "input2 is the second operand of the KNH_STAGE_MATH_* stages and the driver of an audio-rate parameter (ar_param)"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (math2 && st[i].ar_param != 0) { *why = "a KNH_STAGE_MATH_* stage has no parameters"; return KNH_ERR_INVALID_ARGUMENT; }
     if (is_wrapper_kind(st[i].kind) && st[i].input != 0) { *why = "a wrapper stage wraps the stage before it (input = 0)"; return KNH_ERR_INVALID_ARGUMENT; }
     if (source && !ar && st[i].input != 0) { *why = "a source stage reads no signal"; return KNH_ERR_INVALID_ARGUMENT; }
     if ((!source || ar) && !have_x) { *why = "stage needs a preceding signal"; return KNH_ERR_INVALID_ARGUMENT; }
@@ -1969,6 +2000,14 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     if (st[i].kind == KNH_STAGE_MUL_ENVELOPE && sig->find('V') != std::string::npos) { *why = "at most one Envelope stage per chain"; return KNH_ERR_INVALID_ARGUMENT; }
     if (st[i].kind == KNH_STAGE_PAN2 && i + 1 != n) { *why = "Pan2 ends the chain: it must be the last stage"; return KNH_ERR_INVALID_ARGUMENT; }
     if (st[i].kind == KNH_STAGE_PAN2 && st[i].delayed_changes_per_block > 0) { *why = "Pan2 cannot be wrapped in WrPreciseTiming here (its gains change at block boundaries)"; return KNH_ERR_INVALID_ARGUMENT; }
+    if (st[i].ar_param != 0) {  // an audio-rate parameter: the node's float parameter ar_param - 1 is driven by the signal input2 names
+      const uint32_t p = st[i].ar_param - 1u;
+      if (p >= static_cast<uint32_t>(kKinds[st[i].kind].n_params) || expected_value_kind(st[i].kind, p) != KNH_VALUE_FLOAT) { *why = "ar_param names a float parameter of the stage (1 + its index)"; return KNH_ERR_INVALID_ARGUMENT; }
+      if (!ar_param_supported(st[i].kind, p)) { *why = "this parameter cannot be driven at audio rate here (knh_stage_desc.ar_param lists what can)"; return KNH_ERR_UNSUPPORTED_CHAIN; }
+      if (st[i].input2 == 0) { *why = "an audio-rate parameter names the signal that drives it (input2)"; return KNH_ERR_INVALID_ARGUMENT; }
+      if (st[i].flags & (KNH_STAGE_FLAG_AR_FREQ | KNH_STAGE_FLAG_SMOOTH_PARAMS)) { *why = "ar_param cannot be combined with AR_FREQ or SMOOTH_PARAMS on one stage"; return KNH_ERR_INVALID_ARGUMENT; }
+      if (kKinds[st[i].kind].sig == 'I' || st[st[i].input2 - 1].kind == KNH_STAGE_INPUT) { *why = "an audio-rate parameter edge starts at a node, not at a bank input (put the input through `* 1.0`)"; return KNH_ERR_INVALID_ARGUMENT; }
+    }
     sig->push_back(ar ? 'R' : kKinds[st[i].kind].sig);
     have_x = true;
   }
@@ -1982,7 +2021,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
     for (uint32_t i = 0; i < n; ++i) {
       const bool ar = st[i].kind == KNH_STAGE_SIN_WT && (st[i].flags & KNH_STAGE_FLAG_AR_FREQ);
       sources += std::strchr("WNPUKOGBFI", kKinds[st[i].kind].sig) != nullptr && !ar;
-      dag = dag || is_math2_kind(st[i].kind) || (st[i].input != 0 && st[i].input != i);
+      dag = dag || is_math2_kind(st[i].kind) || (st[i].input != 0 && st[i].input != i) || st[i].ar_param != 0;
     }
     dag = dag || sources > 1;
   }
@@ -2005,6 +2044,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
       const bool reads = i > 0 && !(std::strchr("WNPUKOGBFI", (*sig)[i]) != nullptr);  // 'R' reads, the plain sources do not
       if (is_math2_kind(st[i].kind)) { a[i] = node_output(st[i].input - 1); b[i] = node_output(st[i].input2 - 1); }
       else if (reads) a[i] = st[i].input ? node_output(st[i].input - 1) : static_cast<int>(i) - 1;
+      if (st[i].ar_param != 0) b[i] = node_output(st[i].input2 - 1);  // the signal that drives the parameter
       if (a[i] >= 0) last_use[a[i]] = static_cast<int>(i);
       if (b[i] >= 0) last_use[b[i]] = static_cast<int>(i);
     }
@@ -2025,6 +2065,7 @@ int build_signature(const knh_stage_desc* st, uint32_t n, std::string* sig, std:
       if (last_use[i] >= 0) busy[o] = 1;  // (a signal nobody reads holds its slot only while it is written)
       slot[i] = o;
       out.push_back((*sig)[i]);
+      if (st[i].ar_param != 0) out += "%" + std::to_string(st[i].ar_param - 1);  // "%P": parameter P at audio rate (knh_dev::ArP)
       auto num = [](int v) { return v < 0 ? std::string("_") : std::to_string(v); };  // "_": none
       out += "@" + num(sa) + "," + num(sb) + "," + num(o);
     }
@@ -2095,10 +2136,12 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
   for (uint32_t i = 0; i < d.n_stages; ++i) {
     const KindInfo& k = kKinds[d.stages[i].kind];
     StageInfo s{d.stages[i].kind, d.stages[i].flags, d.stages[i].delayed_changes_per_block, slot, k.n_slots, k.n_params, k.n_ctor, pbase,
-                d.stages[i].input, d.stages[i].input2};
+                d.stages[i].input, d.stages[i].input2, d.stages[i].ar_param};
+    // an SvfFilter with a parameter at audio rate keeps cutoff, q, gain and type on the device too (knh_dev::SvfP)
+    if (s.kind == KNH_STAGE_SVF && s.ar_param != 0) s.n_slots = 12;
     b->stages.push_back(s);
     b->ctor.emplace_back(static_cast<size_t>(d.n_voices) * (k.n_ctor > 0 ? k.n_ctor : 0), 0.0);
-    slot += k.n_slots;
+    slot += s.n_slots;
     pbase += k.n_params;
   }
   b->n_slots = slot;

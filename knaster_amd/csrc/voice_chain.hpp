@@ -21,6 +21,12 @@ extern "C" __device__ float __ocml_cos_f32(float);
 extern "C" __device__ double __ocml_cos_f64(double);
 extern "C" __device__ float __ocml_pow_f32(float, float);
 extern "C" __device__ double __ocml_pow_f64(double, double);
+extern "C" __device__ float __ocml_tan_f32(float);
+extern "C" __device__ double __ocml_tan_f64(double);
+extern "C" __device__ float __ocml_exp_f32(float);
+extern "C" __device__ double __ocml_exp_f64(double);
+extern "C" __device__ float __ocml_sqrt_f32(float);
+extern "C" __device__ double __ocml_sqrt_f64(double);
 
 namespace knh_dev {
 
@@ -65,6 +71,16 @@ struct StageDefaults {
   static constexpr u32 kParamMask = 0u;
   template <typename R> static __device__ __forceinline__ void take_params(R&, const R&, bool) {}
   static constexpr bool kBinary = false;  // a MathUGen of two signals (Math2): no tick, an apply(a, b)
+  // >= 0: the node is pushed as `.ar_params()` and this float parameter is linked to a second signal of the voice
+  // (WrArParams, audio_rate.rs:11-85: every sample `param_apply(p, buf[i])`, then one sample of the node): ArP<S, P> below
+  static constexpr int kArParam = -1;
+};
+// A stage whose parameter P is driven at audio rate by another signal of the voice (graph-shaped voices: DagChain reads the
+// driver through the stage's second operand and calls S::ar_set<F, P> in front of every sample).  What the setter of each
+// parameter does per sample is restated in the stage (ar_set); the parameters that are + - x / only are bit-exact, the
+// SvfFilter's and the one-pole filters' cutoff go through the device's tan / pow / sqrt / exp (tolerance).
+template <typename S, int P> struct ArP : S {
+  static constexpr int kArParam = P;
 };
 
 // Event opcodes (host -> device state patches, applied at an in-block frame).
@@ -89,6 +105,7 @@ struct Ctx {
   u32 buffer_frames;
   const void* input_block;  // the bank node's input channels for the block being processed: [in_channels][in_stride] of F
   u32 in_stride;            // = block_size
+  u32 sample_rate;          // ctx.sample_rate(), for setters that run on the device (audio-rate parameters)
 };
 
 // ---------------------------------------------------------------------------
@@ -120,6 +137,12 @@ struct SinWtT : StageDefaults {
   static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long stride) {
     s[0] = (W)r.phase;
     if (AR_FREQ) s[2 * stride] = (W)r.inc;
+  }
+  // SinWt::freq (osc.rs:127-130) / ::phase_offset (:133-135) applied to one sample of the driving signal
+  template <typename F, int P>
+  static __device__ __forceinline__ void ar_set(Regs<F>& r, F v, const Ctx& c) {
+    if (P == 0) r.inc = sat_u32((double)v * c.f2pi);
+    else r.off = sat_u32((double)v * 65536.0);
   }
   template <typename F, bool FMA>
   static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx& c, u32, u32&) {
@@ -742,6 +765,12 @@ struct SinNum : StageDefaults {
   static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = f_to_word(r.phase); }
   static __device__ __forceinline__ float sin_f(float v) { return __ocml_sin_f32(v); }
   static __device__ __forceinline__ double sin_f(double v) { return __ocml_sin_f64(v); }
+  // SinNumeric::freq (osc.rs:240-242: F::new(freq) / F::new(sample_rate as f32)) / ::phase_offset (:244-247)
+  template <typename F, int P>
+  static __device__ __forceinline__ void ar_set(Regs<F>& r, F v, const Ctx& c) {
+    if (P == 0) r.inc = v / (F)(float)c.sample_rate;
+    else r.off = v;
+  }
   template <typename F, bool FMA>
   static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
     const F TAU = (F)6.28318530717958647692;
@@ -1001,6 +1030,78 @@ struct Svf : StageDefaults {
   }
 };
 
+static __device__ __forceinline__ float dev_pow(float a, float b) { return __ocml_pow_f32(a, b); }
+static __device__ __forceinline__ double dev_pow(double a, double b) { return __ocml_pow_f64(a, b); }
+// SvfFilter with a parameter driven at audio rate (ArP<SvfP, P>: P = 0 cutoff_freq, 1 q, 2 gain): every sample runs the
+// setter, which recomputes the coefficients from cutoff, q, gain and the type (svf.rs:81-133 -> set_coeffs :146-242).  The
+// three values and the type are therefore device state too (slots 8..11); tan / pow / sqrt are the device library's, so a
+// voice with such a filter is compared with the reference within a tolerance, not bit for bit.
+// slots: 0..7 as Svf, 8 cutoff, 9 q, 10 gain_db, 11 type
+struct SvfP : Svf {
+  static constexpr int kSlots = 12;
+  static constexpr u32 kParamMask = 0u;  // (graph-shaped voices only: no mid-tile parameter switching there)
+  template <typename F> struct Regs : Svf::Regs<F> { F cutoff, q, gain; u32 ty; };
+  template <typename F, typename W>
+  static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
+    Svf::load<F, W>(r, s, st);
+    r.cutoff = word_to_f<F>(s[8 * st]); r.q = word_to_f<F>(s[9 * st]); r.gain = word_to_f<F>(s[10 * st]); r.ty = (u32)s[11 * st];
+  }
+  template <typename F, typename W>
+  static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
+    Svf::store<F, W>(r, s, st);
+    // the coefficients and the three values moved with the driving signal: what the next launch starts from
+    s[2 * st] = f_to_word(r.a1); s[3 * st] = f_to_word(r.a2); s[4 * st] = f_to_word(r.a3);
+    s[5 * st] = f_to_word(r.m0); s[6 * st] = f_to_word(r.m1); s[7 * st] = f_to_word(r.m2);
+    s[8 * st] = f_to_word(r.cutoff); s[9 * st] = f_to_word(r.q); s[10 * st] = f_to_word(r.gain);
+  }
+  static __device__ __forceinline__ float tan_f(float v) { return __ocml_tan_f32(v); }
+  static __device__ __forceinline__ double tan_f(double v) { return __ocml_tan_f64(v); }
+  static __device__ __forceinline__ float sqrt_f(float v) { return __ocml_sqrt_f32(v); }
+  static __device__ __forceinline__ double sqrt_f(double v) { return __ocml_sqrt_f64(v); }
+  template <typename F>
+  static __device__ __forceinline__ void set_coeffs(Regs<F>& r, const Ctx& c) {  // svf.rs:146-242, as bank.hip's svf_coeffs
+    const F one = (F)1, sr = (F)(float)c.sample_rate;  // F::new(sample_rate as f32)
+    F g = tan_f(((F)3.14159265358979323846 * r.cutoff) / sr);
+    F k = one / r.q;
+    F m0 = (F)0, m1 = (F)0, m2 = (F)0, amp = (F)0;
+    if (r.ty >= 6u && r.ty <= 8u) amp = dev_pow((F)10, r.gain / (F)40);
+    switch (r.ty) {
+      default: m2 = one; break;                                       // Low
+      case 2u: m1 = one; break;                                       // Band
+      case 1u: m0 = one; m1 = -k; m2 = -one; break;                   // High
+      case 3u: m0 = one; m1 = -k; break;                              // Notch
+      case 4u: m0 = one; m1 = -k; m2 = -(F)2; break;                  // Peak
+      case 5u: m0 = one; m1 = -(F)2 * k; break;                       // All
+      case 6u: g = g / sqrt_f(amp); k = one / (r.q * amp); m0 = one; m1 = k * (amp * amp - one); break;           // Bell
+      case 7u: g = g / sqrt_f(amp); m0 = one; m1 = k * (amp - one); m2 = amp * amp - one; break;                    // LowShelf
+      case 8u: g = g * sqrt_f(amp); m0 = amp * amp; m1 = k * (one - amp) * amp; m2 = one - amp * amp; break;        // HighShelf
+    }
+    r.a1 = one / (one + g * (g + k));
+    r.a2 = g * r.a1;
+    r.a3 = g * r.a2;
+    r.m0 = m0; r.m1 = m1; r.m2 = m2;
+  }
+  template <typename F, int P>
+  static __device__ __forceinline__ void ar_set(Regs<F>& r, F v, const Ctx& c) {
+    if (P == 0) r.cutoff = v; else if (P == 1) r.q = v; else r.gain = v;
+    set_coeffs<F>(r, c);
+  }
+  template <typename F, bool FMA>
+  static __device__ __forceinline__ F tick(Regs<F>& r, F v0, const Ctx& c, u32 n, u32& d) { return Svf::tick<F, FMA>(r, v0, c, n, d); }
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) x[j] = Svf::tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 frame) {
+    if ((op & 0x7Fu) != EV_SET) return;
+    if (rel < 8u) { Svf::on_event<F>(r, op, rel, bits, frame); return; }
+    const F v = word_to_f<F>((typename WordOf<F>::type)bits);
+    if (rel == 8u) r.cutoff = v; else if (rel == 9u) r.q = v; else if (rel == 10u) r.gain = v; else r.ty = (u32)bits;
+  }
+};
+
 // OnePoleLpf / OnePoleHpf tick -- onepole.rs:64-92.  slots: 0 last_output, 1 a0, 2 b1
 template <bool HIGHPASS>
 struct OnePoleT : StageDefaults {
@@ -1022,6 +1123,15 @@ struct OnePoleT : StageDefaults {
   }
   template <typename F, typename W>
   static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = f_to_word(r.y); }
+  // OnePoleLpf/Hpf::cutoff_freq -> set_freq_lowpass (onepole.rs:35-46,135-139,172-176): device exp, tolerance only
+  static __device__ __forceinline__ float exp_f(float v) { return __ocml_exp_f32(v); }
+  static __device__ __forceinline__ double exp_f(double v) { return __ocml_exp_f64(v); }
+  template <typename F, int P>
+  static __device__ __forceinline__ void ar_set(Regs<F>& r, F v, const Ctx& c) {
+    const F f = v / (F)c.sample_rate;
+    r.b1 = exp_f((F)-2.0 * (F)3.14159265358979323846 * f);
+    r.a0 = (F)1.0 - r.b1;
+  }
   template <typename F, bool FMA>
   static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32, u32&) {
     if constexpr (FMA) r.y = mad<true>(x, r.a0, r.y * r.b1);
@@ -1073,6 +1183,13 @@ struct MulEnvT : StageDefaults {
   template <typename F, typename W>
   static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
     s[0] = (W)r.state; s[st] = f_to_word(r.t); s[4 * st] = f_to_word(r.scale);
+  }
+  // EnvAsr/EnvAr::attack_time / ::release_time (envelopes.rs:85-110 / :236-261): the rate is a function of the new time
+  // alone (the reference's "skip when unchanged" recomputes the same number), F::from(sample_rate) is the u32 as F
+  template <typename F, int P>
+  static __device__ __forceinline__ void ar_set(Regs<F>& r, F v, const Ctx& c) {
+    const F rate = v == (F)0 ? (F)1 : (F)1 / (v * (F)c.sample_rate);
+    if (P == 0) r.ar = rate; else r.rr = rate;
   }
   // One sample of the envelope itself (EnvAsr/EnvAr::next_sample, envelopes.rs:52-81 / 205-233).
   template <typename F>
@@ -1670,8 +1787,6 @@ typedef AllpassDelayT<true> AllpassFbDelay;
 
 // x (op) value: Constant + MathUGen (util.rs:61-63, math.rs:22-85) and WrMul/WrAdd/WrSub
 // (wrappers_core/math.rs:62-67).  slot 0: value.  OP: 0 mul, 1 add, 2 sub, 3 div
-static __device__ __forceinline__ float dev_pow(float a, float b) { return __ocml_pow_f32(a, b); }
-static __device__ __forceinline__ double dev_pow(double a, double b) { return __ocml_pow_f64(a, b); }
 template <int OP>
 struct ValT : StageDefaults {
   static constexpr int kSlots = 1;
@@ -1687,6 +1802,9 @@ struct ValT : StageDefaults {
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long) { r.v = word_to_f<F>(s[0]); }
   template <typename F, typename W>
   static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
+  // Constant::value (util.rs:47-50) / WrMul's "wr_mul" (wrappers_core/math.rs:92-98): value = F::new(v)
+  template <typename F, int P>
+  static __device__ __forceinline__ void ar_set(Regs<F>& r, F v, const Ctx&) { r.v = v; }
   template <typename F, bool FMA>
   static __device__ __forceinline__ F tick(Regs<F>& r, F x, const Ctx&, u32, u32&) {
     if (OP == 0) return x * r.v;
@@ -1954,6 +2072,7 @@ struct DagChain<F, FMA, BASE, R, LAST, N0, Rest...> {
   static constexpr int A = NodeOf<N0>::a, B = NodeOf<N0>::b, O = NodeOf<N0>::o;
   static_assert(A < R && B < R && O >= 0 && O < R, "signal slots are 0 .. R-1");
   static_assert(!S0::kBinary || (A >= 0 && B >= 0), "a MathUGen of two signals reads both");
+  static_assert(S0::kArParam < 0 || B >= 0, "an audio-rate parameter names the signal that drives it");
   typedef DagChain<F, FMA, BASE + S0::kSlots, R, O, Rest...> RestT;
   static constexpr int kSlots = RestT::kSlots;
   static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
@@ -1974,6 +2093,10 @@ struct DagChain<F, FMA, BASE, R, LAST, N0, Rest...> {
     if constexpr (S0::kBinary) {
 #pragma unroll
       for (int j = 0; j < T; ++j) sig[O][j] = S0::template apply<F>(sig[A][j], sig[B][j]);
+    } else if constexpr (S0::kArParam >= 0) {
+      // WrArParams::process (audio_rate.rs:42-57): param_apply(p, buffer[i]), then one sample of the node -- frame by frame
+#pragma unroll
+      for (int j = 0; j < T; ++j) sig[O][j] = ar_one(sig[A >= 0 ? A : 0][j], sig[B >= 0 ? B : 0][j], c, frame0 + (u32)j);
     } else {
       if constexpr (A != O) {
 #pragma unroll
@@ -1983,8 +2106,17 @@ struct DagChain<F, FMA, BASE, R, LAST, N0, Rest...> {
     }
     rest.template run_tile<T>(sig, c, frame0);
   }
+  // one sample of a node whose parameter kArParam a second signal drives (b = that signal's sample)
+  __device__ __forceinline__ F ar_one(F a, F b, const Ctx& c, u32 frame) {
+    S0::template ar_set<F, (S0::kArParam >= 0 ? S0::kArParam : 0)>(r, b, c);
+    // the wrapper runs the node sample by sample through UGen::process, where an envelope marks done at frame 0 of its
+    // one-sample "block" (envelopes.rs:153-156 / :285-288: next_sample(flags, 0)): the mark carries no in-block frame
+    if constexpr (S0::kIsEnv && S0::kHasSeg) frame = r.seg;
+    return S0::template tick<F, FMA>(r, A >= 0 ? a : (F)0, c, frame, mark);
+  }
   __device__ __forceinline__ void run_one(F (&sig)[R], const Ctx& c, u32 frame) {
     if constexpr (S0::kBinary) sig[O] = S0::template apply<F>(sig[A], sig[B]);
+    else if constexpr (S0::kArParam >= 0) sig[O] = ar_one(sig[A >= 0 ? A : 0], sig[B >= 0 ? B : 0], c, frame);
     else sig[O] = S0::template tick<F, FMA>(r, A >= 0 ? sig[A >= 0 ? A : 0] : (F)0, c, frame, mark);
     rest.run_one(sig, c, frame);
   }
@@ -2054,6 +2186,7 @@ struct VoiceKernelArgs {
   u32 frame_begin, frame_end;       // frames [begin, end) of each block are processed ([0, block_size) unless n_blocks == 1)
   const float* sine_table;          // 16384 floats in HBM (staged to LDS)
   double f2pi;
+  u32 sample_rate;                  // for the setters that run on the device (audio-rate parameters, ArP)
   const double* seg_table;          // segment Envelope table [n_voices][seg_max][3], or null
   u32 seg_max;
   void* delay_ring;                 // SampleDelay rings [n_voices][delay_stride] of F, or null
@@ -2184,6 +2317,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ctx.buffer_frames = a.buffer_frames;
   ctx.input_block = a.input;
   ctx.in_stride = a.block_size;
+  ctx.sample_rate = a.sample_rate;
 
   const u32 wave_global = blockIdx.x * WAVES + wave;
   const u32 v0 = wave_global * 64u;

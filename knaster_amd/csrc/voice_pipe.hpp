@@ -131,6 +131,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   ctx.buffer_frames = a.buffer_frames;
   ctx.input_block = a.input;
   ctx.in_stride = a.block_size;
+  ctx.sample_rate = a.sample_rate;
   const bool live = (u32)lane < nv;
   const u32 voice = live ? v0 + lane : v0 + nv - 1;
   ChainT chain;

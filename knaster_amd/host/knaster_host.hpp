@@ -190,7 +190,7 @@ struct ChainPlan {
     std::string s;
     for (auto& st : stages) {
       s += std::to_string(st.kind) + "." + std::to_string(st.flags) + "." + std::to_string(st.delayed_changes_per_block) + "." +
-           std::to_string(st.input) + "." + std::to_string(st.input2) + ";";
+           std::to_string(st.input) + "." + std::to_string(st.input2) + "." + std::to_string(st.ar_param) + ";";
     }
     return s;
   }
@@ -340,11 +340,21 @@ class Graph {
     visited.push_back(node);
     auto in_of = [&](uint16_t src) -> uint16_t { return src == p.stages.size() ? 0 : src; };  // the stage before: the default
     auto finish = [&]() -> uint16_t { return done[node] = static_cast<uint16_t>(p.stages.size()); };
+    // node.link(param, signal) on a node pushed as .ar_params() (graph_edit.rs:735-754, audio_rate.rs:11-85): the driving
+    // signal is traced first (so that the node's own input can still be "the stage before"), the stage then names it
+    // (knh_stage_desc.ar_param / .input2).  -> {ar_param, input2}
+    auto ar_edge = [&](const NodeRec& x) -> std::pair<uint16_t, uint16_t> {
+      if (x.link_source < 0) return {0, 0};
+      if (!x.spec.ar_params_) throw GraphError("link(): the node was not pushed as .ar_params(); the edge would have no effect (ugen.rs:309-329)");
+      const uint16_t drv = trace(x.link_source, p, visited, done);
+      return {static_cast<uint16_t>(x.link_param + 1), drv};
+    };
     if (n.type == NodeRec::MATH) {
       if (n.math_kind != 0xFFFF) {  // signal (op) Constant: graph_edit.rs:1036-1066
-        const uint16_t src = trace(n.in0, p, visited, done);
         const NodeRec& c = nodes_[static_cast<size_t>(n.in1)];
-        push_stage(p, n.math_kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, n.in1, c.spec.args, in_of(src));
+        const auto ar = ar_edge(c);
+        const uint16_t src = trace(n.in0, p, visited, done);
+        push_stage(p, n.math_kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, n.in1, c.spec.args, in_of(src), ar.second, ar.first);
         visited.push_back(n.in1);
         return finish();
       }
@@ -355,10 +365,11 @@ class Graph {
       if (n.math2_kind == KNH_STAGE_MATH_MUL)
         env = (b.type == NodeRec::UGEN && b.spec.is_env) ? n.in1 : (a.type == NodeRec::UGEN && a.spec.is_env) ? n.in0 : -1;
       if (env >= 0) {
-        const uint16_t src = trace(env == n.in1 ? n.in0 : n.in1, p, visited, done);
         const NodeRec& e = nodes_[static_cast<size_t>(env)];
         if (!e.spec.wrappers.empty()) throw GraphError("wrappers on an envelope inside a product are not fused");
-        push_stage(p, e.spec.kind, e.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, e.spec.precise_timing_, env, e.spec.args, in_of(src));
+        const auto ar = ar_edge(e);
+        const uint16_t src = trace(env == n.in1 ? n.in0 : n.in1, p, visited, done);
+        push_stage(p, e.spec.kind, e.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, e.spec.precise_timing_, env, e.spec.args, in_of(src), ar.second, ar.first);
         visited.push_back(env);
         return finish();
       }
@@ -368,12 +379,13 @@ class Graph {
       const bool commutes = n.math2_kind == KNH_STAGE_MATH_MUL || n.math2_kind == KNH_STAGE_MATH_ADD;
       if (b_const || (a_const && commutes)) {
         const int cn = b_const ? n.in1 : n.in0;
-        const uint16_t src = trace(b_const ? n.in0 : n.in1, p, visited, done);
         const NodeRec& c = nodes_[static_cast<size_t>(cn)];
         if (!c.spec.wrappers.empty()) throw GraphError("wrappers on a Constant operand are not fused");
+        const auto ar = ar_edge(c);
+        const uint16_t src = trace(b_const ? n.in0 : n.in1, p, visited, done);
         const uint16_t kind = n.math2_kind == KNH_STAGE_MATH_MUL ? KNH_STAGE_MUL_CONST : n.math2_kind == KNH_STAGE_MATH_ADD ? KNH_STAGE_ADD_CONST
                             : n.math2_kind == KNH_STAGE_MATH_SUB ? KNH_STAGE_SUB_CONST : n.math2_kind == KNH_STAGE_MATH_DIV ? KNH_STAGE_DIV_CONST : KNH_STAGE_POW_CONST;
-        push_stage(p, kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, cn, c.spec.args, in_of(src));
+        push_stage(p, kind, c.spec.smooth_params_ ? KNH_STAGE_FLAG_SMOOTH_PARAMS : 0, c.spec.precise_timing_, cn, c.spec.args, in_of(src), ar.second, ar.first);
         visited.push_back(cn);
         return finish();
       }
@@ -389,24 +401,23 @@ class Graph {
                         s.kind == KNH_STAGE_BUFFER_READER || s.kind == KNH_STAGE_WHITE_NOISE || s.kind == KNH_STAGE_PINK_NOISE ||
                         s.kind == KNH_STAGE_BROWN_NOISE || s.kind == KNH_STAGE_RANDOM_LIN;
     uint16_t flags = 0, input = 0;
-    if (source) {
-      if (n.link_source >= 0) {
-        if (!(s.kind == KNH_STAGE_SIN_WT && s.ar_params_ && n.link_param == 0))
-          throw GraphError("only SinWt(..).ar_params() with link(\"freq\", ..) is fused");
-        input = in_of(trace(n.link_source, p, visited, done));
-        flags = KNH_STAGE_FLAG_AR_FREQ;
-      }
+    std::pair<uint16_t, uint16_t> ar{0, 0};
+    if (source && n.link_source >= 0 && s.kind == KNH_STAGE_SIN_WT && s.ar_params_ && n.link_param == 0) {
+      // SinWt(..).ar_params().link("freq", ..): the spelling with pre-built kernels (BASELINE config C5)
+      input = in_of(trace(n.link_source, p, visited, done));
+      flags = KNH_STAGE_FLAG_AR_FREQ;
     } else {
-      input = in_of(trace(n.in0, p, visited, done));
+      ar = ar_edge(n);  // any other float parameter of any node the library can drive at audio rate (knh_stage_desc.ar_param)
+      if (!source) input = in_of(trace(n.in0, p, visited, done));
     }
     if (s.smooth_params_) flags |= KNH_STAGE_FLAG_SMOOTH_PARAMS;
-    push_stage(p, s.kind, flags, s.precise_timing_, node, s.args, input);
+    push_stage(p, s.kind, flags, s.precise_timing_, node, s.args, input, ar.second, ar.first);
     for (auto& w : s.wrappers) push_stage(p, w.first, 0, 0, node, {w.second});
     return finish();
   }
   static void push_stage(ChainPlan& p, uint16_t kind, uint16_t flags, uint16_t dcpb, int node, std::vector<double> args, uint16_t input = 0,
-                         uint16_t input2 = 0) {
-    p.stages.push_back(knh_stage_desc{kind, flags, dcpb, 0, input, input2});
+                         uint16_t input2 = 0, uint16_t ar_param = 0) {
+    p.stages.push_back(knh_stage_desc{kind, flags, dcpb, ar_param, input, input2});
     p.stage_node.push_back(node);
     p.stage_args.push_back(std::move(args));
   }

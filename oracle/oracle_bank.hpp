@@ -174,6 +174,9 @@ struct VoiceChainBuilder {
                             st.kind == KNH_STAGE_POW_CONST;
       targets[s].n_params = core->parameters();
       if (st.kind == KNH_STAGE_SIN_WT && (st.flags & KNH_STAGE_FLAG_AR_FREQ)) core = std::make_unique<WrArParams<F>>(std::move(core));
+      // knh_stage_desc.ar_param: `.ar_params()` on the parameterised node, its parameter linked below (a wrapper stage's
+      // own parameter -- WrMul's "wr_mul" -- is the wrapped node's, so the wrapper goes outside the Wr* stages: further down)
+      if (st.ar_param != 0 && !(st.flags & KNH_STAGE_FLAG_AR_FREQ)) core = std::make_unique<WrArParams<F>>(std::move(core));
       if (st.flags & KNH_STAGE_FLAG_SMOOTH_PARAMS) {
         if (st.flags & KNH_STAGE_FLAG_AR_FREQ) throw std::runtime_error("SMOOTH_PARAMS and AR_FREQ cannot be combined");
         core = std::make_unique<WrSmoothParams<F>>(std::move(core));
@@ -210,6 +213,15 @@ struct VoiceChainBuilder {
         wr_targets.emplace_back(s2, off);
         ++s2;
       }
+      // a wrapper stage whose own parameter (WrMul's "wr_mul") is driven at audio rate: `.wr_mul(v).ar_params()`
+      size_t wr_ar_stage = 0, wr_ar_index = 0;
+      for (auto& [ws, off] : wr_targets)
+        if (stages[ws].ar_param != 0) {
+          if (wr_ar_stage != 0 || st.ar_param != 0) throw std::runtime_error("one audio-rate parameter per node and its wrappers");
+          wr_ar_stage = ws;
+          wr_ar_index = off + (stages[ws].ar_param - 1);
+        }
+      if (wr_ar_stage != 0) wrapped = std::make_unique<WrArParams<F>>(std::move(wrapped));
       // WrPreciseTiming is outermost (precise_timing.rs:13).
       if (st.delayed_changes_per_block > 0) core = std::make_unique<WrPreciseTiming<F>>(st.delayed_changes_per_block, std::move(core));
       if (two_node && !wr_targets.empty() && stages[s2 - 1].delayed_changes_per_block > 0)
@@ -244,6 +256,14 @@ struct VoiceChainBuilder {
         targets[ws].index_offset = off;
         targets[ws].n_params = stages[ws].kind == KNH_STAGE_WR_MUL ? 1 : 0;
       }
+      // audio-rate parameter edges: node.link(param, signal) (graph_edit.rs:735-754 -> connect_replace_to_parameter)
+      auto link = [&](const knh_stage_desc& d, size_t param, NodeKey sink) {
+        if (d.input2 == 0) throw std::runtime_error("an audio-rate parameter names the signal that drives it (input2)");
+        if (out_of[d.input2 - 1] == GRAPH_KEY) throw std::runtime_error("an audio-rate parameter edge starts at a node, not at a graph input");
+        g.connect_to_parameter(out_of[d.input2 - 1], ch_of[d.input2 - 1], param, sink);
+      };
+      if (st.ar_param != 0 && !(st.flags & KNH_STAGE_FLAG_AR_FREQ)) link(st, st.ar_param - 1u, core_key);
+      if (wr_ar_stage != 0) link(stages[wr_ar_stage], wr_ar_index, out_key);
       for (size_t k = s; k < s2; ++k) { out_of[k] = out_key; ch_of[k] = 0; }
       x = out_key;
       x_ch = 0;

@@ -24,7 +24,7 @@ VALUE_FLOAT, VALUE_TRIGGER, VALUE_INTEGER, VALUE_BOOL = 0, 1, 2, 3
 
 class StageDesc(C.Structure):  # layout of knh_stage_desc
     _fields_ = [("kind", C.c_uint16), ("flags", C.c_uint16), ("delayed_changes_per_block", C.c_uint16),
-                ("reserved", C.c_uint16), ("input", C.c_uint16), ("input2", C.c_uint16)]
+                ("ar_param", C.c_uint16), ("input", C.c_uint16), ("input2", C.c_uint16)]
 
 
 def build(force: bool = False) -> None:
@@ -89,6 +89,7 @@ def _stage_array(stages):
     for i, s in enumerate(stages):
         arr[i].kind, arr[i].flags, arr[i].delayed_changes_per_block = s.kind, s.flags, s.delayed_changes_per_block
         arr[i].input, arr[i].input2 = getattr(s, "input", 0), getattr(s, "input2", 0)
+        arr[i].ar_param = getattr(s, "ar_param", 0)
     return arr
 
 

@@ -79,6 +79,35 @@ static void plan_groups_voices_by_chain_shape() {
   CHECK(b2.size() == 5 && b2[3].kind == KNH_STAGE_SIN_WT && (b2[3].flags & KNH_STAGE_FLAG_AR_FREQ) && b2[3].delayed_changes_per_block == 4);
   CHECK(b2[1].kind == KNH_STAGE_MUL_CONST && b2[2].kind == KNH_STAGE_ADD_CONST && b2[4].kind == KNH_STAGE_MUL_CONST);
 }
+// node.link(param, signal) to parameters other than SinWt's freq (graph_edit.rs:735-754; WrArParams, audio_rate.rs:11-85)
+static void plan_link_to_any_parameter() {
+  auto [graph, processor] = AudioProcessor<float>::create(2, {64, 48000});
+  (void)processor;
+  graph->plan_only = true;
+  graph->edit([&](GraphEdit<float>& g) {
+    auto lfo = g.push(SinWt(3.));
+    auto s = g.push(SinWt(220.));
+    auto f = g.push(SvfFilter(SvfFilterType::Low, 1000., 1., 0.).ar_params());
+    f.link("cutoff_freq", lfo * 500. + 1000.);
+    ((s >> f) * 0.1).out({0, 0}).to_graph_out();
+  });
+  CHECK(graph->num_banks() == 1);
+  const auto& st = graph->bank(0).plan.stages;  // lfo, * 500, + 1000, s, svf(cutoff <- stage 2), * 0.1
+  CHECK(st.size() == 6);
+  CHECK(st[0].kind == KNH_STAGE_SIN_WT && st[1].kind == KNH_STAGE_MUL_CONST && st[2].kind == KNH_STAGE_ADD_CONST && st[3].kind == KNH_STAGE_SIN_WT);
+  CHECK(st[4].kind == KNH_STAGE_SVF && st[4].ar_param == 1 && st[4].input2 == 3 && st[4].input == 0 && st[4].flags == 0);
+  CHECK(st[5].kind == KNH_STAGE_MUL_CONST);
+  bool threw = false;
+  try {  // without .ar_params() the edge would reach no WrArParams (ugen.rs:309-329): refused rather than silently ignored
+    graph->edit([&](GraphEdit<float>& g) {
+      auto lfo = g.push(SinWt(3.));
+      auto c = g.push(SinWt(220.));
+      c.link("phase_offset", lfo * 100.);
+      (c * 0.1).out({0, 0}).to_graph_out();
+    });
+  } catch (const GraphError&) { threw = true; }
+  CHECK(threw);
+}
 // noise.rs:11-22: WhiteNoise / PinkNoise / BrownNoise::new() draw their seeds from one process-wide counter, in
 // construction order; the mirror hands that seed to the bank as the stage's constructor argument.
 static void plan_noise_sources_take_seeds_in_construction_order() {
@@ -329,6 +358,62 @@ static void gpu_run_blocks_equals_block_by_block() {
   CHECK(std::memcmp(results[0].data(), results[1].data(), results[0].size() * sizeof(float)) == 0);
   float peak = 0;
   for (float x : results[0]) peak = std::max(peak, std::fabs(x));
+  CHECK(peak > 1e-3f);
+}
+
+// carrier.link("phase_offset", lfo * depth + offset) and an envelope whose release_time follows a signal, through the graph
+// API, against the reference-shaped graph with the reference's wrapper and parameter edges: bit for bit.
+static void gpu_link_to_any_parameter() {
+  const int N = 40, B = 64;
+  auto voices = c3_voices(N);
+  auto [graph, processor] = AudioProcessor<float>::create(2, {B, 48000});
+  kno::Graph<float> ref(0, 2, B, 48000);
+  std::vector<Sig<float>::Parameter> restart;
+  std::vector<std::pair<kno::NodeKey, size_t>> ref_restart;
+  graph->edit([&](GraphEdit<float>& g) {
+    for (int i = 0; i < N; ++i) {
+      const auto& v = voices[i];
+      auto lfo = g.push(SinWt(2.0 + 0.1 * i));
+      auto c = g.push(SinWt(v.freq).ar_params());
+      c.link("phase_offset", lfo * 4000. + 8192.);
+      auto e = g.push(EnvAr(0.001, 0.004).ar_params());
+      e.link("release_time", lfo * 0.001 + 0.003);
+      ((c * e) * v.gain).out({0, 0}).to_graph_out();
+      restart.push_back(e.param("t_restart"));
+      // the same voice with the oracle's graph API
+      auto r_lfo = ref.push(std::make_unique<kno::SinWt<float>>(float(2.0 + 0.1 * i)));
+      auto r_off = ref.math_with_constant(ref.math_with_constant(r_lfo, 0, kno::MathOp::Mul, 4000.f), 0, kno::MathOp::Add, 8192.f);
+      auto r_c = ref.push(std::make_unique<kno::WrArParams<float>>(std::make_unique<kno::SinWt<float>>(float(v.freq))));
+      ref.connect_to_parameter(r_off, 0, 1, r_c);
+      auto r_rel = ref.math_with_constant(ref.math_with_constant(r_lfo, 0, kno::MathOp::Mul, 0.001f), 0, kno::MathOp::Add, 0.003f);
+      auto r_e = ref.push(std::make_unique<kno::WrArParams<float>>(std::make_unique<kno::EnvAr<float>>(0.001f, 0.004f)));
+      ref.connect_to_parameter(r_rel, 0, 1, r_e);
+      auto r_m = ref.push(std::make_unique<kno::MathUGen<float>>(1, kno::MathOp::Mul));
+      ref.connect_to_node(r_c, 0, 0, r_m, false);
+      ref.connect_to_node(r_e, 0, 1, r_m, false);
+      auto r_g = ref.math_with_constant(r_m, 0, kno::MathOp::Mul, float(v.gain));
+      ref.connect_to_output(r_g, 0, 0, true);
+      ref.connect_to_output(r_g, 0, 1, true);
+      ref_restart.emplace_back(r_e, 2);
+    }
+  });
+  CHECK(graph->num_banks() == 1);
+  ref.commit_changes();
+  std::vector<float> want(2 * B);
+  float peak = 0;
+  for (int b = 0; b < 6; ++b) {
+    if (b == 0 || b == 3)
+      for (int i = 0; i < N; ++i) { restart[i].trig(); ref.set(ref_restart[i].first, ref_restart[i].second, kno::ParameterValue::Trig()); }
+    processor->run_without_inputs();
+    ref.run({}, want.data());
+    auto o = processor->output_block();
+    // per voice the arithmetic is the reference's; the mixes differ by the order of their additions only (tree against
+    // the reference's left fold): compare within the mix tolerance
+    for (size_t i = 0; i < size_t(B); ++i) {
+      CHECK(std::fabs(o.read(0, i) - want[i]) <= 1e-5f);
+      peak = std::max(peak, std::fabs(o.read(0, i)));
+    }
+  }
   CHECK(peak > 1e-3f);
 }
 
@@ -655,6 +740,7 @@ int main(int argc, char** argv) {
   if (plan) {
     RUN(plan_readme_example);
     RUN(plan_groups_voices_by_chain_shape);
+    RUN(plan_link_to_any_parameter);
     RUN(plan_noise_sources_take_seeds_in_construction_order);
     RUN(plan_many_sines_with_pan2);
     RUN(plan_voices_that_are_graphs);
@@ -666,6 +752,7 @@ int main(int argc, char** argv) {
     RUN(gpu_readme_example);
     RUN(gpu_voice_graph_matches_reference_shaped_graph);
     RUN(gpu_run_blocks_equals_block_by_block);
+    RUN(gpu_link_to_any_parameter);
     RUN(gpu_heterogeneous_voices_mix_on_device);
     RUN(gpu_segment_envelopes_of_ragged_length);
     RUN(gpu_polyblep_delay_limiter_voices);
