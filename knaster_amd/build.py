@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libknaster_hip.so")
-SOURCES = ["kernels_pipe.hip", "kernels_single.hip", "kernels_wide.hip", "kernels_fold.hip", "kernels_interp.hip", "bank.hip", "jit.hip", "comm.hip"]
+SOURCES = ["kernels_pipe.hip", "kernels_single.hip", "kernels_wide.hip", "kernels_fold.hip", "kernels_interp.hip", "kernels_events.hip", "bank.hip", "jit.hip", "comm.hip"]
 # translation units: (source, object, extra flags).  kernels_pipe.hip is built once per pipeline form (its three tables of
 # kernels take the longest to compile; side by side they take a third of the time)
 UNITS = [("kernels_pipe.hip", "kernels_pipe_mixer.o", ["-DKNH_PIPE_PART=0"]), ("kernels_pipe.hip", "kernels_pipe_fold.o", ["-DKNH_PIPE_PART=1"]),

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -420,15 +421,21 @@ struct Bank final : knh_bank {
   // Calls to a node wrapped in WrPreciseTiming (and in nothing that keeps host state of its own): one compact record per
   // call, per block in arrival order.  When the block is assembled a single pass replays them against the armed delays
   // and each node's queue state (precise_timing.rs:65-135) and writes the device events; no queue is ever materialised.
-  struct QRec {
+  struct QRec {         // (the same bytes as knh_dev::DevRec: records of device-resolved stages are read by the resolver kernels as they are)
     uint32_t voice;
     uint16_t delay;     // set_delay_within_block_for_param value, when `arm` is set
     uint16_t stage;     // (graph-shaped voices hold up to 512 stages, frame-parallel ones 4 096)
     uint8_t param;
-    uint8_t kind : 4, arm : 1, has_value : 1;
+    uint8_t kb;         // bits 0-3 ParameterValue kind, bit 4 arm, bit 5 has a value
+    uint16_t block;     // device-resolved stages: the block of the launch the call is addressed to
+    uint32_t pad;
     union { double f; int64_t i; } v;
+    uint32_t kind() const { return kb & 15u; }
+    bool arm() const { return (kb & 0x10u) != 0; }
+    bool has_value() const { return (kb & 0x20u) != 0; }
   };
-  static_assert(sizeof(QRec) == 24, "QRec is 24 bytes");
+  static_assert(sizeof(QRec) == sizeof(knh_dev::DevRec) && offsetof(QRec, v) == offsetof(knh_dev::DevRec, value) &&
+                offsetof(QRec, block) == offsetof(knh_dev::DevRec, block) && offsetof(QRec, kb) == offsetof(knh_dev::DevRec, kb), "QRec is DevRec");
   std::vector<std::vector<QRec>> qfuture;  // [block_offset]
   struct NodeQ { uint32_t epoch; uint16_t at; uint16_t taken : 15, blocked : 1; };  // a node's queue during the block `epoch`
   std::vector<NodeQ> node_q;               // [voice * n_wrapped + wrapped index of the stage]
@@ -438,6 +445,161 @@ struct Bank final : knh_bank {
   std::vector<QRec>& qblock(uint32_t block_offset) {
     if (qfuture.size() <= block_offset) qfuture.resize(block_offset + 1);
     return qfuture[block_offset];
+  }
+  // ---- change queues resolved on the device (kernels_events.hip) ---------------------------------------------------
+  // Stages wrapped in WrPreciseTiming whose setters need no host library call (SinWt, SinNumeric, constants and wr_mul,
+  // the EnvAsr / EnvAr times and triggers): the host appends the call's record to pinned memory and that is all; armed
+  // delays, queue order, capacity, the patches and the per-voice lists are the resolver kernels' (KNH_DEV_EVENTS=0: the host's,
+  // as in round 2).  Stages that do need the host (SvfFilter: tan, one-pole: exp, ...) keep the host path; a node's queue
+  // lives in exactly one of the two places.
+  std::vector<uint8_t> stage_dev;             // [stage]
+  std::vector<uint8_t> dev_class;             // [stage * 8 + param]: 1 + the value kind a device-resolved node's parameter takes, 0: not one
+  bool dev_events = false;
+  QRec* h_recs2[2] = {nullptr, nullptr};      // pinned; two alternate: the resolver of a launch reads one while the host fills the other
+  size_t h_recs_cap2[2] = {0, 0};
+  hipEvent_t recs_done[2] = {nullptr, nullptr};
+  bool recs_busy[2] = {false, false};
+  unsigned recs_parity = 0;
+  QRec* h_recs = nullptr;                     // = h_recs2[recs_parity]
+  size_t n_recs = 0;
+  uint32_t recs_max_block = 0;
+  knh_dev::DevStage* d_stages = nullptr;
+  uint16_t* d_armed = nullptr;
+  uint32_t *d_ev_cnt = nullptr, *d_rec_start = nullptr;
+  knh_dev::u64* d_keys = nullptr;
+  knh_dev::DevRec* d_recs = nullptr;          // the launch's records, copied by the counting kernel (one pass over PCIe)
+  size_t d_keys_cap = 0;
+  // The resolver runs on a stream of its own, so that it works on launch k + 1 while the voice kernel of launch k runs; the
+  // lists it makes therefore come in two sets, used alternately: a set is rewritten only after the voice kernel that read it
+  // has finished (lists_free), and a voice kernel starts only when its set is complete (ev_ready).
+  hipStream_t ev_stream = nullptr;
+  hipEvent_t ev_ready = nullptr, lists_free[2] = {nullptr, nullptr};
+  bool lists_busy[2] = {false, false};
+  uint32_t* d_out_start2[2] = {nullptr, nullptr};
+  Event* d_out_events2[2] = {nullptr, nullptr};
+  size_t d_out_cap2[2] = {0, 0};
+  unsigned out_parity = 0;
+  int out_in_use = -1;                        // the set the voice kernel being launched reads
+  static bool dev_resolvable_kind(uint16_t kind) {
+    switch (kind) {
+      case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR:
+      case KNH_STAGE_MUL_CONST: case KNH_STAGE_ADD_CONST: case KNH_STAGE_SUB_CONST: case KNH_STAGE_DIV_CONST: case KNH_STAGE_POW_CONST:
+      case KNH_STAGE_WR_MUL: return true;
+      default: return false;
+    }
+  }
+  int dev_reserve(size_t more) {  // room for `more` records in the buffer being filled
+    const unsigned b = recs_parity;
+    if (n_recs + more <= h_recs_cap2[b]) return KNH_OK;
+    const size_t cap = std::max<size_t>((n_recs + more) * 2, 16384);
+    QRec* fresh = nullptr;
+    KNH_HIP(hipSetDevice(device));
+    KNH_HIP(hipHostMalloc(&fresh, cap * sizeof(QRec)));
+    if (n_recs) std::memcpy(fresh, h_recs2[b], n_recs * sizeof(QRec));
+    if (h_recs2[b]) KNH_HIP(hipHostFree(h_recs2[b]));  // (the buffer being filled is not one a kernel reads)
+    h_recs2[b] = fresh;
+    h_recs_cap2[b] = cap;
+    h_recs = fresh;
+    return KNH_OK;
+  }
+  int push_rec(uint32_t block_offset, QRec r) {
+    if (!stage_dev[r.stage]) { qblock(block_offset).push_back(r); return KNH_OK; }
+    int rc = dev_reserve(1);
+    if (rc != KNH_OK) return rc;
+    r.block = static_cast<uint16_t>(block_offset);
+    h_recs[n_recs++] = r;
+    recs_max_block = std::max(recs_max_block, block_offset);
+    return KNH_OK;
+  }
+  // The launch's records -> the per-voice event lists in device memory, merged with the host-made list (ev_start / events,
+  // pinned, or null).  Enqueued on `s` in front of the voice kernel.
+  int resolve_on_device(hipStream_t s, uint32_t n_blocks, uint32_t fb, uint32_t fe, bool have_host, size_t host_total) {
+    const unsigned b = recs_parity;
+    size_t n_now = n_recs;
+    if (recs_max_block >= n_blocks) {  // calls addressed beyond this launch: they wait, in the other buffer, for the next one
+      const unsigned o = b ^ 1u;
+      if (recs_busy[o]) { KNH_HIP(hipEventSynchronize(recs_done[o])); recs_busy[o] = false; }
+      size_t keep = 0, later = 0;
+      for (size_t i = 0; i < n_recs; ++i) later += h_recs[i].block >= n_blocks;
+      if (later > h_recs_cap2[o]) {
+        if (h_recs2[o]) KNH_HIP(hipHostFree(h_recs2[o]));
+        h_recs2[o] = nullptr;
+        h_recs_cap2[o] = std::max<size_t>(later * 2, 16384);
+        KNH_HIP(hipHostMalloc(&h_recs2[o], h_recs_cap2[o] * sizeof(QRec)));
+      }
+      later = 0;
+      uint32_t mx = 0;
+      for (size_t i = 0; i < n_recs; ++i) {
+        if (h_recs[i].block >= n_blocks) {
+          QRec r = h_recs[i];
+          r.block = static_cast<uint16_t>(r.block - n_blocks);
+          mx = std::max<uint32_t>(mx, r.block);
+          h_recs2[o][later++] = r;
+        } else {
+          h_recs[keep++] = h_recs[i];
+        }
+      }
+      n_now = keep;
+      n_recs = later;  // what the next launch starts with
+      recs_max_block = mx;
+    } else {
+      n_recs = 0;
+      recs_max_block = 0;
+    }
+    const unsigned set = out_parity;
+    out_parity ^= 1u;
+    if (n_now > d_keys_cap) {
+      KNH_HIP(hipStreamSynchronize(ev_stream));
+      if (d_keys) KNH_HIP(hipFree(d_keys));
+      if (d_recs) KNH_HIP(hipFree(d_recs));
+      d_keys = nullptr; d_recs = nullptr;
+      d_keys_cap = std::max<size_t>(n_now * 2, 16384);
+      KNH_HIP(hipMalloc(&d_keys, d_keys_cap * sizeof(knh_dev::u64)));
+      KNH_HIP(hipMalloc(&d_recs, d_keys_cap * sizeof(knh_dev::DevRec)));
+    }
+    if (host_total + n_now > d_out_cap2[set]) {
+      if (lists_busy[set]) { KNH_HIP(hipEventSynchronize(lists_free[set])); lists_busy[set] = false; }
+      KNH_HIP(hipStreamSynchronize(ev_stream));
+      if (d_out_events2[set]) KNH_HIP(hipFree(d_out_events2[set]));
+      d_out_events2[set] = nullptr;
+      d_out_cap2[set] = std::max<size_t>((host_total + n_now) * 2, 16384);
+      KNH_HIP(hipMalloc(&d_out_events2[set], d_out_cap2[set] * sizeof(Event)));
+    }
+    if (lists_busy[set]) { KNH_HIP(hipStreamWaitEvent(ev_stream, lists_free[set], 0)); lists_busy[set] = false; }
+    knh_dev::EventResolveArgs ra{};
+    ra.recs = reinterpret_cast<const knh_dev::DevRec*>(h_recs2[b]);
+    ra.n_recs = static_cast<uint32_t>(n_now);
+    ra.stages = d_stages;
+    ra.n_voices = nv;
+    ra.block_size = static_cast<uint32_t>(block_size);
+    ra.frame_begin = fb;
+    ra.frame_end = fe;
+    ra.n_blocks = n_blocks;
+    ra.sample_rate = sample_rate;
+    ra.f64 = sizeof(F) == 8 ? 1u : 0u;
+    ra.f2pi = f2pi;
+    ra.armed = d_armed;
+    ra.host_start = have_host ? h_ev_start : nullptr;
+    ra.host_events = h_events;
+    ra.cnt = d_ev_cnt;
+    ra.val_cnt = d_ev_cnt + nv;
+    ra.cursor = d_ev_cnt + 2 * static_cast<size_t>(nv);
+    ra.rec_start = d_rec_start;
+    ra.keys = d_keys;
+    ra.dev_recs = d_recs;
+    ra.out_start = d_out_start2[set];
+    ra.out_events = d_out_events2[set];
+    KNH_HIP(knh::launch_resolve_events(ra, ev_stream));
+    KNH_HIP(hipEventRecord(recs_done[b], ev_stream));
+    recs_busy[b] = true;
+    KNH_HIP(hipEventRecord(ev_ready, ev_stream));
+    KNH_HIP(hipStreamWaitEvent(s, ev_ready, 0));  // the voice kernel reads this set
+    out_in_use = static_cast<int>(set);
+    // the host goes on filling the other buffer
+    recs_parity = b ^ 1u;
+    if (recs_busy[recs_parity]) { KNH_HIP(hipEventSynchronize(recs_done[recs_parity])); recs_busy[recs_parity] = false; }
+    h_recs = h_recs2[recs_parity];
+    return KNH_OK;
   }
 
   // device
@@ -506,6 +668,18 @@ struct Bank final : knh_bank {
     for (hipEvent_t e : list_done)
       if (e) (void)hipEventDestroy(e);
     if (in_copied) (void)hipEventDestroy(in_copied);
+    for (hipEvent_t e : recs_done)
+      if (e) (void)hipEventDestroy(e);
+    if (ev_stream) (void)hipStreamSynchronize(ev_stream);
+    void* ev_dev[] = {d_stages, d_armed, d_ev_cnt, d_rec_start, d_out_start2[0], d_out_start2[1], d_keys, d_recs, d_out_events2[0], d_out_events2[1]};
+    for (void* p : ev_dev)
+      if (p) (void)hipFree(p);
+    if (ev_ready) (void)hipEventDestroy(ev_ready);
+    for (hipEvent_t e : lists_free)
+      if (e) (void)hipEventDestroy(e);
+    if (ev_stream) (void)hipStreamDestroy(ev_stream);
+    for (QRec* p : h_recs2)
+      if (p) (void)hipHostFree(p);
     for (auto& p : timing_pool) {
       (void)hipEventDestroy(p.first);
       (void)hipEventDestroy(p.second);
@@ -1033,6 +1207,39 @@ struct Bank final : knh_bank {
     for (size_t si = 0; si < stages.size(); ++si)
       if (fastq(stages[si])) wrapped_index[si] = static_cast<int>(n_wrapped++);
     node_q.assign(static_cast<size_t>(nv) * n_wrapped, NodeQ{0u, 0, 0, 0});
+    {  // which of the wrapped nodes have their queues resolved on the device (kernels_events.hip): up to eight per voice
+      const char* de = std::getenv("KNH_DEV_EVENTS");
+      stage_dev.assign(stages.size(), 0);
+      std::vector<knh_dev::DevStage> ds(stages.size());
+      int n_dev = 0;
+      for (size_t si = 0; si < stages.size(); ++si) {
+        const StageInfo& S = stages[si];
+        const bool on = fastq(S) && dev_resolvable_kind(S.kind) && n_dev < 8 && !(de && de[0] == '0') && S.slot_base < 65536 && n_params_total < 65536;
+        ds[si] = knh_dev::DevStage{S.kind, S.dcpb, static_cast<unsigned short>(S.slot_base), static_cast<unsigned short>(S.param_base), S.flags, S.ar_param,
+                                   static_cast<short>(on ? n_dev : -1), 0};
+        if (on) { stage_dev[si] = 1; ++n_dev; }
+      }
+      dev_events = n_dev > 0;
+      dev_class.assign(stages.size() * 8u, 0);
+      for (size_t si = 0; si < stages.size(); ++si)
+        if (stage_dev[si])
+          for (int pp = 0; pp < stages[si].n_params && pp < 8; ++pp) dev_class[si * 8u + pp] = static_cast<uint8_t>(1 + expected_value_kind(stages[si].kind, pp));
+      if (dev_events) {
+        KNH_HIP(hipMalloc(&d_stages, ds.size() * sizeof(knh_dev::DevStage)));
+        KNH_HIP(hipMemcpy(d_stages, ds.data(), ds.size() * sizeof(knh_dev::DevStage), hipMemcpyHostToDevice));
+        KNH_HIP(hipMalloc(&d_armed, static_cast<size_t>(n_params_total) * nv * sizeof(uint16_t)));
+        KNH_HIP(hipMemset(d_armed, 0, static_cast<size_t>(n_params_total) * nv * sizeof(uint16_t)));
+        KNH_HIP(hipMalloc(&d_ev_cnt, static_cast<size_t>(nv) * 3 * sizeof(uint32_t)));
+        KNH_HIP(hipMalloc(&d_rec_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
+        KNH_HIP(hipStreamCreateWithFlags(&ev_stream, hipStreamNonBlocking));
+        KNH_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        for (int b = 0; b < 2; ++b) {
+          KNH_HIP(hipMalloc(&d_out_start2[b], (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
+          KNH_HIP(hipEventCreateWithFlags(&recs_done[b], hipEventDisableTiming));
+          KNH_HIP(hipEventCreateWithFlags(&lists_free[b], hipEventDisableTiming));
+        }
+      }
+    }
     smooth.assign(stages.size(), {});
     smooth_mark.assign(stages.size(), {});
     for (size_t si = 0; si < stages.size(); ++si)
@@ -1068,9 +1275,8 @@ struct Bank final : knh_bank {
     }
     if (fastq(S)) {
       QRec r{};
-      r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
-      qblock(0).push_back(r);
-      return KNH_OK;
+      r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param); r.kb = 0x10u;
+      return push_rec(0, r);
     }
     next_delay[static_cast<size_t>(S.param_base + param) * nv + voice] = delay;  // precise_timing.rs:146-148
     return KNH_OK;
@@ -1081,8 +1287,7 @@ struct Bank final : knh_bank {
     const StageInfo& S = stages[stage];
     if (!kind_ok(S, param, kind)) return fail(KNH_ERR_WRONG_VALUE_KIND, "parameter value kind does not match the parameter type");
     if (fastq(S) && frame_base == 0) {  // (frame_base != 0: a replay inside process, which has its own order)
-      qblock(0).push_back(make_qrec(voice, stage, param, kind, f, i, 0, false));
-      return KNH_OK;
+      return push_rec(0, make_qrec(voice, stage, param, kind, f, i, 0, false));
     }
     if (S.dcpb > 0) {  // WrPreciseTiming::param_apply, precise_timing.rs:126-135
       uint16_t d = next_delay[static_cast<size_t>(S.param_base + param) * nv + voice];
@@ -1097,7 +1302,7 @@ struct Bank final : knh_bank {
   static QRec make_qrec(uint32_t voice, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t i, uint16_t delay, bool arm) {
     QRec r{};
     r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param);
-    r.kind = static_cast<uint8_t>(kind & 15u); r.arm = arm ? 1 : 0; r.has_value = 1;
+    r.kb = static_cast<uint8_t>((kind & 15u) | (arm ? 0x10u : 0u) | 0x20u);
     if (kind == KNH_VALUE_FLOAT) r.v.f = f; else r.v.i = i;
     return r;
   }
@@ -1191,12 +1396,10 @@ struct Bank final : knh_bank {
     if (fastq(stages[stage])) {
       if (is_delay) {
         QRec r{};
-        r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param); r.arm = 1;
-        qblock(block_offset).push_back(r);
-      } else {
-        qblock(block_offset).push_back(make_qrec(voice, stage, param, kind, f, i, 0, false));
+        r.voice = voice; r.delay = delay; r.stage = static_cast<uint16_t>(stage); r.param = static_cast<uint8_t>(param); r.kb = 0x10u;
+        return push_rec(block_offset, r);
       }
-      return KNH_OK;
+      return push_rec(block_offset, make_qrec(voice, stage, param, kind, f, i, 0, false));
     }
     if (future.size() <= block_offset) future.resize(block_offset + 1);
     future[block_offset].push_back(Call{static_cast<uint8_t>(is_delay), delay, voice, stage, param, kind, f, i});
@@ -1224,6 +1427,37 @@ struct Bank final : knh_bank {
     int rc = KNH_OK;
     size_t k = 0;
     while (k < count) {
+      if (dev_events) {
+        // Calls to nodes whose queues the DEVICE resolves: one table look-up and one 24-byte record in pinned memory per call,
+        // whatever the order of stages and parameters in the batch (a host that addresses two parameters of alternate voices
+        // -- BASELINE config C5 -- sends runs of one call).  dev_class[stage][param] = 1 + the ParameterValue kind it takes.
+        const size_t ns = stages.size();
+        if (stgs[k] < ns && params[k] < 8u && kinds[k] < 8u && dev_class[stgs[k] * 8u + params[k]] == kinds[k] + 1u) {
+          int r2 = dev_reserve(count - k);
+          if (r2 != KNH_OK) return r2;
+          uint64_t* out = reinterpret_cast<uint64_t*>(h_recs + n_recs);  // three 8-byte words per record (QRec's layout)
+          const uint64_t blk = static_cast<uint64_t>(block_offset & 0xFFFFu) << 16;
+          size_t p = k, w = 0;
+          for (; p < count; ++p) {
+            const uint32_t st = stgs[p], pr = params[p], kd = kinds[p];
+            if (!(st < ns && pr < 8u && kd < 8u && dev_class[st * 8u + pr] == kd + 1u)) break;
+            const uint32_t v = voices[p];
+            if (v >= nv) { rc = fail(KNH_ERR_OUT_OF_RANGE, "voice out of range"); continue; }
+            const uint64_t d = delays ? delays[p] : 0u;
+            uint64_t val;
+            if (kd == KNH_VALUE_FLOAT) { const double f = fvalues ? fvalues[p] : 0.0; std::memcpy(&val, &f, 8); }
+            else { const int64_t iv = ivalues ? ivalues[p] : 0; std::memcpy(&val, &iv, 8); }
+            out[3 * w + 0] = static_cast<uint64_t>(v) | (d << 32) | (static_cast<uint64_t>(st) << 48);
+            out[3 * w + 1] = static_cast<uint64_t>(pr) | (static_cast<uint64_t>(kd | (d ? 0x10u : 0u) | 0x20u) << 8) | blk;
+            out[3 * w + 2] = val;
+            ++w;
+          }
+          n_recs += w;
+          recs_max_block = std::max(recs_max_block, block_offset);
+          k = p;
+          continue;
+        }
+      }
       size_t e = k + 1;
       while (e < count && stgs[e] == stgs[k] && params[e] == params[k] && kinds[e] == kinds[k]) ++e;
       bool direct = e - k >= 16 && stgs[k] < stages.size() && params[k] < static_cast<uint32_t>(stages[stgs[k]].n_params) &&
@@ -1472,10 +1706,10 @@ struct Bank final : knh_bank {
       const QRec& r = recs[ri];
       const StageInfo& S = stages[r.stage];
       uint16_t& armed = next_delay[static_cast<size_t>(S.param_base + r.param) * nv + r.voice];
-      if (r.arm) armed = r.delay;
-      if (!r.has_value) continue;
-      const double f = r.kind == KNH_VALUE_FLOAT ? r.v.f : 0.0;
-      const int64_t iv = r.kind == KNH_VALUE_FLOAT ? 0 : r.v.i;
+      if (r.arm()) armed = r.delay;
+      if (!r.has_value()) continue;
+      const double f = r.kind() == KNH_VALUE_FLOAT ? r.v.f : 0.0;
+      const int64_t iv = r.kind() == KNH_VALUE_FLOAT ? 0 : r.v.i;
       if (armed == 0) {  // no delay armed: straight through, before the block
         apply_now(r.voice, r.stage, r.param, f, iv, frame_base, pending);
         continue;
@@ -1496,8 +1730,8 @@ struct Bank final : knh_bank {
     for (const auto& d : due_scratch) {  // (a node's queued changes: first in, first out, their due frames never decrease)
       const QRec& r = recs[d.rec];
       const StageInfo& S = stages[r.stage];
-      const double f = r.kind == KNH_VALUE_FLOAT ? r.v.f : 0.0;
-      const int64_t iv = r.kind == KNH_VALUE_FLOAT ? 0 : r.v.i;
+      const double f = r.kind() == KNH_VALUE_FLOAT ? r.v.f : 0.0;
+      const int64_t iv = r.kind() == KNH_VALUE_FLOAT ? 0 : r.v.i;
       const uint32_t due = d.due;
       const size_t first_ev = pending.size();
       apply_now(r.voice, r.stage, r.param, f, iv, frame_base + due, pending);
@@ -1780,6 +2014,12 @@ struct Bank final : knh_bank {
     }
     a.ev_start = have_events ? h_ev_start : nullptr;  // pinned host memory, device-visible
     a.events = h_events;
+    if (dev_events && n_recs > 0) {  // calls to nodes whose queues the device resolves: the lists are made there, the host's merged in
+      int r2 = resolve_on_device(s, n_blocks, fb, fe, have_events, have_events ? h_ev_start[nv] : 0u);
+      if (r2 != KNH_OK) return r2;
+      a.ev_start = d_out_start2[out_in_use];
+      a.events = d_out_events2[out_in_use];
+    }
     a.partials = d_partials;
     a.voices_out = want_voices ? d_voices : nullptr;
     a.done_frames = d_done;
@@ -1803,6 +2043,11 @@ struct Bank final : knh_bank {
     if (interp) KNH_HIP(launch_interp(a, s));
     else KNH_HIP(launch_voice(a, n_waves, s));
     if (tp) KNH_HIP(hipEventRecord(tp->second, s));
+    if (out_in_use >= 0) {  // the resolver may rewrite this set of lists once this kernel has read it
+      KNH_HIP(hipEventRecord(lists_free[out_in_use], s));
+      lists_busy[out_in_use] = true;
+      out_in_use = -1;
+    }
     if (have_events && list_in_use >= 0) {
       KNH_HIP(hipEventRecord(list_done[list_in_use], s));
       list_busy[list_in_use] = true;

@@ -18,9 +18,44 @@ enum { INTERP_VAL_MUL = 0, INTERP_VAL_ADD, INTERP_VAL_SUB, INTERP_VAL_DIV, INTER
        INTERP_MATH_MUL, INTERP_MATH_ADD, INTERP_MATH_SUB, INTERP_MATH_DIV, INTERP_SIN_WT };
 struct InterpOp { u32 kind; unsigned short a, b, o, pad; u32 slot; };  // 16 bytes
 static_assert(sizeof(InterpOp) == 16, "one 16-byte LDS read per stage");
+// Device-side resolution of WrPreciseTiming change queues (kernels_events.hip).  DevRec is the host's 24-byte record of one
+// call (Bank::QRec: the same bytes); DevStage what the resolver needs to know of a stage.
+struct DevRec {
+  u32 voice;
+  unsigned short delay;   // set_delay_within_block_for_param value, when the arm bit is set
+  unsigned short stage;
+  unsigned char param;
+  unsigned char kb;       // bits 0-3 ParameterValue kind, bit 4 arm, bit 5 has a value
+  unsigned short block;   // block of the launch the call is addressed to
+  u32 pad;
+  u64 value;              // f64 bits (Float) or the integer
+};
+static_assert(sizeof(DevRec) == 24, "one 24-byte record per call");
+struct DevStage {
+  unsigned short kind, dcpb, slot_base, param_base, flags, ar_param;
+  short widx;             // index among the device-resolved wrapped stages (its queue state), -1: not one
+  unsigned short pad;
+};
+struct EventResolveArgs {
+  const DevRec* recs;       // pinned host memory, arrival order
+  u32 n_recs;
+  const DevStage* stages;   // device
+  u32 n_voices, block_size, frame_begin, frame_end, n_blocks, sample_rate, f64;
+  double f2pi;
+  unsigned short* armed;    // device, [n_params_total][n_voices]: WrPreciseTiming::next_delay of every parameter (persistent)
+  const u32* host_start;    // the host-made event list of the launch (pinned), or null
+  const Event* host_events;
+  u32 *cnt, *val_cnt, *cursor;  // device scratch, [n_voices] each, contiguous from cnt
+  u32* rec_start;           // [n_voices + 1]
+  u64* keys;                // [n_recs]
+  DevRec* dev_recs;         // [n_recs]: the records in device memory (the counting kernel copies them: one pass over PCIe)
+  u32* out_start;           // [n_voices + 1]: the launch's ev_start
+  Event* out_events;        // [host events + value records]
+};
 }  // namespace knh_dev
 
 namespace knh {
+hipError_t launch_resolve_events(const knh_dev::EventResolveArgs& a, hipStream_t s);
 
 template <typename F>
 using VoiceLaunchFn = hipError_t (*)(const knh_dev::VoiceKernelArgs<F>& args, unsigned n_wavefronts, hipStream_t stream);

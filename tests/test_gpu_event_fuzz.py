@@ -289,3 +289,54 @@ def test_bad_calls_are_refused_and_leave_no_trace(knh, seed):
         assert_bit_equal(dirty.process_blocks(k)[0], clean.process_blocks(k)[0], f"seed {seed} {name} blocks {2 * blk}..")
     clean.close()
     dirty.close()
+
+
+@pytest.mark.parametrize("name,n,bs", [("C5", 300, 128), ("C5", 70, 100), ("M1", 200, 64)])
+def test_device_resolved_change_queues_equal_the_hosts(knh, monkeypatch, name, n, bs):
+    """The WrPreciseTiming queues of nodes whose setters need no host library call are resolved by kernels
+    (kernels_events.hip; KNH_DEV_EVENTS=0: by the host, as before): the same calls -- batches with delays, repeats that fill
+    and block the queues, single arm / value calls, calls scheduled ahead inside and beyond a multi-block launch -- give the
+    same samples, bit for bit."""
+    from knaster_amd.bank import Stage, TRIGGER
+    rng = np.random.default_rng(4242)
+    if name == "C5":
+        w = configs.config("C5", n_voices=n, block_size=bs)
+        targets = [(0, 0, (50.0, 3000.0)), (0, 1, (0.0, 60000.0)), (3, 1, (0.0, 60000.0)), (3, 0, (100.0, 900.0)), (0, 2, None), (3, 2, None)]
+    else:
+        st = [Stage(L.STAGE_SIN_WT, delayed_changes_per_block=3), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_MUL_ENV_AR, delayed_changes_per_block=2),
+              Stage(L.STAGE_MUL_CONST, delayed_changes_per_block=1)]
+        w = configs.Workload("devq", st, n, bs, L.F32, 2)
+        p = configs.voice_parameters(n)
+        w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.5), 2: np.tile([0.001, 0.003], (n, 1)), 3: np.full((n, 1), 1.0 / n)}
+        targets = [(0, 0, (50.0, 3000.0)), (0, 1, (0.0, 60000.0)), (0, 2, None), (2, 0, (0.0005, 0.004)), (2, 1, (0.001, 0.01)), (2, 2, None),
+                   (3, 0, (0.0, 0.02)), (1, 0, (0.1, 0.9))]
+    script = []
+    for launch in range(5):
+        calls = []
+        for _ in range(int(rng.integers(3, 9))):
+            stage, param, rng_ = targets[int(rng.integers(0, len(targets)))]
+            k = int(rng.integers(1, n))
+            voices = rng.integers(0, n, size=k).astype(np.uint32)  # repeats: queues fill, block and overflow
+            delays = rng.choice([0, 0, 1, 7, bs // 2, bs - 1, bs, bs + 5], size=k).astype(np.uint16)
+            vals = None if rng_ is None else rng.uniform(rng_[0], rng_[1], size=k)
+            calls.append((int(rng.integers(0, 6)), voices, stage, param, vals, delays))  # block offsets 0..5: launches of 4 blocks, so some wait
+        singles = [(int(rng.integers(0, n)), *targets[int(rng.integers(0, len(targets)))], int(rng.choice([0, 3, bs - 2]))) for _ in range(6)]
+        script.append((calls, singles))
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("KNH_DEV_EVENTS", mode)
+        g = make_gpu(knh, w)
+        res = []
+        for calls, singles in script:
+            for off, voices, stage, param, vals, delays in calls:
+                g.param_apply_many(voices, stage, param, L.VALUE_TRIGGER if vals is None else L.VALUE_FLOAT, vals, None, delays, block_offset=off)
+            for voice, stage, param, rng_, delay in singles:
+                g.set_delay_within_block_for_param(voice, stage, param, delay)
+                g.param_apply(voice, stage, param, TRIGGER if rng_ is None else float(0.5 * (rng_[0] + rng_[1])))
+            res.append(g.process_blocks(4)[0])
+            res.append(g.process_block_voices()[1])  # and a single block with per-voice output
+        outs[mode] = res
+        g.close()
+    for a, b in zip(outs["1"], outs["0"]):
+        assert_bit_equal(a, b, "device-resolved against host-resolved")
+    assert max(float(np.abs(x).max()) for x in outs["1"]) > 1e-5
