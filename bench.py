@@ -168,6 +168,14 @@ class Env:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
+    def gather_list(self, values):
+        """-> [values of rank 0, values of rank 1, ...] on every rank"""
+        if self.world == 1:
+            return [list(values)]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, list(values))
+        return box
+
     def max_over_ranks(self, x: float) -> float:
         if self.world == 1:
             return x
@@ -266,9 +274,12 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = bank.timing_read()
+    reduce_ms, reduces = bank.collective_timing_read()
     bank.timing_reset(False)
     elapsed = env.max_over_ranks(elapsed)
     kernel_avg_ms = env.max_over_ranks(kernel_ms / max(launches, 1))
+    # every rank's own two numbers, so that a multi-GPU run explains itself: voice-kernel time and reduce time per launch
+    per_rank = env.gather_list([kernel_ms / max(launches, 1), reduce_ms / max(reduces, 1) if reduces else 0.0, cnt])
 
     # The same path when the boundary hands the blocks to the HOST (knh_bank_process_blocks: D2H copy of
     # every launch's stereo blocks over PCIe + stream sync).  Reported beside `value`, never as `value`.
@@ -301,7 +312,7 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     out = dict(workload=w_all, ugens=ugens, elapsed=elapsed, kernel_avg_ms=kernel_avg_ms, launches=launches, host_rate=host_rate,
                host_rate_blocking=host_rate_blocking if env.world == 1 else None,
                sane=sane, peak=peak, bytes_per_voice_block=rd + wr, n_pre=n_pre, voices_rank0=cnt if env.rank == 0 else None,
-               ranks_seen=bank.ranks(), total_voices=total_voices, steps=steps, collective=collective)
+               ranks_seen=bank.ranks(), total_voices=total_voices, steps=steps, collective=collective, per_rank=per_rank)
     bank.close()
     return out
 
@@ -479,6 +490,10 @@ def main():
                                f"{BLOCKS_PER_LAUNCH} blocks per launch; the library's ncclReduce of the stereo blocks to rank 0 once per "
                                f"launch, on its own stream",
                 "ranks_seen_by_rccl": m["ranks_seen"], "collective": m["collective"],
+                "per_rank": {"kernel_ms_per_launch": [r[0] for r in m["per_rank"]], "reduce_ms_per_launch": [r[1] for r in m["per_rank"]],
+                             "voices": [r[2] for r in m["per_rank"]],
+                             "note": "HIP-event device time per 64-block launch on each rank: its voice kernel, and the sum of the ranks' "
+                                     "mixed blocks to rank 0 (ncclReduce on the communicator's stream; overlaps the next launch's kernel)"},
                 "events": "t_restart on every voice at block 0 and t_release at block 32 of every 64-block cycle",
             },
             "roofline": {
@@ -543,6 +558,8 @@ def main():
                 "roofline_achieved_gbs": float(s["bytes_per_voice_block"]) * s["voices_rank0"] * BLOCKS_PER_LAUNCH / (s["kernel_avg_ms"] * 1e-3) / 1e9
                 if s["kernel_avg_ms"] > 0 else 0.0,
                 "ranks_seen_by_rccl": s["ranks_seen"], "output_finite": s["sane"],
+                "per_rank": {"kernel_ms_per_launch": [r[0] for r in s["per_rank"]], "reduce_ms_per_launch": [r[1] for r in s["per_rank"]],
+                             "voices": [r[2] for r in s["per_rank"]]},
             }
         if not args.no_cpu_baseline and world == 1 and headline == "C3":
             try:

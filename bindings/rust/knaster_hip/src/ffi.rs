@@ -168,6 +168,7 @@ unsafe extern "C" {
     pub fn knh_bank_synchronize(bank: *mut knh_bank) -> i32;
     pub fn knh_bank_timing_reset(bank: *mut knh_bank, enable: i32) -> i32;
     pub fn knh_bank_timing_read(bank: *mut knh_bank, kernel_ms: *mut f64, launches: *mut u64) -> i32;
+    pub fn knh_bank_collective_timing_read(bank: *mut knh_bank, reduce_ms: *mut f64, reduces: *mut u64) -> i32;
     pub fn knh_bank_algorithmic_bytes_per_voice_block(bank: *const knh_bank, read_bytes: *mut u32, write_bytes: *mut u32) -> i32;
     // several GPUs of one node: one process owning them all, or one process per GPU with an RCCL reduce
     pub fn knh_bank_process_blocks_begin(bank: *mut knh_bank, n_blocks: u32, frame_clock: u64) -> i32;
@@ -189,4 +190,6 @@ unsafe extern "C" {
     pub fn knh_comm_wait_buffer(comm: *mut knh_comm, buf: *const c_void, stream: *mut c_void) -> i32;
     pub fn knh_comm_wait(comm: *mut knh_comm, stream: *mut c_void) -> i32;
     pub fn knh_comm_synchronize(comm: *mut knh_comm) -> i32;
+    pub fn knh_comm_timing_reset(comm: *mut knh_comm, enable: i32) -> i32;
+    pub fn knh_comm_timing_read(comm: *mut knh_comm, reduce_ms: *mut f64, reduces: *mut u64) -> i32;
 }

@@ -463,6 +463,11 @@ int32_t knh_bank_synchronize(knh_bank* bank);
  * events on the stream the kernel runs on. */
 int32_t knh_bank_timing_reset(knh_bank* bank, int32_t enable);
 int32_t knh_bank_timing_read(knh_bank* bank, double* kernel_ms, uint64_t* launches);
+/* The same for the exchange between GPUs of a bank made by knh_bank_create_rank[_custom]: time and count of the sums of the
+ * ranks' mixed blocks since the last knh_bank_timing_reset (RCCL: device time of the ncclReduce calls on the communicator's
+ * stream; a host reduce function: wall time of its calls).  0 / 0 for any other bank.  A first multi-GPU run explains itself
+ * with the two: kernel time per launch and reduce time per launch, per rank (bench.py prints both lists). */
+int32_t knh_bank_collective_timing_read(knh_bank* bank, double* reduce_ms, uint64_t* reduces);
 /* Algorithmic HBM bytes one voice moves per processed block (state read once,
  * mutable state written once); see DESIGN.md. */
 int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_t* read_bytes,
@@ -522,6 +527,10 @@ int32_t knh_comm_reduce_sum(knh_comm* comm, void* buf, size_t count, uint32_t sa
 int32_t knh_comm_wait_buffer(knh_comm* comm, const void* buf, void* stream);
 int32_t knh_comm_wait(knh_comm* comm, void* stream);
 int32_t knh_comm_synchronize(knh_comm* comm);
+/* Measurement hooks: device time in milliseconds and count of the reduces since the last reset (HIP events on the
+ * communicator's stream). */
+int32_t knh_comm_timing_reset(knh_comm* comm, int32_t enable);
+int32_t knh_comm_timing_read(knh_comm* comm, double* reduce_ms, uint64_t* reduces);
 
 #ifdef __cplusplus
 }

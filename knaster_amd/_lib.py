@@ -95,6 +95,7 @@ PROTOTYPES = {
     "knh_bank_synchronize": (C.c_int32, [C.c_void_p]),
     "knh_bank_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
     "knh_bank_timing_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "knh_bank_collective_timing_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "knh_bank_algorithmic_bytes_per_voice_block": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
@@ -121,6 +122,8 @@ PROTOTYPES.update({
     "knh_comm_wait_buffer": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "knh_comm_wait": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "knh_comm_synchronize": (C.c_int32, [C.c_void_p]),
+    "knh_comm_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "knh_comm_timing_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 })
 
 _lib = None

@@ -295,6 +295,12 @@ class VoiceBank:
         self._check(self._lib.knh_bank_timing_read(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def collective_timing_read(self):
+        """(ms, count) of the sums across GPUs since the last timing_reset (rank banks; 0, 0 otherwise)."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._check(self._lib.knh_bank_collective_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def algorithmic_bytes_per_voice_block(self):
         r, w = C.c_uint32(0), C.c_uint32(0)
         self._check(self._lib.knh_bank_algorithmic_bytes_per_voice_block(self._h, C.byref(r), C.byref(w)))

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -332,6 +333,11 @@ struct knh_bank {
   virtual int debug_read(uint32_t* out16) = 0;
   virtual int timing_reset(int enable) = 0;
   virtual int timing_read(double* ms, uint64_t* launches) = 0;
+  virtual int collective_timing_read(double* ms, uint64_t* reduces) {
+    if (ms) *ms = 0.0;
+    if (reduces) *reduces = 0;
+    return KNH_OK;
+  }
   virtual uint32_t ranks() const { return 1; }
 
   int fail(int code, const std::string& msg) {
@@ -2862,6 +2868,12 @@ int32_t knh_bank_timing_read(knh_bank* bank, double* kernel_ms, uint64_t* launch
   return guarded(bank, [&]() -> int32_t {
     if (!bank) return KNH_ERR_INVALID_ARGUMENT;
     return bank->timing_read(kernel_ms, launches);
+  });
+}
+int32_t knh_bank_collective_timing_read(knh_bank* bank, double* reduce_ms, uint64_t* reduces) {
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    return bank->collective_timing_read(reduce_ms, reduces);
   });
 }
 int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_t* read_bytes, uint32_t* write_bytes) {

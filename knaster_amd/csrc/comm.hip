@@ -17,6 +17,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/knaster_hip.h"
 
@@ -77,12 +79,29 @@ struct knh_comm {
   struct Slot { void* buf = nullptr; hipEvent_t done = nullptr; uint64_t stamp = 0; };
   Slot slots[4];
   uint64_t clock = 0;
+  // measurement (bench.py): device time of the reduces since the last reset, from HIP events on the communicator's stream
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_pool;
+  size_t timing_used = 0;
+  double timing_ms = 0.0;
+  uint64_t timing_count = 0;
   std::string err;
   int fail(int code, const std::string& m) { err = m; return code; }
 };
 
 // no C++ exception crosses the C ABI (bank.hip has the same guard for the bank entry points)
 namespace {
+int comm_timing_collect(knh_comm* c) {
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamSynchronize failed");
+  for (size_t k = 0; k < c->timing_used; ++k) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->timing_pool[k].first, c->timing_pool[k].second) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventElapsedTime failed");
+    c->timing_ms += ms;
+    c->timing_count += 1;
+  }
+  c->timing_used = 0;
+  return KNH_OK;
+}
 template <typename Fn>
 int32_t comm_guarded(knh_comm* c, Fn&& fn) noexcept {
   try {
@@ -148,6 +167,7 @@ void knh_comm_destroy(knh_comm* c) {
   if (c->reduced) (void)hipEventDestroy(c->reduced);
   for (auto& sl : c->slots)
     if (sl.done) (void)hipEventDestroy(sl.done);
+  for (auto& p : c->timing_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -177,8 +197,24 @@ int32_t knh_comm_reduce_sum(knh_comm* c, void* buf, size_t count, uint32_t sampl
     hipStream_t producer = static_cast<hipStream_t>(after_stream);
     if (hipEventRecord(c->produced, producer) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
     if (hipStreamWaitEvent(c->stream, c->produced, 0) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
+    std::pair<hipEvent_t, hipEvent_t>* tp = nullptr;
+    if (c->timing) {
+      if (c->timing_used == c->timing_pool.size()) {
+        if (c->timing_pool.size() >= 4096) {
+          int r2 = comm_timing_collect(c);
+          if (r2 != KNH_OK) return r2;
+        } else {
+          hipEvent_t e0, e1;
+          if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventCreate failed");
+          c->timing_pool.emplace_back(e0, e1);
+        }
+      }
+      tp = &c->timing_pool[c->timing_used++];
+      if (hipEventRecord(tp->first, c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
+    }
     ncclResult_t rc = rccl()->Reduce(buf, buf, count, sample_type == KNH_F64 ? ncclFloat64 : ncclFloat32, ncclSum, static_cast<int>(root), c->comm, c->stream);
     if (rc != ncclSuccess) return c->fail(KNH_ERR_DEVICE, std::string("ncclReduce: ") + rccl()->GetErrorString(rc));
+    if (tp && hipEventRecord(tp->second, c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
     if (hipEventRecord(c->reduced, c->stream) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipEventRecord failed");
     c->pending = true;
     knh_comm::Slot* slot = nullptr;
@@ -216,6 +252,31 @@ int32_t knh_comm_wait(knh_comm* c, void* stream) {
     if (!c->pending) return KNH_OK;
     if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
     if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->reduced, 0) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipStreamWaitEvent failed");
+    return KNH_OK;
+  });
+}
+
+int32_t knh_comm_timing_reset(knh_comm* c, int32_t enable) {
+  return comm_guarded(c, [&]() -> int32_t {
+    if (!c) return KNH_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
+    int rc = comm_timing_collect(c);
+    if (rc != KNH_OK) return rc;
+    c->timing_ms = 0.0;
+    c->timing_count = 0;
+    c->timing = enable != 0;
+    return KNH_OK;
+  });
+}
+
+int32_t knh_comm_timing_read(knh_comm* c, double* reduce_ms, uint64_t* reduces) {
+  return comm_guarded(c, [&]() -> int32_t {
+    if (!c) return KNH_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
+    int rc = comm_timing_collect(c);
+    if (rc != KNH_OK) return rc;
+    if (reduce_ms) *reduce_ms = c->timing_ms;
+    if (reduces) *reduces = c->timing_count;
     return KNH_OK;
   });
 }

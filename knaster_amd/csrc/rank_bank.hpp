@@ -219,7 +219,9 @@ struct RankBank final : knh_bank {
     }
     if (world > 1) {
       if (custom) {
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = custom(custom_user, dst, n_out, sizeof(F) == 8 ? KNH_F64 : KNH_F32, 0, s);
+        if (reduce_timing) { custom_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); custom_count += 1; }
         if (rc != KNH_OK) return fail(rc, "the host's reduce function failed");
       } else {
         int rc = knh_comm_reduce_sum(comm, dst, n_out, sizeof(F) == 8 ? KNH_F64 : KNH_F32, 0, s);
@@ -267,9 +269,23 @@ struct RankBank final : knh_bank {
     if (!local) { std::memset(out16, 0, 16 * sizeof(uint32_t)); return KNH_OK; }
     return adopt(local->debug_read(out16));
   }
+  bool reduce_timing = false;
+  double custom_ms = 0.0;
+  uint64_t custom_count = 0;
   int timing_reset(int enable) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    reduce_timing = enable != 0;
+    custom_ms = 0.0;
+    custom_count = 0;
+    if (comm) { int rc = knh_comm_timing_reset(comm, enable); if (rc != KNH_OK) return fail(rc, knh_comm_last_error(comm)); }
     return local ? adopt(local->timing_reset(enable)) : KNH_OK;
+  }
+  int collective_timing_read(double* ms, uint64_t* reduces) override {
+    if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    if (comm) { int rc = knh_comm_timing_read(comm, ms, reduces); return rc == KNH_OK ? KNH_OK : fail(rc, knh_comm_last_error(comm)); }
+    if (ms) *ms = custom_ms;
+    if (reduces) *reduces = custom_count;
+    return KNH_OK;
   }
   int timing_read(double* ms, uint64_t* launches) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");

@@ -230,3 +230,25 @@ def test_bench_two_ranks_rehearsal(knh):
     assert "REHEARSAL" in d["data"]
     assert d["c4_strong"]["scaling"] == "strong" and d["c4_strong"]["voices_total"] == 4096 and d["c4_strong"]["voices_per_gpu"] == 2048
     assert d["c4_strong"]["dtype"] == "f64" and d["c4_strong"]["value"] > 0 and d["c4_strong"]["output_finite"]
+    # every rank's own kernel time and reduce time per launch (what a first real multi-GPU run is read with)
+    for pr in (d["config"]["per_rank"], d["c4_strong"]["per_rank"]):
+        assert len(pr["kernel_ms_per_launch"]) == 2 and all(x > 0 for x in pr["kernel_ms_per_launch"])
+        assert len(pr["reduce_ms_per_launch"]) == 2 and all(x > 0 for x in pr["reduce_ms_per_launch"])
+        assert pr["voices"] == [2048, 2048]
+
+
+def test_bench_two_ranks_rehearsal_c4_headline(knh):
+    """The same with BASELINE.json's multi-GPU configuration as the headline (`--config C4`: f64, the voices of ONE bank split
+    over the ranks, strong scaling)."""
+    env = dict(os.environ, KNH_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", "C4", "--c4-voices", "8192"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64" and d["value"] > 0 and d["output_finite"]
+    assert d["config"]["voices_total"] == 8192 and d["config"]["voices_per_gpu"] == 4096 and d["config"]["ranks_seen_by_rccl"] == 2
+    assert d["config"]["per_rank"]["voices"] == [4096, 4096] and "c4_strong" not in d and "REHEARSAL" in d["data"]

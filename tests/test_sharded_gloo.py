@@ -1,7 +1,8 @@
-"""The N > 1 path on CPU: world_size 2, gloo.  Each rank owns a contiguous voice range; the only
-collective is the sum-reduce of the per-rank mixed blocks.  The per-rank compute is stood in for by
-the CPU oracle (test infrastructure) because the HIP bank needs a GPU; what is under test is the
-sharding arithmetic, the host-side event routing and the reduce."""
+"""The N > 1 path on CPU: world_size 2, gloo.  Each rank owns the contiguous voice range the LIBRARY gives it
+(knh_shard_voice_range: what knh_bank_create_rank uses); the only collective is the sum-reduce of the per-rank mixed blocks.
+The library's banks need a GPU (tests/test_gpu_multi.py runs knh_bank_create_rank / _custom there, two ranks in two
+processes included), so here the per-rank compute is stood in for by the CPU oracle and the routing by a few lines of test
+code (`_RankStandIn`): what is under test is the voice ranges, the route-by-range rule and the reduce."""
 import os
 import socket
 import sys
@@ -12,40 +13,61 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_shard_ranges_partition_the_voices():
-    from knaster_amd.sharded import owner_of, shard_range
-
-    for n, world in [(16384, 8), (65536, 8), (10, 3), (7, 8), (1, 1)]:
-        covered = []
-        for r in range(world):
-            lo, hi = shard_range(n, r, world)
-            assert 0 <= lo <= hi <= n
-            covered += list(range(lo, hi))
-        assert covered == list(range(n))
-        for v in (0, n // 2, n - 1):
-            r, local = owner_of(v, n, world)
-            lo, hi = shard_range(n, r, world)
-            assert lo <= v < hi and local == v - lo
-    assert shard_range(65536, 3, 8) == (24576, 32768)  # C4: 8192 voices per GPU
-
-
-def test_shard_ranges_are_the_library_s(knh):
-    """knaster_amd.sharded.shard_range restates knh_shard_voice_range (the ranges knh_bank_create_rank uses): whole
-    64-voice groups, as even as they go.  Needs the library, not a GPU."""
+def shard_range(n_voices, rank, world):
+    """[lo, hi) of `rank`: knh_shard_voice_range (needs the library, not a GPU)"""
     from knaster_amd import shard_voice_range
-    from knaster_amd.sharded import shard_range
 
-    for n in (1, 63, 64, 65, 130, 1000, 16384, 65536, 100000):
+    first, count = shard_voice_range(n_voices, rank, world)
+    return first, first + count
+
+
+def test_shard_ranges_partition_the_voices(knh):
+    """knh_shard_voice_range: whole 64-voice groups, as even as they go, contiguous, covering every voice once."""
+    for n in (1, 7, 10, 63, 64, 65, 130, 1000, 16384, 65536, 100000):
         for world in (1, 2, 3, 4, 8):
             nxt = 0
             for r in range(world):
-                first, count = shard_voice_range(n, r, world)
-                assert (first, first + count) == shard_range(n, r, world)
-                assert first == nxt and (first % 64 == 0 or count == 0)
-                nxt = first + count
+                lo, hi = shard_range(n, r, world)
+                assert lo == nxt and (lo % 64 == 0 or hi == lo) and lo <= hi <= n
+                nxt = hi
             assert nxt == n
+    assert shard_range(65536, 3, 8) == (24576, 32768)  # C4: 8192 voices per GPU
+    assert shard_range(16384 * 8, 7, 8) == (114688, 131072)
     with pytest.raises(ValueError):
-        shard_voice_range(10, 2, 2)
+        shard_range(10, 2, 2)
+
+
+class _RankStandIn:
+    """What the library's rank bank does with a parameter stream and a launch (rank_bank.hpp), in test code: calls for this
+    rank's voices go to the local bank with local indices, the rest is some other rank's business; after the launch the
+    mixed blocks are sum-reduced to rank 0."""
+
+    def __init__(self, local, n_voices_total, rank, world, reduce_fn):
+        self.local, self.rank, self.world, self.reduce_fn = local, rank, world, reduce_fn
+        self.lo, self.hi = shard_range(n_voices_total, rank, world)
+
+    def param_apply_many(self, voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None, block_offset=0):
+        v = np.asarray(voices, dtype=np.int64)
+        mine = (v >= self.lo) & (v < self.hi)
+        if not mine.any():
+            return 0
+        pick = lambda a: None if a is None else (np.broadcast_to(np.asarray(a), v.shape)[mine])
+        self.local.param_apply_many((v[mine] - self.lo).astype(np.uint32), pick(stages), pick(params), pick(kinds), pick(fvalues),
+                                    pick(ivalues), pick(delays), block_offset=block_offset)
+        return int(mine.sum())
+
+    def process_blocks(self, n_blocks):
+        out, flags = self.local.process_blocks(n_blocks)
+        return (self.reduce_fn(out) if self.world > 1 else out), flags
+
+
+def _gloo_reduce(arr):
+    import torch
+    import torch.distributed as dist
+
+    t = torch.as_tensor(np.ascontiguousarray(arr))
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+    return t.numpy()
 
 
 class _OracleLocal:
@@ -80,14 +102,13 @@ def _worker(rank, world, port, q):
 
     from knaster_amd import _lib as L
     from knaster_amd import configs
-    from knaster_amd.sharded import ShardedBank, shard_range, torch_reduce_fn
     from oracle import oracle_py
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         w = configs.config("C3", n_voices=70, block_size=64)
         lo, hi = shard_range(w.n_voices, rank, world)
-        sb = ShardedBank(_OracleLocal(oracle_py, w, lo, hi), w.n_voices, rank, world, torch_reduce_fn(0))
+        sb = _RankStandIn(_OracleLocal(oracle_py, w, lo, hi), w.n_voices, rank, world, _gloo_reduce)
         all_voices = np.arange(w.n_voices)
         n = sb.param_apply_many(all_voices, w.restart[0], w.restart[1], L.VALUE_TRIGGER)            # block 0
         assert n == hi - lo
