@@ -7,6 +7,8 @@ give the GPU tests a target that does not need the oracle at run time.  Re-valid
 crate wherever `cargo` exists.
 
     python tests/golden/make_golden.py
+    python tests/golden/make_golden.py --inputs   # only writes <case>.ctor.bin: the constructor arguments, for the Rust-side
+                                                  # generator bindings/rust/knaster_hip/examples/dump_golden.rs (run where cargo exists)
 """
 import os
 import sys
@@ -60,7 +62,25 @@ def workload(case: str):
     return configs.config(name, n_voices=nv, block_size=bs), blocks
 
 
+def write_inputs():
+    """<case>.ctor.bin: u32 magic, n_voices, block_size, blocks, n_stages; per stage u32 n_args + f64[n_voices][n_args]."""
+    import struct
+
+    for case in CASES:
+        w, blocks = workload(case)
+        with open(os.path.join(HERE, case + ".ctor.bin"), "wb") as f:
+            f.write(struct.pack("<5I", 0x4B4E4831, w.n_voices, w.block_size, blocks, len(w.stages)))
+            for s in range(len(w.stages)):
+                a = np.ascontiguousarray(w.ctor.get(s, np.zeros((w.n_voices, 0))), dtype="<f8").reshape(w.n_voices, -1)
+                f.write(struct.pack("<I", a.shape[1]))
+                f.write(a.tobytes())
+        print(os.path.join(HERE, case + ".ctor.bin"))
+
+
 def main():
+    if "--inputs" in sys.argv:
+        write_inputs()
+        return
     from helpers import make_oracle
     from oracle import oracle_py
 

@@ -71,6 +71,64 @@ def test_full_size_c3_mix_orders_and_oracle_subset(knh, oracle, monkeypatch, pip
         assert np.max(np.abs(ref)) > 1e-4  # not silence
 
 
+def test_full_size_c2_sin_numeric(knh, oracle):
+    """BASELINE.json config C2 at its full size: 1 024 voices of SinNumeric * gain, block 256, the kernel form the bench runs
+    (phase | sin on eight wavefronts | mixer).  Every voice against the oracle within 4e-5 of its gain (the node's sin is the
+    device library's; the phase accumulator is exact, so the error does not grow over the blocks), the mix within 1e-5, and
+    equal to the documented tree fold of the device's own per-voice signals bit for bit."""
+    w = configs.config("C2")
+    assert w.n_voices == 1024 and w.block_size == 256
+    g = make_gpu(knh, w, L.MIX_TREE)
+    o = make_oracle(oracle, w, want_mix=False)
+    gain = 1.0 / w.n_voices
+    for block in range(6):
+        if block == 3:  # new frequencies on a third of the voices, on both
+            v = np.arange(0, w.n_voices, 3, dtype=np.uint32)
+            for bank in (g, o):
+                bank.param_apply_many(v, 0, 0, L.VALUE_FLOAT, 110.0 + 0.37 * v)
+        out, voices, _ = g.process_block_voices()
+        _, o_voices, _, _ = o.process_block()
+        assert np.max(np.abs(voices.astype(np.float64) - o_voices.astype(np.float64))) <= 4e-5 * gain, f"block {block}"
+        assert_bit_equal(out[0], tree_mix(voices), f"block {block}: tree mix")
+        assert np.max(np.abs(out[0].astype(np.float64) - o_voices.astype(np.float64).sum(axis=0))) <= 1e-5
+        assert np.abs(o_voices).max() > 0.5 * gain
+    g.close()
+    o.close()
+
+
+def test_full_size_c5_fm_with_sample_accurate_changes(knh, oracle):
+    """BASELINE.json config C5 at its full size: 4 096 voices of audio-rate FM, block 128, every voice a delayed change every
+    second block (resolved on the device: kernels_events.hip).  160 sampled voices -- whole wavefront groups at both ends and in
+    the middle -- equal the oracle run on just those voices with just their changes, bit for bit, over 8 blocks given one by
+    one; the same 8 blocks scheduled ahead in one launch give the same mix."""
+    w = configs.config("C5")
+    assert w.n_voices == 4096 and w.block_size == 128
+    pick = np.unique(np.concatenate([np.arange(0, 64), np.arange(2040, 2072), np.arange(w.n_voices - 64, w.n_voices)]))
+    sub = configs.Workload("sub", w.stages, len(pick), w.block_size, w.sample_type, w.out_channels, {s: a[pick] for s, a in w.ctor.items()})
+    local = {int(v): i for i, v in enumerate(pick)}
+    g = make_gpu(knh, w, L.MIX_TREE)
+    g2 = make_gpu(knh, w, L.MIX_TREE)
+    o = make_oracle(oracle, sub, want_mix=False)
+    mixes = []
+    for block in range(8):
+        e = configs.c5_events(w, block)
+        if e is not None:
+            g.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5])
+            g2.param_apply_many(e[0], e[1], e[2], e[3], e[4], None, e[5], block_offset=block)
+            m = np.isin(e[0], pick)
+            o.param_apply_many(np.array([local[int(v)] for v in e[0][m]], dtype=np.uint32), e[1][m], e[2][m], e[3][m], e[4][m], None, e[5][m])
+        out, voices, _ = g.process_block_voices()
+        _, o_voices, _, _ = o.process_block()
+        assert_bit_equal(voices[pick], o_voices, f"block {block}: sampled voices vs oracle")
+        assert_bit_equal(out[0], tree_mix(voices), f"block {block}: tree mix")
+        mixes.append(out)
+        assert np.abs(o_voices).max() > 1e-5
+    ahead, _ = g2.process_blocks(8)
+    assert_bit_equal(ahead, np.stack(mixes), "eight blocks scheduled ahead in one launch")
+    for bank in (g, g2, o):
+        bank.close()
+
+
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1000, 512), ("C4", 300, 100), ("C5", 260, 128), ("C2", 200, 48),
                                                       ("D3", 500, 512), ("B3", 300, 256)])
 def test_pipelined_kernel_equals_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
