@@ -25,7 +25,7 @@ v = out.get("voice_pipe_kernel", {})
 if "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
     v["hbm_bytes_per_launch"] = (v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
 out["command"] = ("tools/make_profiles.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- "
-                  "python3 bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-c4 (separate passes; one step = one 64-block launch); tools/pmc_summary.py")
+                  "python3 bench.py --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --no-c4 --no-configs (separate passes; one step = four 64-block launches); tools/pmc_summary.py")
 out["workload"] = {"voices": 16384, "block_size": 512, "blocks_per_launch": 64, "chain": "WmSA", "sample_type": "f32"}
 out["notes"] = [
     "FETCH_SIZE/WRITE_SIZE are in units of 1024 B as rocprofv3 reports them",
