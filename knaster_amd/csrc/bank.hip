@@ -2147,6 +2147,7 @@ struct Bank final : knh_bank {
     if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
     if (wide_waves == 4) return wide->f32_w4[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (wide_waves == 8) return wide->f32_w8[desc.allow_fma ? 1 : 0](a, n_waves, s);
+    if (wide_waves == 16) return wide->f32_w16[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (dag) return dag->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (pipe) return pipe->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f32[desc.allow_fma ? 1 : 0](a, n_waves, s);
@@ -2155,6 +2156,7 @@ struct Bank final : knh_bank {
     if (jit) return knh::jit_launch(jit, &a, sizeof(a), n_waves, s);
     if (wide_waves == 4) return wide->f64_w4[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (wide_waves == 8) return wide->f64_w8[desc.allow_fma ? 1 : 0](a, n_waves, s);
+    if (wide_waves == 16) return wide->f64_w16[desc.allow_fma ? 1 : 0](a, n_waves, s);
     if (pipe) return pipe->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
     return entry->f64[desc.allow_fma ? 1 : 0](a, n_waves, s);
   }
@@ -2372,14 +2374,16 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
       // 768, 1 024 groups): f32 pipeline 13.9 26.3 27.0 39.8 52.5 against 41-42 flat; f64 24.6 47.4 47.8 70.7 94.0 against
       // 55-57 flat.  So: three rounds of the pipeline in f32, two in f64.
       const unsigned pipe_max = d.sample_type == KNH_F64 ? 512u : 768u;
-      int ww = groups <= pipe_max && b->pipe ? 0 : (groups <= 1024 ? 4 : 8);
+      // (sixteen groups per workgroup -- four wavefronts per SIMD -- once they fill the chip: measured 110.6 -> 101.3 us per block
+      // at 4 096 groups, 218.6 -> 197.8 at 8 192, f32; at 2 048 groups they would leave half the CUs idle; f64 gains nothing)
+      int ww = groups <= pipe_max && b->pipe ? 0 : (groups <= 1024 ? 4 : (groups >= 4096 && d.sample_type == KNH_F32 ? 16 : 8));
       if (!b->pipe && groups <= 256) ww = 0;
       // a delay line wants the pipeline's 32-sample tiles (whole 128-byte lines per visit, reads one tile ahead):
       // measured 1.37e12 against 0.88e12 UGen-samples/s at 262 144 voices
       if (b->pipe && sig.find_first_of("DYZ") != std::string::npos) ww = 0;
       const char* wenv = std::getenv("KNH_WIDE");
       if (wenv) ww = std::atoi(wenv);
-      if (ww == 4 || ww == 8) b->wide_waves = ww;
+      if (ww == 4 || ww == 8 || ww == 16) b->wide_waves = ww;
     }
   }
   b->nv = d.n_voices;

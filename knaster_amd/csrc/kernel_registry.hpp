@@ -88,6 +88,8 @@ struct WideEntry {
   const char* signature;
   VoiceLaunchFn<float> f32_w4[2], f32_w8[2];
   VoiceLaunchFn<double> f64_w4[2], f64_w8[2];
+  VoiceLaunchFn<float> f32_w16[2];    // sixteen groups per workgroup: four wavefronts per SIMD (banks of thousands of groups)
+  VoiceLaunchFn<double> f64_w16[2];
 };
 const WideEntry* find_wide(const char* signature);
 

@@ -19,7 +19,9 @@ static hipError_t launch_wide(const VoiceKernelArgs<F>& args, unsigned n_wavefro
    {launch_wide<float, false, 4, __VA_ARGS__>, launch_wide<float, true, 4, __VA_ARGS__>},            \
    {launch_wide<float, false, 8, __VA_ARGS__>, launch_wide<float, true, 8, __VA_ARGS__>},            \
    {launch_wide<double, false, 4, __VA_ARGS__>, launch_wide<double, true, 4, __VA_ARGS__>},          \
-   {launch_wide<double, false, 8, __VA_ARGS__>, launch_wide<double, true, 8, __VA_ARGS__>}}
+   {launch_wide<double, false, 8, __VA_ARGS__>, launch_wide<double, true, 8, __VA_ARGS__>},          \
+   {launch_wide<float, false, 16, __VA_ARGS__>, launch_wide<float, true, 16, __VA_ARGS__>},          \
+   {launch_wide<double, false, 16, __VA_ARGS__>, launch_wide<double, true, 16, __VA_ARGS__>}}
 static const WideEntry kWides[] = {
     KNH_WIDE("Wm", SinWt, MulVal),
     KNH_WIDE("Nm", SinNum, MulVal),

@@ -2284,7 +2284,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   typedef typename ChainSelect<(SlotCount<S...>::value > 0), F, FMA, S...>::type ChainT;
   typedef typename WordOf<F>::type W;
   // frames per reduce tile: sized so that WAVES tiles + the sine table fit the CU's 160 KiB of LDS
-  constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 8 ? 2 : 1);
+  constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 16 ? 4 : (WAVES >= 8 ? 2 : 1));
   constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
                                                 // writes (ds_write_b32) and row reads (ds_read_b128)
   __shared__ float sine[ChainT::kUsesSine ? 16384 : 1];

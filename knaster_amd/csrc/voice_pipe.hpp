@@ -87,6 +87,17 @@ template <int MODE, int NG> struct EdgeMap {
   static __device__ __forceinline__ int in_tile(int I, int g) { return I > 0 ? out_tile(I - 1, g) : 0; }
   static __device__ __forceinline__ int mixer_tile(int g) { return out_tile(NG - 1, g); }
 };
+// The pipeline's step barrier.  Its wavefronts run different code (one role each) and reach the barrier from different call
+// sites; what is relied on is the HARDWARE barrier of gfx950 -- s_barrier counts the wavefronts of the workgroup that have
+// arrived, wherever in the program each one is -- not HIP's __syncthreads(), whose contract speaks of one call site reached
+// by all threads.  So it is spelled as the instruction, between the two workgroup-scope fences that make each wavefront's LDS
+// writes of the step visible to the readers of the next (what __syncthreads() expands to on this target).
+__device__ __forceinline__ void pipe_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <typename F> struct PipeShared {
   float* sine;
   F* edge;  // tiles of [64][stride]; edge i carries group i's output: EdgeMap says which tile holds what
@@ -388,7 +399,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       busy_out += t3 - t2;
 #endif
     }
-    __syncthreads();
+    pipe_barrier();
   }
 #ifdef KNH_DAG_STAMPS
   if (wave_global == 0u && lane == 0) {
@@ -471,7 +482,7 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
       busy += __builtin_amdgcn_s_memtime() - t0;
 #endif
     }
-    __syncthreads();
+    pipe_barrier();
   }
 #ifdef KNH_DAG_STAMPS
   if (wave_global == 0u && lane == 0) a.flags[4 + NG] = (u32)(busy / (u64)(n_tiles > 0 ? n_tiles : 1));
@@ -573,7 +584,7 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
     // no voices: this group only keeps the workgroup's barriers company, step for step
     const u32 n_frames = a.frame_end - a.frame_begin;
     const int n_steps = (int)((n_frames + T - 1) / T) * (int)a.n_blocks + NG - (MODE == PIPE_FOLD ? 1 : 0);
-    for (int s = 0; s < n_steps; ++s) __syncthreads();
+    for (int s = 0; s < n_steps; ++s) pipe_barrier();
   } else if (wave == CHAINW) {
     pipe_run_mixer<F, FMA, T, MODE, NG, kPan>(sh, a, lane, wave_global, v0, nv);
   } else {
@@ -583,9 +594,9 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
   constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);
   if constexpr (kAnyEnv) {
     u32* marks = reinterpret_cast<u32*>(edge) + (long)grp * (CHAINW * 64);  // the tiles are dead: every wavefront is past its last barrier-separated read
-    __syncthreads();
+    pipe_barrier();
     if (wave < CHAINW) marks[wave * 64 + lane] = done_frame;
-    __syncthreads();
+    pipe_barrier();
     if (wave == 0 && !dead) {
       u32 d = 0xFFFFFFFFu;
 #pragma unroll

@@ -362,10 +362,10 @@ def test_runtime_built_pipeline_equals_runtime_built_single_wave_kernel(knh, mon
 @pytest.mark.parametrize("name,n_voices,block_size", [("C3", 1500, 512), ("C4", 700, 100), ("C5", 520, 128), ("C2", 300, 48),
                                                       ("D3", 900, 256), ("B3", 700, 128)])
 def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_voices, block_size):
-    """KNH_WIDE=4/8: four or eight 64-voice groups per workgroup (the build used for very large banks)."""
+    """KNH_WIDE=4/8/16: four, eight or sixteen 64-voice groups per workgroup (the builds used for very large banks)."""
     w = configs.config(name, n_voices=n_voices, block_size=block_size)
     outs = {}
-    for wide in ("0", "4", "8"):
+    for wide in ("0", "4", "8", "16"):
         monkeypatch.setenv("KNH_PIPELINE", "0")
         monkeypatch.setenv("KNH_WIDE", wide)
         g = make_gpu(knh, w)
@@ -382,7 +382,7 @@ def test_many_wave_kernels_equal_single_wave_kernel(knh, monkeypatch, name, n_vo
         res.append((g.process_blocks(3)[0], None, 0, None))
         outs[wide] = res
         g.close()
-    for other in ("4", "8"):
+    for other in ("4", "8", "16"):
         for (o0, v0, f0, d0), (o1, v1, f1, d1) in zip(outs["0"], outs[other]):
             assert_bit_equal(o0, o1, f"mix, wide {other}")
             if v0 is not None:
