@@ -19,7 +19,7 @@ SOURCES = ["kernels_pipe.hip", "kernels_single.hip", "kernels_wide.hip", "kernel
 # kernels take the longest to compile; side by side they take a third of the time)
 UNITS = [("kernels_pipe.hip", "kernels_pipe_mixer.o", ["-DKNH_PIPE_PART=0"]), ("kernels_pipe.hip", "kernels_pipe_fold.o", ["-DKNH_PIPE_PART=1"]),
          ("kernels_pipe.hip", "kernels_pipe_inplace.o", ["-DKNH_PIPE_PART=2"])] + [(s, s.replace(".hip", ".o"), []) for s in SOURCES[1:]]
-HEADERS = ["voice_chain.hpp", "voice_pipe.hpp", "voice_frame.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", "rank_bank.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
+HEADERS = ["stage_table.hpp", "bank_base.hpp", "voice_bank.hpp", "chain_signature.hpp", "voice_chain.hpp", "voice_pipe.hpp", "voice_frame.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", "rank_bank.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
            os.path.join("..", "build.py")]
 FLAGS = [
     "--offload-arch=gfx950",
