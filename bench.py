@@ -558,6 +558,20 @@ def main():
                 "roofline_achieved_gbs": float(s["bytes_per_voice_block"]) * s["voices_rank0"] * BLOCKS_PER_LAUNCH / (s["kernel_avg_ms"] * 1e-3) / 1e9
                 if s["kernel_avg_ms"] > 0 else 0.0,
                 "ranks_seen_by_rccl": s["ranks_seen"], "output_finite": s["sane"],
+                # What bounds a rank's share (profiles/r03_c4_pipe_wave_busy_cycles.txt, tools/micro/exec_mask_f64.hip): an f64
+                # instruction holds its SIMD for four cycles, so f64 wavefronts are throughput-bound.  Up to 256 voice groups per
+                # GPU (the pipeline, a group per CU) the filter wavefront's 15 f64 instructions per sample (63 cycles) plus its
+                # tile's way through LDS (30) are the floor of a block's time WHATEVER the number of voices -- a GPU with 8 192
+                # voices takes as long per block as one with 16 384; beyond that (one whole-chain wavefront per SIMD) it is the
+                # f64 work of all stages, ~210 SIMD-cycles per voice-group sample.
+                "issue": {
+                    "regime": "pipeline: one 64-voice group per CU" if s["voices_rank0"] <= 16384 else ("pipeline, two groups per CU" if s["voices_rank0"] <= 32768 else "one whole-chain wavefront per SIMD"),
+                    "floor_cycles_per_sample": 93.0 if s["voices_rank0"] <= 16384 else 210.0,
+                    "floor_us_per_block": (93.0 if s["voices_rank0"] <= 16384 else 210.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
+                    "kernel_us_per_block": s["kernel_avg_ms"] * 1e3 / BLOCKS_PER_LAUNCH,
+                    "note": "strong scaling of this bank is bounded by the pipeline floor: per-GPU time per block stops falling once a GPU "
+                            "holds 16 384 voices or fewer (256 voice groups or fewer: fewer CUs busy, not faster ones)",
+                },
                 "per_rank": {"kernel_ms_per_launch": [r[0] for r in s["per_rank"]], "reduce_ms_per_launch": [r[1] for r in s["per_rank"]],
                              "voices": [r[2] for r in s["per_rank"]]},
             }

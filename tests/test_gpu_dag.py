@@ -120,6 +120,51 @@ def random_dag(rng, n_stages):
     return st, ctor
 
 
+def with_audio_rate_parameters(rng, st):
+    """Some parameters of a random voice linked to earlier signals of the voice (knh_stage_desc.ar_param / .input2): the ones
+    whose setters are exact -- Constant.value, SinWt freq and phase_offset (negative and huge values saturate, NaN gives 0)."""
+    out = []
+    for i, x in enumerate(st):
+        if i >= 1 and rng.random() < 0.45:
+            drv = int(rng.integers(1, i + 1))
+            if x.kind in (L.STAGE_MUL_CONST, L.STAGE_ADD_CONST, L.STAGE_SUB_CONST):
+                x = Stage(x.kind, x.flags, x.delayed_changes_per_block, x.input, drv, ar_param=1)
+            elif x.kind == L.STAGE_SIN_WT:
+                x = Stage(x.kind, x.flags, x.delayed_changes_per_block, x.input, drv, ar_param=int(rng.integers(1, 3)))
+        out.append(x)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "12"))))
+def test_random_dag_voices_with_audio_rate_parameters(knh, oracle, seed):
+    rng = np.random.default_rng(3000 + seed)
+    st, ctor = random_dag(rng, int(rng.integers(5, 13)))
+    st = with_audio_rate_parameters(rng, st)
+    assume_some = any(x.ar_param for x in st)
+    n = int(rng.integers(1, 140))
+    w = configs.Workload(f"dagar{seed}", st, n, int(rng.choice([16, 48, 64, 100])), L.F32 if seed % 3 else L.F64, 1)
+    w.ctor = {s: np.tile(np.asarray(a, dtype=np.float64), (n, 1)) * (1.0 + 0.01 * np.arange(n)).reshape(n, 1) if st[s].kind == L.STAGE_SIN_WT
+              else np.tile(np.asarray(a, dtype=np.float64), (n, 1)) for s, a in ctor.items()}
+    envs = [i for i, s in enumerate(st) if s.kind == L.STAGE_MUL_ENV_AR]
+    g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    o = make_oracle(oracle, w)
+    for b in range(4):
+        for bank in (g, o):
+            if b in (0, 2):
+                for e in envs:
+                    fire_all(bank, n, e, 2)
+            if b == 1:  # ordinary changes: ignored where a signal drives the parameter, applied elsewhere
+                for i, x in enumerate(st):
+                    if x.kind in (L.STAGE_MUL_CONST, L.STAGE_ADD_CONST, L.STAGE_SUB_CONST):
+                        bank.param_apply_many(np.arange(n, dtype=np.uint32), i, 0, L.VALUE_FLOAT, np.full(n, 0.3 + 0.01 * i))
+        _, gv, _ = g.process_block_voices()
+        _, ov, _, od = o.process_block()
+        assert_bit_equal(gv, ov, f"seed {seed} block {b} ({'with' if assume_some else 'without'} audio-rate parameters)")
+        np.testing.assert_array_equal(g.read_done_frames(), od)
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KNH_TEST_SEEDS", "12"))))
 def test_random_dag_voices_match_the_oracle(knh, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
