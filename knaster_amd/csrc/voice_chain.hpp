@@ -966,6 +966,88 @@ struct Svf : StageDefaults {
     (void)first_prev;
     r.ic1 = ic.x; r.ic2 = ic.y;
   }
+  // The low-pass output (svf.rs:148-157: m0 = 0, m1 = 0, m2 = 1) without its three multiplies and two adds, bit for bit:
+  //   (0*x + 0*v1) + 1*v2 = z + v2 with z = +-0 while x and v1 are finite, and z + v2 = v2 unless v2 = -0;
+  //   v2 = (ic2 + a2*ic1) + a3*v3 is -0 only if both terms are, so only if ic2 = -0; and ic2' = 2*v2 - ic2 is never -0 (it
+  //   would need v2 = -0 with ic2 = +0), so v2 = -0 can only happen in the first sample after ic2 was SET to -0: low_pass()
+  //   refuses that state and the general step runs.  When x or v1 is not finite the reference returns NaN (0*inf); x not
+  //   finite makes v1 = a1*ic1 + a2*(x - ic2) not finite too, so fma(0, v1, v2) -- v2 when v1 is finite, NaN when it is not,
+  //   and +0 + v2 = v2 -- is the reference's value in every case, in one instruction.
+  // The step is then seven instructions: v3, (a1*ic1, a2*ic1), (a2*v3, a3*v3), ic2 + a2*ic1, (v1, v2), the output of the
+  // sample before (which fills the wait state between the packed add and the packed fma that reads it: (v1, v2) alternate
+  // between two register pairs for that), (ic1', ic2'), and one s_nop for the wait state nothing is left to fill.
+  template <typename F> static __device__ __forceinline__ bool low_pass(const Regs<F>& r) {
+    typedef typename WordOf<F>::type W;
+    const W one = sizeof(F) == 4 ? (W)0x3F800000u : (W)0x3FF0000000000000ull, neg0 = (W)1 << (sizeof(F) * 8 - 1);
+    const bool mine = (f_to_word(r.m0) | f_to_word(r.m1)) == 0 && f_to_word(r.m2) == one && f_to_word(r.ic2) != neg0;
+    return __builtin_amdgcn_ballot_w64(!mine) == 0;
+  }
+  template <int T>
+  static __device__ __forceinline__ void tick_tile_low(Regs<float>& r, float (&x)[T]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 ic = {r.ic1, r.ic2};
+    const f2 a12 = {r.a1, r.a2}, a23 = {r.a2, r.a3};
+    f2 q = {0.0f, 0.0f};
+    float first_prev;
+    static_assert(T % 8 == 0, "the filter tile is unrolled in blocks of eight samples");
+    // one sample: V receives (v1, v2), OUT the output of the sample before, whose (v1, v2) are PL, PH
+#define KNH_SVF_LOW(OUT, IN, V, PL, PH)                                                                            \
+      "v_sub_f32 v114, %[x" #IN "], v101\n\t"                             /* v3 = x - ic2                     */   \
+      "v_pk_mul_f32 v[102:103], %[a12], v[100:101] op_sel_hi:[1,0]\n\t"   /* (a1*ic1, a2*ic1)                 */   \
+      "v_pk_mul_f32 v[104:105], %[a23], v[114:115] op_sel_hi:[1,0]\n\t"   /* (a2*v3, a3*v3)                   */   \
+      "v_add_f32 v103, v101, v103\n\t"                                    /* ic2 + a2*ic1                     */   \
+      "v_pk_add_f32 " V ", v[102:103], v[104:105]\n\t"                    /* (v1, v2)                         */   \
+      "v_fma_f32 %[y" #OUT "], 0, " PL ", " PH "\n\t"                     /* previous: v2 (NaN if v1 is not finite) */ \
+      "v_pk_fma_f32 v[100:101], " V ", 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"         \
+      "s_nop 0\n\t"
+#define KNH_SVF_LOW_A(OUT, IN) KNH_SVF_LOW(OUT, IN, "v[106:107]", "v108", "v109")
+#define KNH_SVF_LOW_B(OUT, IN) KNH_SVF_LOW(OUT, IN, "v[108:109]", "v106", "v107")
+#pragma unroll
+    for (int j = 0; j < T; j += 8) {
+      float y0, y1, y2, y3, y4, y5, y6, y7;  // results of samples j-1 .. j+6
+      asm volatile(KNH_SVF_LOW_A(0, 0) KNH_SVF_LOW_B(1, 1) KNH_SVF_LOW_A(2, 2) KNH_SVF_LOW_B(3, 3)
+                   KNH_SVF_LOW_A(4, 4) KNH_SVF_LOW_B(5, 5) KNH_SVF_LOW_A(6, 6) KNH_SVF_LOW_B(7, 7)
+                   : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3), [y4] "=&v"(y4), [y5] "=&v"(y5),
+                     [y6] "=&v"(y6), [y7] "=&v"(y7), "+{v[100:101]}"(ic), "+{v[108:109]}"(q)
+                   : [x0] "v"(x[j]), [x1] "v"(x[j + 1]), [x2] "v"(x[j + 2]), [x3] "v"(x[j + 3]), [x4] "v"(x[j + 4]),
+                     [x5] "v"(x[j + 5]), [x6] "v"(x[j + 6]), [x7] "v"(x[j + 7]), [a12] "v"(a12), [a23] "v"(a23)
+                   : "v102", "v103", "v104", "v105", "v106", "v107", "v114", "v115");
+      if (j > 0) x[j - 1] = y0; else first_prev = y0;  // nothing is pending before the first sample
+      x[j] = y1; x[j + 1] = y2; x[j + 2] = y3; x[j + 3] = y4; x[j + 4] = y5; x[j + 5] = y6; x[j + 6] = y7;
+    }
+#undef KNH_SVF_LOW_A
+#undef KNH_SVF_LOW_B
+#undef KNH_SVF_LOW
+    asm volatile("s_nop 0\n\tv_fma_f32 %[xout], 0, v108, v109" : [xout] "=v"(x[T - 1]) : "{v[108:109]}"(q));
+    (void)first_prev;
+    r.ic1 = ic.x; r.ic2 = ic.y;
+  }
+  // the same in f64: eleven instructions for the general step's fifteen, every operand at least two instructions old
+  template <int T>
+  static __device__ __forceinline__ void tick_tile_low_f64(Regs<double>& r, double (&x)[T]) {
+    double ic1 = r.ic1, ic2 = r.ic2;
+    const double a1 = r.a1, a2 = r.a2, a3 = r.a3;
+    double v1p = 0.0, v2p = 0.0;
+#define KNH_STEP(stmt) stmt; __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      KNH_STEP(const double v3 = x[j] - ic2);
+      KNH_STEP(const double p2 = a2 * ic1);
+      KNH_STEP(const double p1 = a1 * ic1);
+      KNH_STEP(const double q2 = a3 * v3);
+      KNH_STEP(const double q1 = a2 * v3);
+      KNH_STEP(const double t = ic2 + p2);
+      if (j > 0) { KNH_STEP(x[j - 1] = __builtin_fma(0.0, v1p, v2p)); }
+      KNH_STEP(const double v2 = t + q2);
+      KNH_STEP(const double v1 = p1 + q1);
+      KNH_STEP(ic2 = __builtin_fma(2.0, v2, -ic2));
+      KNH_STEP(ic1 = __builtin_fma(2.0, v1, -ic1));
+      v1p = v1; v2p = v2;
+    }
+    x[T - 1] = __builtin_fma(0.0, v1p, v2p);
+#undef KNH_STEP
+    r.ic1 = ic1; r.ic2 = ic2;
+  }
   // f64, exact arithmetic: the same fifteen roundings per sample as tick(), in an order fixed by hand.  An f64 instruction
   // occupies the SIMD for four cycles (half the f32 rate), so a wavefront alone on its SIMD could run the step in 15 x 4 = 60
   // cycles -- unless an instruction reads the result of the one before it, which holds the issue for about twice that.  The
@@ -1011,9 +1093,9 @@ struct Svf : StageDefaults {
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
     if constexpr (sizeof(F) == 4 && !FMA) {
-      tick_tile_packed<T>(r, x);
+      if (low_pass(r)) tick_tile_low<T>(r, x); else tick_tile_packed<T>(r, x);
     } else if constexpr (sizeof(F) == 8 && !FMA) {
-      tick_tile_f64<T>(r, x);
+      if (low_pass(r)) tick_tile_low_f64<T>(r, x); else tick_tile_f64<T>(r, x);
     } else {
 #pragma unroll
       for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
