@@ -62,6 +62,60 @@ def test_every_voice_filters_the_node_input(knh, oracle, monkeypatch, form, samp
         bank.close()
 
 
+def assert_same_class_or_bits(a, b, what):
+    """bit for bit where the reference's sample is a number; NaN where it is NaN (payloads are the FPU's, not the algorithm's)"""
+    nan = np.isnan(b)
+    np.testing.assert_array_equal(np.isnan(a), nan, err_msg=f"{what}: NaN positions")
+    assert_bit_equal(np.where(nan, 0, a).astype(a.dtype), np.where(nan, 0, b).astype(b.dtype), what)
+
+
+@pytest.mark.parametrize("poison", ["overflow", "inf", "nan"])
+@pytest.mark.parametrize("form", ["single", "pipe"])
+@pytest.mark.parametrize("sample_type", [L.F32, L.F64])
+def test_low_pass_tiles_on_zeros_denormals_overflow_and_nan(knh, oracle, monkeypatch, form, sample_type, poison):
+    """The low-pass filter's tiles leave out the output mix's multiplies by m0 = 0, m1 = 0, m2 = 1 (svf.rs:148-157, :262-279;
+    Svf::tick_tile_low).  That is only the same value if the signs of zero, the subnormals, an overflow inside the filter and a
+    NaN / infinity on the input come out as the reference's: wavefronts of low-pass voices only (the shortened step) beside
+    wavefronts with every filter type (the general step), all against the oracle."""
+    monkeypatch.setenv("KNH_PIPELINE", "0" if form == "single" else "1")
+    n, bs, nb = 192, 64, 6
+    p = configs.voice_parameters(n)
+    ty = np.full(n, float(L.SVF_LOW))
+    ty[64:128] = np.arange(64) % 9  # the nine types side by side in the middle wavefront
+    st = [Stage(L.STAGE_INPUT), Stage(L.STAGE_SVF), Stage(L.STAGE_MUL_CONST)]
+    w = configs.Workload("lowedge", st, n, bs, sample_type, 1, in_channels=1)
+    w.ctor = {0: np.zeros((n, 1)), 1: np.stack([ty, p["cutoff"], p["q"], np.full(n, 3.0)], axis=1), 2: np.full((n, 1), 0.5)}
+    g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    o = make_oracle(oracle, w)
+    dtype = np.float64 if sample_type == L.F64 else np.float32
+    tiny = np.finfo(dtype).smallest_subnormal
+    big = np.finfo(dtype).max
+    rng = np.random.default_rng(11)
+    ins = (0.5 * rng.standard_normal((nb, 1, bs))).astype(dtype)
+    ins[1, 0, :] = 0.0
+    ins[1, 0, 5:9] = -0.0
+    ins[1, 0, 20:40] = (rng.integers(-3, 4, 20) * tiny).astype(dtype)          # subnormal steps around zero
+    ins[2, 0, :] = (rng.standard_normal(bs) * 1e-3).astype(dtype) * tiny * 1e3   # a signal that lives among the subnormals
+    ins[3, 0, :] = 0.0                                                          # the state decays through them
+    if poison == "overflow":
+        ins[4, 0, 17] = big
+        ins[4, 0, 18] = -big                                                    # overflows inside the filter
+    else:
+        ins[4, 0, 21] = np.inf if poison == "inf" else np.nan                   # (block 5: the filter never recovers)
+    with np.errstate(all="ignore"):
+        for b in range(nb):
+            g.set_input(ins[b])
+            o.set_input(ins[b])
+            g_out, g_voices, _ = g.process_block_voices()
+            o_out, o_voices, _, _ = o.process_block()
+            assert_same_class_or_bits(g_voices, o_voices, f"block {b} per-voice")
+            if b < 4:
+                assert_bit_equal(g_out, o_out, f"block {b} mix")
+    assert np.isnan(o_voices).any()
+    g.close()
+    o.close()
+
+
 def test_ring_modulating_the_node_input_and_driving_a_frequency_with_it(knh, oracle):
     """Graph-shaped voices on an input: input 0 times a per-voice oscillator; and (input 1 * depth + f0) as the audio-rate
     frequency of a SinWt (.ar_params() + link, audio_rate.rs:42-57) -- the set_ar_param_buffer case."""
