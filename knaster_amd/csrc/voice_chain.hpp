@@ -156,8 +156,20 @@ struct SinWtT : StageDefaults {
   }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    if constexpr (AR_FREQ) {
 #pragma unroll
-    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+      for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+    } else {
+      // phase + phase_offset as ONE running sum over the tile (u32 arithmetic wraps, so the phase afterwards is that sum
+      // minus the offset): add, shift, mask, read per sample
+      u32 q = r.phase + r.off;
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        x[j] = (F)c.sine[(q >> 16) & 16383u];
+        q += r.inc;
+      }
+      r.phase = q - r.off;
+    }
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
@@ -872,17 +884,25 @@ struct Svf : StageDefaults {
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = false;
   static constexpr bool kHasSeg = false;
-  template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m0, m1, m2; };
+  // nl ("not low"): zero iff the output mix is the low-pass one (m0 = 0, m1 = 0, m2 = 1 to the bit), kept beside the three so
+  // that the per-tile choice of the step (low_pass() below) looks at one register, not at three that are otherwise idle in
+  // that step -- which the register allocator therefore keeps in scratch memory, a memory round trip per tile away
+  template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m0, m1, m2; typename WordOf<F>::type nl; };
+  template <typename R> static __device__ __forceinline__ void note_mix(R& r) {
+    r.nl = (f_to_word(r.m0) | f_to_word(r.m1)) | (f_to_word(r.m2) ^ f_to_word((decltype(r.m2))1));
+  }
   static constexpr u32 kParamMask = 0b11111100u;  // the six coefficients (every setter recomputes them on the host)
   template <typename R> static __device__ __forceinline__ void take_params(R& r, const R& n, bool c) {
     r.a1 = c ? n.a1 : r.a1; r.a2 = c ? n.a2 : r.a2; r.a3 = c ? n.a3 : r.a3;
     r.m0 = c ? n.m0 : r.m0; r.m1 = c ? n.m1 : r.m1; r.m2 = c ? n.m2 : r.m2;
+    r.nl = c ? n.nl : r.nl;
   }
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
     r.ic1 = word_to_f<F>(s[0]); r.ic2 = word_to_f<F>(s[st]); r.a1 = word_to_f<F>(s[2 * st]);
     r.a2 = word_to_f<F>(s[3 * st]); r.a3 = word_to_f<F>(s[4 * st]); r.m0 = word_to_f<F>(s[5 * st]);
     r.m1 = word_to_f<F>(s[6 * st]); r.m2 = word_to_f<F>(s[7 * st]);
+    note_mix(r);
   }
   template <typename F, typename W>
   static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long st) {
@@ -978,8 +998,8 @@ struct Svf : StageDefaults {
   // between two register pairs for that), (ic1', ic2'), and one s_nop for the wait state nothing is left to fill.
   template <typename F> static __device__ __forceinline__ bool low_pass(const Regs<F>& r) {
     typedef typename WordOf<F>::type W;
-    const W one = sizeof(F) == 4 ? (W)0x3F800000u : (W)0x3FF0000000000000ull, neg0 = (W)1 << (sizeof(F) * 8 - 1);
-    const bool mine = (f_to_word(r.m0) | f_to_word(r.m1)) == 0 && f_to_word(r.m2) == one && f_to_word(r.ic2) != neg0;
+    const W neg0 = (W)1 << (sizeof(F) * 8 - 1);
+    const bool mine = r.nl == 0 && f_to_word(r.ic2) != neg0;
     return __builtin_amdgcn_ballot_w64(!mine) == 0;
   }
   template <int T>
@@ -1105,10 +1125,11 @@ struct Svf : StageDefaults {
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32 rel, u64 bits, u32 /*frame*/) {
     if ((op & 0x7Fu) != EV_SET) return;
     F v = word_to_f<F>((typename WordOf<F>::type)bits);
-    switch (rel) {
-      case 0: r.ic1 = v; break; case 1: r.ic2 = v; break; case 2: r.a1 = v; break; case 3: r.a2 = v; break;
-      case 4: r.a3 = v; break; case 5: r.m0 = v; break; case 6: r.m1 = v; break; default: r.m2 = v; break;
-    }
+    // (selects, not a switch: a switch over the fields becomes an indexed store into the struct, which then lives in
+    // scratch memory -- and every tile waits for a scratch load of its coefficients)
+    r.ic1 = rel == 0 ? v : r.ic1; r.ic2 = rel == 1 ? v : r.ic2; r.a1 = rel == 2 ? v : r.a1; r.a2 = rel == 3 ? v : r.a2;
+    r.a3 = rel == 4 ? v : r.a3; r.m0 = rel == 5 ? v : r.m0; r.m1 = rel == 6 ? v : r.m1; r.m2 = rel >= 7 ? v : r.m2;
+    note_mix(r);
   }
 };
 
@@ -1899,8 +1920,20 @@ struct ValT : StageDefaults {
   }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    if constexpr (sizeof(F) == 4 && OP <= 2 && T % 2 == 0) {
+      // two neighbouring samples to a packed instruction (v_pk_mul_f32 / v_pk_add_f32: the same roundings)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 v = {r.v, r.v};
 #pragma unroll
-    for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+      for (int j = 0; j < T; j += 2) {
+        f2 p = {x[j], x[j + 1]};
+        p = OP == 0 ? p * v : (OP == 1 ? p + v : p - v);
+        x[j] = p.x; x[j + 1] = p.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+    }
   }
   template <typename F>
   static __device__ __forceinline__ void on_event(Regs<F>& r, u32 op, u32, u64 bits, u32 /*frame*/) {
@@ -2369,9 +2402,16 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 16 ? 4 : (WAVES >= 8 ? 2 : 1));
   constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
                                                 // writes (ds_write_b32) and row reads (ds_read_b128)
-  __shared__ float sine[ChainT::kUsesSine ? 16384 : 1];
-  __shared__ __attribute__((aligned(16))) F tile[WAVES][TN][TS];
-  __shared__ __attribute__((aligned(16))) F pan_gain[ChainT::kPan ? WAVES : 1][2][ChainT::kPan ? 64 : 1];  // [wave][left, right][voice]
+  // (one LDS object with the table first: the table at LDS address 0, a table read's address is the masked phase itself)
+  struct Lds {
+    float sine[ChainT::kUsesSine ? 16384 : 4];
+    __attribute__((aligned(16))) F tile[WAVES][TN][TS];
+    __attribute__((aligned(16))) F pan_gain[ChainT::kPan ? WAVES : 1][2][ChainT::kPan ? 64 : 1];  // [wave][left, right][voice]
+  };
+  __shared__ Lds lds;
+  auto& sine = lds.sine;
+  auto& tile = lds.tile;
+  auto& pan_gain = lds.pan_gain;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;

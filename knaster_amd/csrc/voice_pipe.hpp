@@ -527,18 +527,26 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
   static_assert(GPW == 1 || GPW == 2, "one or two voice groups per workgroup");
   static_assert(T <= 64 && T % 8 == 0, "a tile column per lane of the folding wavefront");
   constexpr bool kSine = (false || ... || GroupInfo<Gs>::uses_sine);
-  __shared__ float sine[kSine ? 16384 : 1];
   // the last edge feeds the mixer; with PIPE_FOLD it is one buffer private to the last group, with PIPE_INPLACE there is none
   // (the edge before it has three buffers instead)
   constexpr long kEdgeElems = (long)EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile;  // per voice group
-  __shared__ __attribute__((aligned(16))) F edge[GPW * kEdgeElems];
   // what is left of the CU's 160 KiB holds the workgroup's events (16 bytes each), up to 2 048 of them
-  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 1) - (long)sizeof(F) * GPW * kEdgeElems;
+  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 4) - (long)sizeof(F) * GPW * kEdgeElems;
 #ifndef KNH_EVCAP_MAX
 #define KNH_EVCAP_MAX 2048
 #endif
   constexpr int kEvCap = kLdsFree < 16 ? 0 : (kLdsFree / 16 > KNH_EVCAP_MAX ? KNH_EVCAP_MAX : (int)(kLdsFree / 16));
-  __shared__ __attribute__((aligned(16))) Event ev_stage[kEvCap > 0 ? kEvCap : 1];
+  // One LDS object, the sine table first: it then sits at LDS address 0, and a table read's address is the masked phase
+  // itself (the 16-bit offset field of ds_read_b32 cannot hold the table's address behind 85 KiB of tiles; an add per sample could).
+  struct Lds {
+    float sine[kSine ? 16384 : 4];
+    __attribute__((aligned(16))) F edge[GPW * kEdgeElems];
+    __attribute__((aligned(16))) Event ev_stage[kEvCap > 0 ? kEvCap : 1];
+  };
+  __shared__ Lds lds;
+  float* const sine = lds.sine;
+  F* const edge = lds.edge;
+  Event* const ev_stage = lds.ev_stage;
 
   const int lane = threadIdx.x & 63;
   const int wave_all = threadIdx.x >> 6;               // wavefront of the workgroup
