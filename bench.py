@@ -45,11 +45,13 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_OPS = 78.6e12        # 157.3 TFLOP/s FP32 vector counts an FMA as 2: 78.6e12 non-fused ops/s
 OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per voice-sample / 4 UGens
-# The filter wavefront of the C3 pipeline kernel issues ten VALU instructions per sample (five of them packed); a wavefront
-# alone on its SIMD needs 44 shader-clock cycles for those ten (tools/micro/svf_chain.hip, profiles/r01_micro_svf_chain.txt),
-# 18.3 ns at the 2.4 GHz the chip holds under this load (tools/micro/clock_share.hip).  That is the floor of the kernel's
-# time per sample: the serial filter recurrence of one 64-voice group cannot be spread over more wavefronts.
-SVF_STEP_CYCLES = 44.0
+# The filter wavefront of the C3 pipeline kernel issues seven VALU instructions and one wait state per sample of a low-pass
+# filter (four of them packed: Svf::tick_tile_low; the general step of the other eight filter types has nine and a half); a
+# wavefront alone on its SIMD needs 33 shader-clock cycles for them (tools/micro/svf_tile.hip with the low-pass step,
+# profiles/r03_micro_svf_tile_low.txt), 13.9 ns at the 2.4 GHz the chip holds under this load (tools/micro/clock_share.hip).
+# That is the floor of the kernel's time per sample: the serial filter recurrence of one 64-voice group cannot be spread over
+# more wavefronts.
+SVF_STEP_CYCLES = 33.25
 SHADER_CLOCK_GHZ = 2.4
 PIPE_TILE = 64                 # samples per pipeline step of the shipped C3 kernel (voice_pipe.hpp)
 BLOCKS_PER_LAUNCH = 64         # blocks per launch = per RCCL reduce (one note cycle)
@@ -532,10 +534,12 @@ def main():
                 "kernel_ns_per_sample": ns_per_sample,
                 "frac": (SVF_STEP_CYCLES / SHADER_CLOCK_GHZ) / ns_per_sample if ns_per_sample and not args.allow_fma else None,
                 "tile_samples": PIPE_TILE,
-                "note": "floor = the ten instructions of one filter step issued by a wavefront alone on its SIMD (44 cycles, "
-                        "micro-benchmark) at 2.4 GHz; the rest of the kernel's time per sample is that wavefront's LDS hand-over, "
-                        "block/event bookkeeping and the workgroup barrier once per 64-sample tile (the oscillator, envelope and "
-                        "mixer wavefronts on the other three SIMDs are all faster: profiles/r02_pipe_wave_busy_cycles.txt)",
+                "note": "floor = the seven instructions and one wait state of one low-pass filter step issued by a wavefront alone on "
+                        "its SIMD (33 cycles, micro-benchmark) at 2.4 GHz; the rest of the kernel's time per sample is that wavefront's "
+                        "LDS hand-over (16 loads, 16 stores of 1 KiB per 64-sample tile: ~13 cycles per sample, during which it issues "
+                        "nothing else), block/event bookkeeping and the workgroup barrier once per tile.  The oscillator, envelope and "
+                        "mixer wavefronts on the other three SIMDs are all faster and hide behind it "
+                        "(profiles/r03_pipe_wave_busy_cycles.txt, _filter_alone.txt)",
             }
         if world == 1 and not args.no_configs:
             pb = [per_block_boundary("C3"), per_block_boundary("C1", 2048)]
@@ -560,14 +564,15 @@ def main():
                 "ranks_seen_by_rccl": s["ranks_seen"], "output_finite": s["sane"],
                 # What bounds a rank's share (profiles/r03_c4_pipe_wave_busy_cycles.txt, tools/micro/exec_mask_f64.hip): an f64
                 # instruction holds its SIMD for four cycles, so f64 wavefronts are throughput-bound.  Up to 256 voice groups per
-                # GPU (the pipeline, a group per CU) the filter wavefront's 15 f64 instructions per sample (63 cycles) plus its
-                # tile's way through LDS (30) are the floor of a block's time WHATEVER the number of voices -- a GPU with 8 192
-                # voices takes as long per block as one with 16 384; beyond that (one whole-chain wavefront per SIMD) it is the
-                # f64 work of all stages, ~210 SIMD-cycles per voice-group sample.
+                # GPU (the pipeline, a group per CU) the filter wavefront's 11 f64 instructions per sample of a low-pass filter
+                # (46 cycles; 15 = 63 for the other types) plus its tile's way through LDS (30) are the floor of a block's time
+                # WHATEVER the number of voices -- a GPU with 8 192 voices takes as long per block as one with 16 384; beyond
+                # that (one whole-chain wavefront per SIMD) it is the f64 work of all stages, ~190 SIMD-cycles per voice-group
+                # sample.
                 "issue": {
                     "regime": "pipeline: one 64-voice group per CU" if s["voices_rank0"] <= 16384 else ("pipeline, two groups per CU" if s["voices_rank0"] <= 32768 else "one whole-chain wavefront per SIMD"),
-                    "floor_cycles_per_sample": 93.0 if s["voices_rank0"] <= 16384 else 210.0,
-                    "floor_us_per_block": (93.0 if s["voices_rank0"] <= 16384 else 210.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
+                    "floor_cycles_per_sample": 76.0 if s["voices_rank0"] <= 16384 else 190.0,
+                    "floor_us_per_block": (76.0 if s["voices_rank0"] <= 16384 else 190.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
                     "kernel_us_per_block": s["kernel_avg_ms"] * 1e3 / BLOCKS_PER_LAUNCH,
                     "note": "strong scaling of this bank is bounded by the pipeline floor: per-GPU time per block stops falling once a GPU "
                             "holds 16 384 voices or fewer (256 voice groups or fewer: fewer CUs busy, not faster ones)",

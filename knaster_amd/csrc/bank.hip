@@ -71,9 +71,10 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
       const unsigned groups = (d.n_voices + 63u) / 64u;
       const char* penv = std::getenv("KNH_PAIR");
       const knh::PipeEntry* pair = b->entry && level >= 1 ? knh::find_pipe(sig.c_str(), 1u << 2 /* PIPE_INPLACE */, 2) : nullptr;
-      // Measured (us per 512-frame block; C3 f32 at 384 / 512 / 1 024 / 2 048 groups: 19.8 / 20.3 / 38.8 / 76.1 against 26.3 / 26.7 /
-      // 41.1 / 60.2 for the forms of round 2; C4 f64 at 512 / 1 024: 42.9 / 83.7 against 48.8 / 57.2 -- an f64 wavefront alone
-      // already keeps its SIMD's f64 pipe busy, so a second one beside it gains little): f32 up to 1 024 groups, f64 up to 512.
+      // Measured (us per 512-frame block, profiles/r03_form_sweep.txt; C3 f32 at 384 / 512 / 1 024 / 1 536 groups: 17.7 / 18.1 /
+      // 35.1 / 51.9 against 23.4 / 23.6 / 41.1 / 52.5 for the best other form; C4 f64 at 512 / 1 024: 38.8 / 76.6 against
+      // 40.0 / 50.4 -- an f64 wavefront alone already keeps its SIMD's f64 pipe busy, so a second one beside it gains
+      // little): f32 up to 1 024 groups, f64 up to 512.
       const bool want = penv ? penv[0] == '1' : (groups > 256u && groups <= (d.sample_type == KNH_F64 ? 512u : 1024u));
       if (pair && want && !(penv && penv[0] == '0')) { b->pipe = pair; b->pipe_pair = true; }
     }
