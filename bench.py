@@ -505,7 +505,7 @@ def main():
                 # (the library's choice, bank.hip make_bank: the pipeline up to 768 voice groups in f32, 512 in f64)
                 "kernel": ("voice_pipe_kernel<double,false,32,PIPE_INPLACE,...>" if f64 else
                            "voice_pipe_kernel<float,false,64,PIPE_INPLACE,Group<SinWt,MulVal>,Group<Svf>,Group<MulAsr>>")
-                          if nv_rank <= (32768 if f64 else 49152) else "voice_kernel<..., WAVES = 4 or 8, SinWt, MulVal, Svf, MulAsr>",
+                          if nv_rank <= (16384 if f64 else 32768) else "voice_kernel<..., WAVES = 4 or 8, SinWt, MulVal, Svf, MulAsr>",
                 "kernel_avg_ms": kernel_avg_ms, "launches": m["launches"], "blocks_per_launch": float(BLOCKS_PER_LAUNCH),
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "note": "fused kernel moves 92 B (f64: 184 B) per voice per block; it is bound by the instruction issue of its "
@@ -567,15 +567,16 @@ def main():
                 # GPU (the pipeline, a group per CU) the filter wavefront's 11 f64 instructions per sample of a low-pass filter
                 # (46 cycles; 15 = 63 for the other types) plus its tile's way through LDS (30) are the floor of a block's time
                 # WHATEVER the number of voices -- a GPU with 8 192 voices takes as long per block as one with 16 384; beyond
-                # that (one whole-chain wavefront per SIMD) it is the f64 work of all stages, ~190 SIMD-cycles per voice-group
-                # sample.
+                # that (whole-chain wavefronts, four voice groups per workgroup = one wavefront per SIMD up to 65 536 voices) it
+                # is the f64 work of all stages: ~15 f64 instructions (60 cycles) + ~10 others per sample.
                 "issue": {
-                    "regime": "pipeline: one 64-voice group per CU" if s["voices_rank0"] <= 16384 else ("pipeline, two groups per CU" if s["voices_rank0"] <= 32768 else "one whole-chain wavefront per SIMD"),
-                    "floor_cycles_per_sample": 76.0 if s["voices_rank0"] <= 16384 else 190.0,
-                    "floor_us_per_block": (76.0 if s["voices_rank0"] <= 16384 else 190.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
+                    "regime": "pipeline: one 64-voice group per CU" if s["voices_rank0"] <= 16384 else "one whole-chain wavefront per SIMD",
+                    "floor_cycles_per_sample": 76.0 if s["voices_rank0"] <= 16384 else 80.0,
+                    "floor_us_per_block": (76.0 if s["voices_rank0"] <= 16384 else 80.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
                     "kernel_us_per_block": s["kernel_avg_ms"] * 1e3 / BLOCKS_PER_LAUNCH,
-                    "note": "strong scaling of this bank is bounded by the pipeline floor: per-GPU time per block stops falling once a GPU "
-                            "holds 16 384 voices or fewer (256 voice groups or fewer: fewer CUs busy, not faster ones)",
+                    "note": "strong scaling of this bank: per-GPU time per block is flat from 65 536 down to 16 385 voices per GPU (fewer "
+                            "SIMDs busy, not faster ones), drops once a GPU's share fits the pipeline (16 384 voices or fewer: a 64-voice "
+                            "group per CU) and is flat again below that",
                 },
                 "per_rank": {"kernel_ms_per_launch": [r[0] for r in s["per_rank"]], "reduce_ms_per_launch": [r[1] for r in s["per_rank"]],
                              "voices": [r[2] for r in s["per_rank"]]},

@@ -71,24 +71,25 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
       const unsigned groups = (d.n_voices + 63u) / 64u;
       const char* penv = std::getenv("KNH_PAIR");
       const knh::PipeEntry* pair = b->entry && level >= 1 ? knh::find_pipe(sig.c_str(), 1u << 2 /* PIPE_INPLACE */, 2) : nullptr;
-      // Measured (us per 512-frame block, profiles/r03_form_sweep.txt; C3 f32 at 384 / 512 / 1 024 / 1 536 groups: 17.7 / 18.1 /
-      // 35.1 / 51.9 against 23.4 / 23.6 / 41.1 / 52.5 for the best other form; C4 f64 at 512 / 1 024: 38.8 / 76.6 against
-      // 40.0 / 50.4 -- an f64 wavefront alone already keeps its SIMD's f64 pipe busy, so a second one beside it gains
-      // little): f32 up to 1 024 groups, f64 up to 512.
-      const bool want = penv ? penv[0] == '1' : (groups > 256u && groups <= (d.sample_type == KNH_F64 ? 512u : 1024u));
+      // Measured (us per 512-frame block, profiles/r03_form_sweep.txt): C3 f32 at 320 / 512 groups 17.8 / 18.5 against 23.5 / 23.8
+      // for one group per workgroup and 25.5 / 25.8 for four whole-chain wavefronts per workgroup; from 640 groups on the latter
+      // win (26.1-27.1 up to 1 024 groups against 34.7-35.1).  f64 gains nothing from it (38.6-39.1 against 37.0-37.2: an f64
+      // wavefront alone already keeps its SIMD's f64 pipe busy).  So: f32 banks of 257-512 groups.
+      const bool want = penv ? penv[0] == '1' : (groups > 256u && groups <= 512u && d.sample_type != KNH_F64);
       if (pair && want && !(penv && penv[0] == '0')) { b->pipe = pair; b->pipe_pair = true; }
     }
     b->wide = b->entry && !b->pipe_pair ? knh::find_wide(sig.c_str()) : nullptr;
     if (b->wide) {
       const unsigned groups = (d.n_voices + 63u) / 64u;
       // The pipeline takes ceil(groups / 256 CUs) rounds of its one-group-per-CU time, the 4-group kernel one round of the
-      // whole chain's single-wavefront time up to 1 024 groups.  Measured on C3 / C4 (us per 512-frame block at 256, 384, 512,
-      // 768, 1 024 groups): f32 pipeline 13.9 26.3 27.0 39.8 52.5 against 41-42 flat; f64 24.6 47.4 47.8 70.7 94.0 against
-      // 55-57 flat.  So: three rounds of the pipeline in f32, two in f64.
-      const unsigned pipe_max = d.sample_type == KNH_F64 ? 512u : 768u;
-      // (sixteen groups per workgroup -- four wavefronts per SIMD -- once they fill the chip: measured 110.6 -> 101.3 us per block
-      // at 4 096 groups, 218.6 -> 197.8 at 8 192, f32; at 2 048 groups they would leave half the CUs idle; f64 gains nothing)
-      int ww = groups <= pipe_max && b->pipe ? 0 : (groups <= 1024 ? 4 : (groups >= 4096 && d.sample_type == KNH_F32 ? 16 : 8));
+      // whole chain's single-wavefront time up to 1 024 groups, the 8-group kernel one of two wavefronts per SIMD up to 2 048.
+      // Measured on C3 / C4 (us per 512-frame block, profiles/r03_form_sweep.txt): f32 pipeline 23.5 at 257-512 groups, 35 at
+      // 513-768, against 25.5-27.1 flat for four groups per workgroup and 37-40 for eight (79.6 at 4 096 groups, where sixteen
+      // take 85.6 -- their tiles are too short for the 32-sample visits the others make); f64 pipeline 39.6-40.1 at 257-512
+      // groups against 37.0-38.7 flat for four per workgroup, 68-72 for eight up to 2 048.  So: the pipeline for two rounds in
+      // f32, one in f64; four groups per workgroup up to 1 024 groups, eight beyond.
+      const unsigned pipe_max = d.sample_type == KNH_F64 ? 256u : 512u;
+      int ww = groups <= pipe_max && b->pipe ? 0 : (groups <= 1024 ? 4 : 8);
       if (!b->pipe && groups <= 256) ww = 0;
       // a delay line wants the pipeline's 32-sample tiles (whole 128-byte lines per visit, reads one tile ahead):
       // measured 1.37e12 against 0.88e12 UGen-samples/s at 262 144 voices

@@ -2400,6 +2400,10 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   typedef typename WordOf<F>::type W;
   // frames per reduce tile: sized so that WAVES tiles + the sine table fit the CU's 160 KiB of LDS
   constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 16 ? 4 : (WAVES >= 8 ? 2 : 1));
+  // samples evaluated stage by stage in registers per visit: up to 32 in the many-groups-per-workgroup forms (the per-visit costs --
+  // event test, the filter's choice of step, register set-up around its fixed-register code -- are paid a quarter as often as with
+  // eight: 53.7 -> 39.9 us per block at 131 072 voices, C4's 65 536 f64 voices 50.5 -> 38.0), eight in the one-wavefront kernel
+  constexpr int KT = WAVES >= 4 ? (TN < 32 ? TN : 32) : kTile;
   constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
                                                 // writes (ds_write_b32) and row reads (ds_read_b128)
   // (one LDS object with the table first: the table at LDS address 0, a table read's address is the masked phase itself)
@@ -2480,21 +2484,21 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
     F* partial_row = a.partials + ((long)b * n_waves_total + wave_global) * a.block_size;
     for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {
       const u32 len = a.frame_end - n0 < (u32)TN ? a.frame_end - n0 : (u32)TN;
-      for (u32 j0 = 0; j0 < len; j0 += kTile) {
+      for (u32 j0 = 0; j0 < len; j0 += KT) {
         const u32 n = n0 + j0;
         apply_events_upto(base + n);
-        const bool full = j0 + kTile <= len;
-        const bool ev_inside = nxt.frame < base + n + kTile;
+        const bool full = j0 + KT <= len;
+        const bool ev_inside = nxt.frame < base + n + KT;
         if (full && !__builtin_amdgcn_ballot_w64(ev_inside)) {
-          // fast path: kTile samples, stage by stage, fully unrolled
-          F x[kTile];
+          // fast path: KT samples, stage by stage, fully unrolled
+          F x[KT];
 #pragma unroll
-          for (int j = 0; j < kTile; ++j) x[j] = (F)0;
-          chain.template tick_tile<kTile>(x, ctx, n);
+          for (int j = 0; j < KT; ++j) x[j] = (F)0;
+          chain.template tick_tile<KT>(x, ctx, n);
 #pragma unroll
-          for (int j = 0; j < kTile; ++j) my[j0 + j][lane] = x[j];
+          for (int j = 0; j < KT; ++j) my[j0 + j][lane] = x[j];
         } else {
-          const u32 m = len - j0 < (u32)kTile ? len - j0 : (u32)kTile;
+          const u32 m = len - j0 < (u32)KT ? len - j0 : (u32)KT;
           for (u32 j = 0; j < m; ++j) {
             apply_events_upto(base + n + j);
             my[j0 + j][lane] = chain.tick((F)0, ctx, n + j);
