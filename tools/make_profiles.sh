@@ -14,6 +14,12 @@ echo "== kernel trace + stats"
 rm -rf "$OUT/stats"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" || { tail -5 "$OUT/stats.err"; exit 1; }
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
+find "$OUT/stats" -name "*kernel_trace.csv" -exec python3 "$ROOT/tools/trace_summary.py" {} \; > "$OUT/bench_kernel_trace_summary.json"
+echo "== kernel stats of the headline launches alone (no per-block / C1 / C2 / C5 / C4 legs: every launch of the kernel is a 64-block one)"
+rm -rf "$OUT/stats_h"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_h" -o bench -- $BENCH --no-configs --no-c4 --no-cpu-baseline > "$OUT/bench_headline_only_under_rocprof.json" 2> "$OUT/stats_h.err" || { tail -5 "$OUT/stats_h.err"; exit 1; }
+find "$OUT/stats_h" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_headline_only_kernel_stats.csv" \;
+rm -rf "$OUT/stats_h"
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $C"
   rm -rf "$OUT/pmc_$C"
