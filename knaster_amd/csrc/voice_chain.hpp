@@ -777,6 +777,17 @@ struct SinNum : StageDefaults {
   static __device__ __forceinline__ void store(const Regs<F>& r, W* s, long) { s[0] = f_to_word(r.phase); }
   static __device__ __forceinline__ float sin_f(float v) { return __ocml_sin_f32(v); }
   static __device__ __forceinline__ double sin_f(double v) { return __ocml_sin_f64(v); }
+  // (p * TAU).sin() for a phase p in revolutions (osc.rs:264).  f32: v_sin_f32 IS sin(2 pi x) of an argument in revolutions,
+  // one instruction for the device library's forty.  Over every f32 p of [0, 2) it is within 8.7e-7 of the reference's value
+  // -- glibc's sinf of the f32-rounded product -- and within 1.3e-7 of the exact sine (the reference's own rounding of p * TAU
+  // is the larger part of the difference): tools/micro/hw_sin.hip, profiles/r03_micro_hw_sin.txt.  Beyond |p| < 2 (a phase
+  // offset of several turns, a negative frequency running away) the reference's argument rounding grows with |p| and must be
+  // reproduced to stay within tolerance: those wavefronts take the library's sinf of the rounded product, as before.
+  static __device__ __forceinline__ float sin_turns(float p) {
+    if (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(p) < 2.0f)) == 0) return __builtin_amdgcn_sinf(p);
+    return __ocml_sin_f32(p * 6.28318530717958647692f);
+  }
+  static __device__ __forceinline__ double sin_turns(double p) { return __ocml_sin_f64(p * 6.28318530717958647692); }
   // SinNumeric::freq (osc.rs:240-242: F::new(freq) / F::new(sample_rate as f32)) / ::phase_offset (:244-247)
   template <typename F, int P>
   static __device__ __forceinline__ void ar_set(Regs<F>& r, F v, const Ctx& c) {
@@ -785,8 +796,7 @@ struct SinNum : StageDefaults {
   }
   template <typename F, bool FMA>
   static __device__ __forceinline__ F tick(Regs<F>& r, F, const Ctx&, u32, u32&) {
-    const F TAU = (F)6.28318530717958647692;
-    F out = sin_f((r.phase + r.off) * TAU);
+    F out = sin_turns(r.phase + r.off);
     r.phase += r.inc;
     if (r.phase > (F)1) r.phase -= (F)1;
     return out;
@@ -864,8 +874,7 @@ struct SinMap : StageDefaults {
   template <typename F, typename W> static __device__ __forceinline__ void store(const Regs<F>&, W*, long) {}
   template <typename F, bool FMA>
   static __device__ __forceinline__ F tick(Regs<F>&, F p, const Ctx&, u32, u32&) {
-    const F TAU = (F)6.28318530717958647692;
-    return SinNum::sin_f(p * TAU);
+    return SinNum::sin_turns(p);
   }
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {

@@ -71,10 +71,31 @@ def test_c4_f64_chain_bit_exact(knh, oracle):
 
 def test_c2_sin_numeric_within_tolerance(knh, oracle):
     w = configs.config("C2", n_voices=256, block_size=256)
-    # device sin vs glibc sinf: not bit-exact by design; phase accumulation is, so errors do not grow
-    run_pair(knh, oracle, w, 6, voice_tol=1e-5 / 256 * 4)
+    # the device's sine (f32: v_sin_f32 on the phase in revolutions, within 8.7e-7 of glibc's sinf of the rounded product over
+    # every phase of [0, 2): tools/micro/hw_sin.hip) is not bit-exact by design; the phase accumulation is, so errors do not
+    # grow.  The tolerance is the north star's 1e-5 on a full-scale sine (the voices' gain is 1/256).
+    run_pair(knh, oracle, w, 6, voice_tol=1e-5 / 256)
     w64 = configs.config("C2", n_voices=64, block_size=256, sample_type=L.F64)
     run_pair(knh, oracle, w64, 3, voice_tol=1e-12)
+
+
+@pytest.mark.parametrize("form", ["single", "pipe"])
+def test_sin_numeric_phases_of_several_turns(knh, oracle, monkeypatch, form):
+    """A phase offset of several turns, a negative frequency running away from zero: the reference's f32 rounding of
+    (phase + offset) * TAU grows with the phase and is part of its value; the device then takes the library sine of the same
+    rounded product (SinNum::sin_turns), still within 1e-5 of the reference -- at 40 turns the exact sine is 1e-5 away."""
+    monkeypatch.setenv("KNH_PIPELINE", "0" if form == "single" else "1")
+    n = 192
+    w = configs.config("C2", n_voices=n, block_size=256)
+    w.ctor[0][64:128, 0] *= -1.0      # negative frequencies: the phase only wraps above one (osc.rs:266-268)
+    off = np.zeros(n)
+    off[:64] = np.linspace(1.5, 40.0, 64)   # some below two turns (the hardware sine), most above
+    off[128:] = np.linspace(-40.0, -1.5, 64)
+
+    def ev(block, bank):
+        if block == 0:
+            bank.param_apply_many(np.arange(n, dtype=np.uint32), 0, 1, L.VALUE_FLOAT, off)
+    run_pair(knh, oracle, w, 8, ev, voice_tol=1e-5 / n)
 
 
 def test_c5_audio_rate_fm_with_sample_accurate_changes(knh, oracle):
