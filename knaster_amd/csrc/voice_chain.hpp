@@ -895,8 +895,10 @@ struct Svf : StageDefaults {
   static constexpr bool kHasSeg = false;
   // nl ("not low"): zero iff the output mix is the low-pass one (m0 = 0, m1 = 0, m2 = 1 to the bit), kept beside the three so
   // that the per-tile choice of the step (low_pass() below) looks at one register, not at three that are otherwise idle in
-  // that step -- which the register allocator therefore keeps in scratch memory, a memory round trip per tile away
-  template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m0, m1, m2; typename WordOf<F>::type nl; };
+  // that step.  m0 is NOT next to m1, m2 on purpose: as neighbours the three were accessed as overlapping two-float vectors
+  // -- (m0, m1) where they are loaded, (m1, m2) where the packed step wants them -- and a struct slice with overlapping vector
+  // accesses is not promoted to registers: it became a 12-byte object in scratch memory, a memory round trip per tile away.
+  template <typename F> struct Regs { F ic1, ic2, a1, a2, a3, m1, m2; typename WordOf<F>::type nl; F m0; };
   template <typename R> static __device__ __forceinline__ void note_mix(R& r) {
     r.nl = (f_to_word(r.m0) | f_to_word(r.m1)) | (f_to_word(r.m2) ^ f_to_word((decltype(r.m2))1));
   }
