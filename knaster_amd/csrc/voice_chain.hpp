@@ -2411,10 +2411,10 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   typedef typename WordOf<F>::type W;
   // frames per reduce tile: sized so that WAVES tiles + the sine table fit the CU's 160 KiB of LDS
   constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 16 ? 4 : (WAVES >= 8 ? 2 : 1));
-  // samples evaluated stage by stage in registers per visit: up to 32 in the many-groups-per-workgroup forms (the per-visit costs --
-  // event test, the filter's choice of step, register set-up around its fixed-register code -- are paid a quarter as often as with
-  // eight: 53.7 -> 39.9 us per block at 131 072 voices, C4's 65 536 f64 voices 50.5 -> 38.0), eight in the one-wavefront kernel
-  constexpr int KT = WAVES >= 4 ? (TN < 32 ? TN : 32) : kTile;
+  // samples evaluated stage by stage in registers per visit: up to 32 (the per-visit costs -- event test, the filter's choice of
+  // step, register set-up around its fixed-register code -- are paid a quarter as often as with the eight of rounds 1-2:
+  // 53.7 -> 39.9 us per block at 131 072 voices, C4's 65 536 f64 voices 50.5 -> 38.0, C1's one voice 2.43 -> 1.94)
+  constexpr int KT = TN < 32 ? TN : 32;
   constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
                                                 // writes (ds_write_b32) and row reads (ds_read_b128)
   // (one LDS object with the table first: the table at LDS address 0, a table read's address is the masked phase itself)
