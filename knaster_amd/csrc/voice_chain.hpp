@@ -782,10 +782,16 @@ struct SinNum : StageDefaults {
   // -- glibc's sinf of the f32-rounded product -- and within 1.3e-7 of the exact sine (the reference's own rounding of p * TAU
   // is the larger part of the difference): tools/micro/hw_sin.hip, profiles/r03_micro_hw_sin.txt.  Beyond |p| < 2 (a phase
   // offset of several turns, a negative frequency running away) the reference's argument rounding grows with |p| and must be
-  // reproduced to stay within tolerance: those wavefronts take the library's sinf of the rounded product, as before.
+  // reproduced to stay within tolerance: those samples take the library's sinf of the rounded product, as before.
+  // (the choice is per voice and sample: which voices share a wavefront does not change anyone's value)
   static __device__ __forceinline__ float sin_turns(float p) {
-    if (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(p) < 2.0f)) == 0) return __builtin_amdgcn_sinf(p);
-    return __ocml_sin_f32(p * 6.28318530717958647692f);
+    const bool far = !(__builtin_fabsf(p) < 2.0f);
+    float y = __builtin_amdgcn_sinf(p);
+    if (__builtin_amdgcn_ballot_w64(far) != 0) {
+      const float lib = __ocml_sin_f32(p * 6.28318530717958647692f);
+      y = far ? lib : y;
+    }
+    return y;
   }
   static __device__ __forceinline__ double sin_turns(double p) { return __ocml_sin_f64(p * 6.28318530717958647692); }
   // SinNumeric::freq (osc.rs:240-242: F::new(freq) / F::new(sample_rate as f32)) / ::phase_offset (:244-247)

@@ -98,6 +98,30 @@ def test_sin_numeric_phases_of_several_turns(knh, oracle, monkeypatch, form):
     run_pair(knh, oracle, w, 8, ev, voice_tol=1e-5 / n)
 
 
+def test_sin_numeric_value_does_not_depend_on_the_wavefront_mates(knh, monkeypatch):
+    """Which sine a sample takes (hardware below two turns, library beyond) is decided per voice and sample, so a voice's signal
+    is the same whoever shares its wavefront: every voice alone in a bank against all of them in one, in both kernel forms."""
+    n = 70
+    w = configs.config("C2", n_voices=n, block_size=64)
+    off = np.where(np.arange(n) % 3 == 0, 17.25, 0.125)   # every third voice far out, its neighbours not
+    many = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("KNH_PIPELINE", form)
+        g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+        g.param_apply_many(np.arange(n, dtype=np.uint32), 0, 1, L.VALUE_FLOAT, off)
+        _, many[form], _ = g.process_block_voices()
+        g.close()
+    assert_bit_equal(many["0"], many["1"], "single-wave against pipelined")
+    for v in (0, 1, 3, 64, 69):
+        w1 = configs.config("C2", n_voices=1, block_size=64)
+        w1.ctor = {0: w.ctor[0][v:v + 1], 1: w.ctor[1][v:v + 1]}
+        g = make_gpu(knh, w1, L.MIX_LEFT_FOLD)
+        g.param_apply_many(np.zeros(1, dtype=np.uint32), 0, 1, L.VALUE_FLOAT, off[v:v + 1])
+        _, alone, _ = g.process_block_voices()
+        g.close()
+        assert_bit_equal(alone[0], many["1"][v], f"voice {v} alone")
+
+
 def test_c5_audio_rate_fm_with_sample_accurate_changes(knh, oracle):
     w = configs.config("C5", n_voices=192, block_size=128)
 
