@@ -157,8 +157,16 @@ struct SinWtT : StageDefaults {
   template <typename F, bool FMA, int T>
   static __device__ __forceinline__ void tick_tile(Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
     if constexpr (AR_FREQ) {
+      // the same running sum with the driving signal's increment per sample (audio_rate.rs:42-57: the setter, then the sample)
+      u32 q = r.phase + r.off, inc = r.inc;
 #pragma unroll
-      for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+      for (int j = 0; j < T; ++j) {
+        inc = sat_u32((double)x[j] * c.f2pi);
+        x[j] = (F)c.sine[(q >> 16) & 16383u];
+        q += inc;
+      }
+      r.inc = inc;
+      r.phase = q - r.off;
     } else {
       // phase + phase_offset as ONE running sum over the tile (u32 arithmetic wraps, so the phase afterwards is that sum
       // minus the offset): add, shift, mask, read per sample
