@@ -568,11 +568,13 @@ def main():
                 # (46 cycles; 15 = 63 for the other types) plus its tile's way through LDS (30) are the floor of a block's time
                 # WHATEVER the number of voices -- a GPU with 8 192 voices takes as long per block as one with 16 384; beyond
                 # that (whole-chain wavefronts, four voice groups per workgroup = one wavefront per SIMD up to 65 536 voices) it
-                # is the f64 work of all stages: ~15 f64 instructions (60 cycles) + ~10 others per sample.
+                # is the f64 work of all stages: 23.6 VALU instructions per voice-sample (SQ counters), ~15 of them f64 at four
+                # SIMD cycles each.  A second wavefront per SIMD buys almost nothing there (eight groups per workgroup at twice
+                # the voices: 168 cycles per wavefront-sample against 178): the SIMD is saturated by one.
                 "issue": {
                     "regime": "pipeline: one 64-voice group per CU" if s["voices_rank0"] <= 16384 else "one whole-chain wavefront per SIMD",
-                    "floor_cycles_per_sample": 76.0 if s["voices_rank0"] <= 16384 else 80.0,
-                    "floor_us_per_block": (76.0 if s["voices_rank0"] <= 16384 else 80.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
+                    "floor_cycles_per_sample": 76.0 if s["voices_rank0"] <= 16384 else 90.0,
+                    "floor_us_per_block": (76.0 if s["voices_rank0"] <= 16384 else 90.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
                     "kernel_us_per_block": s["kernel_avg_ms"] * 1e3 / BLOCKS_PER_LAUNCH,
                     "note": "strong scaling of this bank: per-GPU time per block is flat from 65 536 down to 16 385 voices per GPU (fewer "
                             "SIMDs busy, not faster ones), drops once a GPU's share fits the pipeline (16 384 voices or fewer: a 64-voice "
