@@ -2509,25 +2509,35 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
     F* partial_row = a.partials + ((long)b * n_waves_total + wave_global) * a.block_size;
     for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {
       const u32 len = a.frame_end - n0 < (u32)TN ? a.frame_end - n0 : (u32)TN;
-      for (u32 j0 = 0; j0 < len; j0 += KT) {
+      // visits of KT samples where a whole one fits and no voice of the wavefront has a change inside it, of eight samples
+      // where that holds for eight (the rest of a tile that is not a multiple of KT long, the neighbourhood of a change),
+      // sample by sample (changes applied in front of their frame) for what is left
+      for (u32 j0 = 0; j0 < len;) {
         const u32 n = n0 + j0;
         apply_events_upto(base + n);
-        const bool full = j0 + KT <= len;
-        const bool ev_inside = nxt.frame < base + n + KT;
-        if (full && !__builtin_amdgcn_ballot_w64(ev_inside)) {
-          // fast path: KT samples, stage by stage, fully unrolled
+        if (j0 + KT <= len && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + KT)) {
           F x[KT];
 #pragma unroll
           for (int j = 0; j < KT; ++j) x[j] = (F)0;
           chain.template tick_tile<KT>(x, ctx, n);
 #pragma unroll
           for (int j = 0; j < KT; ++j) my[j0 + j][lane] = x[j];
+          j0 += KT;
+        } else if (KT > kTile && j0 + kTile <= len && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + kTile)) {
+          F x[kTile];
+#pragma unroll
+          for (int j = 0; j < kTile; ++j) x[j] = (F)0;
+          chain.template tick_tile<kTile>(x, ctx, n);
+#pragma unroll
+          for (int j = 0; j < kTile; ++j) my[j0 + j][lane] = x[j];
+          j0 += kTile;
         } else {
-          const u32 m = len - j0 < (u32)KT ? len - j0 : (u32)KT;
+          const u32 m = len - j0 < (u32)kTile ? len - j0 : (u32)kTile;
           for (u32 j = 0; j < m; ++j) {
             apply_events_upto(base + n + j);
             my[j0 + j][lane] = chain.tick((F)0, ctx, n + j);
           }
+          j0 += m;
         }
       }
       // Transposed reduce: lane j folds frame j over the wave's voices in voice order.
