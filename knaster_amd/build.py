@@ -19,7 +19,7 @@ SOURCES = ["kernels_pipe.hip", "kernels_single.hip", "kernels_wide.hip", "kernel
 # kernels take the longest to compile; side by side they take a third of the time)
 UNITS = [("kernels_pipe.hip", "kernels_pipe_mixer.o", ["-DKNH_PIPE_PART=0"]), ("kernels_pipe.hip", "kernels_pipe_fold.o", ["-DKNH_PIPE_PART=1"]),
          ("kernels_pipe.hip", "kernels_pipe_inplace.o", ["-DKNH_PIPE_PART=2"])] + [(s, s.replace(".hip", ".o"), []) for s in SOURCES[1:]]
-HEADERS = ["stage_table.hpp", "bank_base.hpp", "voice_bank.hpp", "chain_signature.hpp", "voice_chain.hpp", "voice_pipe.hpp", "voice_frame.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", "rank_bank.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
+HEADERS = ["stage_table.hpp", "bank_base.hpp", "voice_bank.hpp", "chain_signature.hpp", "voice_stages.hpp", "voice_chain.hpp", "voice_pipe.hpp", "voice_frame.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", "rank_bank.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
            os.path.join("..", "build.py")]
 FLAGS = [
     "--offload-arch=gfx950",
@@ -49,9 +49,11 @@ def needs_build() -> bool:
 
 
 def write_jit_source() -> None:
-    """csrc/jit_source.inc: voice_chain.hpp + voice_pipe.hpp as C++ raw string literals, embedded in the library so
+    """csrc/jit_source.inc: voice_stages.hpp + voice_chain.hpp + voice_pipe.hpp + voice_frame.hpp as C++ raw string literals, embedded in the library so
     that chains without a pre-built kernel can be fused at run time by hiprtc (jit.hip), in single-wave or pipelined form."""
-    text = open(os.path.join(CSRC, "voice_chain.hpp")).read()
+    text = open(os.path.join(CSRC, "voice_stages.hpp")).read()
+    chain = open(os.path.join(CSRC, "voice_chain.hpp")).read()
+    text += "\n" + chain.replace("#pragma once", "").replace('#include "voice_stages.hpp"', "")
     pipe = open(os.path.join(CSRC, "voice_pipe.hpp")).read()
     text += "\n" + pipe.replace("#pragma once", "").replace('#include "voice_chain.hpp"', "")
     frame = open(os.path.join(CSRC, "voice_frame.hpp")).read()

@@ -596,7 +596,7 @@ int32_t knh_bank_collective_timing_read(knh_bank* bank, double* reduce_ms, uint6
 int32_t knh_bank_algorithmic_bytes_per_voice_block(const knh_bank* bank, uint32_t* read_bytes, uint32_t* write_bytes) {
   return guarded(nullptr, [&]() -> int32_t {
     if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-    // every slot is read once; mutable slots are written once (masks mirror voice_chain.hpp kMutableMask)
+    // every slot is read once; mutable slots are written once (masks mirror voice_stages.hpp kMutableMask)
     uint32_t r = 0, w = 0;
     const uint32_t word = bank->desc.sample_type == KNH_F64 ? 8 : 4;
     for (const StageInfo& s : bank->stages) {

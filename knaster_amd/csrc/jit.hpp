@@ -1,5 +1,5 @@
 // jit.hpp -- run-time fusion of chains that have no pre-built kernel: the device header
-// (voice_chain.hpp, embedded in the library at build time) is handed to hiprtc with the chain's
+// (voice_stages.hpp + voice_chain.hpp, embedded in the library at build time) is handed to hiprtc with the chain's
 // stage list as template arguments, compiled for gfx950 and cached per process.
 #pragma once
 #include <hip/hip_runtime.h>

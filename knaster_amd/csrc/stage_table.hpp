@@ -211,7 +211,7 @@ struct StageInfo {
 };
 
 // Which (stage kind, float parameter) pairs can be driven at audio rate (knh_stage_desc.ar_param): the setters restated on
-// the device (voice_chain.hpp, ar_set).
+// the device (voice_stages.hpp, ar_set).
 inline bool ar_param_supported(uint16_t kind, uint32_t param) {
   switch (kind) {
     case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: return param <= 1;

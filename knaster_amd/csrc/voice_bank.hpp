@@ -711,7 +711,7 @@ struct Bank final : knh_bank {
           } break;
           case KNH_STAGE_RANDOM_LIN: {  // noise.rs:172-200: new() draws the first value, init() turns freq into a step and draws the second
             uint64_t rng = (a[0] >= 0.0 ? static_cast<uint64_t>(a[0]) : 0u) * 94u + 53u;
-            auto draw = [&rng]() {  // fastrand 2.3.0 Rng::f32 (wyrand), restated: voice_chain.hpp NoiseRng
+            auto draw = [&rng]() {  // fastrand 2.3.0 Rng::f32 (wyrand), restated: voice_stages.hpp NoiseRng
               rng += 0x2d358dccaa6c78a5ull;
               const unsigned __int128 t = static_cast<unsigned __int128>(rng) * static_cast<unsigned __int128>(rng ^ 0x8bb84b93962eacc9ull);
               const uint32_t r = static_cast<uint32_t>(static_cast<uint64_t>(t) ^ static_cast<uint64_t>(t >> 64));
