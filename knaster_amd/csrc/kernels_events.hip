@@ -144,6 +144,10 @@ constexpr int kMaxWrapped = 8;  // device-resolved WrPreciseTiming nodes per voi
 __global__ void __launch_bounds__(64) ev_resolve_kernel(EventResolveArgs a) {
   const u32 v = blockIdx.x * 64u + threadIdx.x;
   if (v >= a.n_voices) return;
+  // the counting passes are through with this voice's counters: zero them for the next launch (no clearing command per launch)
+  a.cnt[v] = 0u;
+  a.val_cnt[v] = 0u;
+  a.cursor[v] = 0u;
   u64* keys = a.keys + a.rec_start[v];
   const u32 n = a.rec_start[v + 1] - a.rec_start[v];
   // arrival order: (block, index) ascending.  A voice's records of one launch are few (BASELINE config C5: sixteen): up to
@@ -235,8 +239,7 @@ __global__ void __launch_bounds__(64) ev_resolve_kernel(EventResolveArgs a) {
 
 hipError_t launch_resolve_events(const EventResolveArgs& a, hipStream_t s) {
   if (a.n_voices == 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(a.cnt, 0, (size_t)a.n_voices * 3u * sizeof(u32), s);  // cnt, val_cnt, cursor: one allocation
-  if (e != hipSuccess) return e;
+  // (cnt, val_cnt, cursor are zero: cleared when they were allocated, and by the last pass of the launch before)
   if (a.n_recs) hipLaunchKernelGGL(ev_count_kernel, dim3((a.n_recs + 255u) / 256u), dim3(256), 0, s, a);
   hipLaunchKernelGGL(ev_scan_kernel, dim3(1), dim3(1024), 0, s, a);
   if (a.n_recs) hipLaunchKernelGGL(ev_scatter_kernel, dim3((a.n_recs + 255u) / 256u), dim3(256), 0, s, a);

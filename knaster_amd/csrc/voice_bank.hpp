@@ -133,9 +133,9 @@ struct Bank final : knh_bank {
   size_t d_keys_cap = 0;
   // The resolver runs on a stream of its own, so that it works on launch k + 1 while the voice kernel of launch k runs; the
   // lists it makes therefore come in two sets, used alternately: a set is rewritten only after the voice kernel that read it
-  // has finished (lists_free), and a voice kernel starts only when its set is complete (ev_ready).
+  // has finished (lists_free), and a voice kernel starts only when its set is complete (recs_done of that launch).
   hipStream_t ev_stream = nullptr;
-  hipEvent_t ev_ready = nullptr, lists_free[2] = {nullptr, nullptr};
+  hipEvent_t lists_free[2] = {nullptr, nullptr};
   bool lists_busy[2] = {false, false};
   uint32_t* d_out_start2[2] = {nullptr, nullptr};
   Event* d_out_events2[2] = {nullptr, nullptr};
@@ -252,10 +252,9 @@ struct Bank final : knh_bank {
     ra.out_start = d_out_start2[set];
     ra.out_events = d_out_events2[set];
     KNH_HIP(knh::launch_resolve_events(ra, ev_stream));
-    KNH_HIP(hipEventRecord(recs_done[b], ev_stream));
+    KNH_HIP(hipEventRecord(recs_done[b], ev_stream));  // the records are read, and the lists complete: one event says both
     recs_busy[b] = true;
-    KNH_HIP(hipEventRecord(ev_ready, ev_stream));
-    KNH_HIP(hipStreamWaitEvent(s, ev_ready, 0));  // the voice kernel reads this set
+    KNH_HIP(hipStreamWaitEvent(s, recs_done[b], 0));  // the voice kernel reads this set
     out_in_use = static_cast<int>(set);
     // the host goes on filling the other buffer
     recs_parity = b ^ 1u;
@@ -336,7 +335,6 @@ struct Bank final : knh_bank {
     void* ev_dev[] = {d_stages, d_armed, d_ev_cnt, d_rec_start, d_out_start2[0], d_out_start2[1], d_keys, d_recs, d_out_events2[0], d_out_events2[1]};
     for (void* p : ev_dev)
       if (p) (void)hipFree(p);
-    if (ev_ready) (void)hipEventDestroy(ev_ready);
     for (hipEvent_t e : lists_free)
       if (e) (void)hipEventDestroy(e);
     if (ev_stream) (void)hipStreamDestroy(ev_stream);
@@ -892,9 +890,9 @@ struct Bank final : knh_bank {
         KNH_HIP(hipMalloc(&d_armed, static_cast<size_t>(n_params_total) * nv * sizeof(uint16_t)));
         KNH_HIP(hipMemset(d_armed, 0, static_cast<size_t>(n_params_total) * nv * sizeof(uint16_t)));
         KNH_HIP(hipMalloc(&d_ev_cnt, static_cast<size_t>(nv) * 3 * sizeof(uint32_t)));
+        KNH_HIP(hipMemset(d_ev_cnt, 0, static_cast<size_t>(nv) * 3 * sizeof(uint32_t)));  // (kept zero by the resolver's last pass)
         KNH_HIP(hipMalloc(&d_rec_start, (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
         KNH_HIP(hipStreamCreateWithFlags(&ev_stream, hipStreamNonBlocking));
-        KNH_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         for (int b = 0; b < 2; ++b) {
           KNH_HIP(hipMalloc(&d_out_start2[b], (static_cast<size_t>(nv) + 1) * sizeof(uint32_t)));
           KNH_HIP(hipEventCreateWithFlags(&recs_done[b], hipEventDisableTiming));
