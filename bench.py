@@ -45,13 +45,13 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_OPS = 78.6e12        # 157.3 TFLOP/s FP32 vector counts an FMA as 2: 78.6e12 non-fused ops/s
 OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per voice-sample / 4 UGens
-# The filter wavefront of the C3 pipeline kernel issues seven VALU instructions and one wait state per sample of a low-pass
-# filter (four of them packed: Svf::tick_tile_low; the general step of the other eight filter types has nine and a half); a
-# wavefront alone on its SIMD needs 33 shader-clock cycles for them (tools/micro/svf_tile.hip with the low-pass step,
-# profiles/r03_micro_svf_tile_low.txt), 13.9 ns at the 2.4 GHz the chip holds under this load (tools/micro/clock_share.hip).
-# That is the floor of the kernel's time per sample: the serial filter recurrence of one 64-voice group cannot be spread over
-# more wavefronts.
-SVF_STEP_CYCLES = 33.25
+# The filter wavefront of the C3 pipeline kernel issues seven VALU instructions per sample of a low-pass filter (four of
+# them packed: Svf::tick_tile_low; the general step of the other eight filter types has nine and a half); a wavefront alone
+# on its SIMD needs 29 shader-clock cycles for them (tools/micro/svf_low_variants.hip, profiles/r03_micro_svf_low_variants.txt:
+# ~4.15 per issue slot), 12.2 ns at the 2.4 GHz the chip holds under this load (tools/micro/clock_share.hip).  That is the
+# floor of the kernel's time per sample: the serial filter recurrence of one 64-voice group cannot be spread over more
+# wavefronts.
+SVF_STEP_CYCLES = 29.25
 SHADER_CLOCK_GHZ = 2.4
 PIPE_TILE = 64                 # samples per pipeline step of the shipped C3 kernel (voice_pipe.hpp)
 BLOCKS_PER_LAUNCH = 64         # blocks per launch = per RCCL reduce (one note cycle)
@@ -534,8 +534,8 @@ def main():
                 "kernel_ns_per_sample": ns_per_sample,
                 "frac": (SVF_STEP_CYCLES / SHADER_CLOCK_GHZ) / ns_per_sample if ns_per_sample and not args.allow_fma else None,
                 "tile_samples": PIPE_TILE,
-                "note": "floor = the seven instructions and one wait state of one low-pass filter step issued by a wavefront alone on "
-                        "its SIMD (33 cycles, micro-benchmark) at 2.4 GHz; the rest of the kernel's time per sample is that wavefront's "
+                "note": "floor = the seven instructions of one low-pass filter step issued by a wavefront alone on "
+                        "its SIMD (29 cycles, micro-benchmark) at 2.4 GHz; the rest of the kernel's time per sample is that wavefront's "
                         "LDS hand-over (16 loads, 16 stores of 1 KiB per 64-sample tile: ~13 cycles per sample, during which it issues "
                         "nothing else), block/event bookkeeping and the workgroup barrier once per tile.  The oscillator, envelope and "
                         "mixer wavefronts on the other three SIMDs are all faster and hide behind it "

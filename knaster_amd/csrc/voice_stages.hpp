@@ -1020,8 +1020,13 @@ struct Svf : StageDefaults {
   //   finite makes v1 = a1*ic1 + a2*(x - ic2) not finite too, so fma(0, v1, v2) -- v2 when v1 is finite, NaN when it is not,
   //   and +0 + v2 = v2 -- is the reference's value in every case, in one instruction.
   // The step is then seven instructions: v3, (a1*ic1, a2*ic1), (a2*v3, a3*v3), ic2 + a2*ic1, (v1, v2), the output of the
-  // sample before (which fills the wait state between the packed add and the packed fma that reads it: (v1, v2) alternate
-  // between two register pairs for that), (ic1', ic2'), and one s_nop for the wait state nothing is left to fill.
+  // sample before ((v1, v2) alternate between two register pairs, so that it can sit between the packed add and the packed
+  // fma that reads the add's result), (ic1', ic2').  The next sample's first instruction reads the packed fma's result with
+  // nothing in between.  The compiler would put an s_nop there (its hazard table takes op_sel_hi of a packed f32 instruction
+  // for a half-register write: the dst_sel forwarding rule of gfx940); the hardware needs none -- the step with and without
+  // it gives the same bits over 1.3e9 samples, and 29.25 against 33.25 cycles per sample for a wavefront alone on its SIMD
+  // (tools/micro/svf_low_variants.hip, profiles/r03_micro_svf_low_variants.txt): an s_nop costs an issue slot like any
+  // instruction.
   template <typename F> static __device__ __forceinline__ bool low_pass(const Regs<F>& r) {
     typedef typename WordOf<F>::type W;
     const W neg0 = (W)1 << (sizeof(F) * 8 - 1);
@@ -1044,8 +1049,7 @@ struct Svf : StageDefaults {
       "v_add_f32 v103, v101, v103\n\t"                                    /* ic2 + a2*ic1                     */   \
       "v_pk_add_f32 " V ", v[102:103], v[104:105]\n\t"                    /* (v1, v2)                         */   \
       "v_fma_f32 %[y" #OUT "], 0, " PL ", " PH "\n\t"                     /* previous: v2 (NaN if v1 is not finite) */ \
-      "v_pk_fma_f32 v[100:101], " V ", 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"         \
-      "s_nop 0\n\t"
+      "v_pk_fma_f32 v[100:101], " V ", 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
 #define KNH_SVF_LOW_A(OUT, IN) KNH_SVF_LOW(OUT, IN, "v[106:107]", "v108", "v109")
 #define KNH_SVF_LOW_B(OUT, IN) KNH_SVF_LOW(OUT, IN, "v[108:109]", "v106", "v107")
 #pragma unroll
@@ -1064,7 +1068,7 @@ struct Svf : StageDefaults {
 #undef KNH_SVF_LOW_A
 #undef KNH_SVF_LOW_B
 #undef KNH_SVF_LOW
-    asm volatile("s_nop 0\n\tv_fma_f32 %[xout], 0, v108, v109" : [xout] "=v"(x[T - 1]) : "{v[108:109]}"(q));
+    asm volatile("v_fma_f32 %[xout], 0, v108, v109" : [xout] "=v"(x[T - 1]) : "{v[108:109]}"(q));
     (void)first_prev;
     r.ic1 = ic.x; r.ic2 = ic.y;
   }
