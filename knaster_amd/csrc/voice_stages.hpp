@@ -963,8 +963,8 @@ struct Svf : StageDefaults {
   // f32 op 1.2x that, an s_nop two thirds of it), so the instruction count of this loop IS the block time of the
   // filter wave.  The order is fixed by hand: the two output adds of sample j-1 sit between the recurrence instructions
   // of sample j, so no instruction reads the result of the packed
-  // instruction right before it (gfx950 needs one wait state there; the compiler cannot check inside asm, the
-  // spacing below provides it).  Halves of a pair cannot be named through asm operands, hence the fixed registers:
+  // instruction right before it (the compiler's rule for packed f32 results; the hardware turned out not to need the wait
+  // state -- see tick_tile_low below -- but the order costs nothing: the step is its nine issue slots either way).  Halves of a pair cannot be named through asm operands, hence the fixed registers:
   //   v[100:101] (ic1, ic2)   v[102:103] P1   v[104:105] P2   v[106:107] (v1, v2)   v[108:109] (m1*v1, m2*v2)
   //   v112 m0*x + m1*v1 of the sample before   v114 v3
   template <int T>
