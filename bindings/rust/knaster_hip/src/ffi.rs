@@ -165,6 +165,7 @@ unsafe extern "C" {
     pub fn knh_bank_param_apply_many_at(bank: *mut knh_bank, block_offset: u32, count: usize, voices: *const u32, stages: *const u32, params: *const u32, kinds: *const u32, fvalues: *const f64, ivalues: *const i64, delays: *const u16) -> i32;
     pub fn knh_bank_read_done_frames(bank: *mut knh_bank, done_frames: *mut u32) -> i32;
     pub fn knh_bank_debug_words(bank: *mut knh_bank, out16: *mut u32) -> i32;
+    pub fn knh_bank_debug_signature(bank: *const knh_bank) -> *const core::ffi::c_char;
     pub fn knh_bank_synchronize(bank: *mut knh_bank) -> i32;
     pub fn knh_bank_timing_reset(bank: *mut knh_bank, enable: i32) -> i32;
     pub fn knh_bank_timing_read(bank: *mut knh_bank, kernel_ms: *mut f64, launches: *mut u64) -> i32;

@@ -455,6 +455,11 @@ int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames);
 /* Diagnostics: 16 device words of the last launch (0,1: the done/running summary; 4..8: per-role busy
  * cycles per tile when the library was built with -DKNH_DAG_STAMPS, zero otherwise). */
 int32_t knh_bank_debug_words(knh_bank* bank, uint32_t* out16);
+/* Diagnostics: the chain as the device code names it (one character per stage, "@a,b,o" signal slots and "#R" for a
+ * voice that is a graph, "%P" for an audio-rate parameter): what a chain without a pre-built kernel is fused from at
+ * knh_bank_init.  Valid while the bank lives; available before init (tools/jit_compile_fuzz.py compiles such strings
+ * without a GPU). */
+const char* knh_bank_debug_signature(const knh_bank* bank);
 /* Wait for everything enqueued by *_device calls. */
 int32_t knh_bank_synchronize(knh_bank* bank);
 

@@ -92,6 +92,7 @@ PROTOTYPES = {
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "knh_bank_read_done_frames": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "knh_bank_debug_words": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "knh_bank_debug_signature": (C.c_char_p, [C.c_void_p]),
     "knh_bank_synchronize": (C.c_int32, [C.c_void_p]),
     "knh_bank_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
     "knh_bank_timing_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -275,6 +275,10 @@ class VoiceBank:
         self._check(self._lib.knh_bank_read_done_frames(self._h, d.ctypes.data_as(C.c_void_p)))
         return d
 
+    def debug_signature(self) -> str:
+        """the chain as the device code names it (knh_bank_debug_signature)"""
+        return self._lib.knh_bank_debug_signature(self._h).decode()
+
     def debug_words(self) -> np.ndarray:
         d = np.zeros(16, dtype=np.uint32)
         self._check(self._lib.knh_bank_debug_words(self._h, d.ctypes.data_as(C.c_void_p)))

@@ -563,6 +563,7 @@ int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames) {
     return bank->read_done_frames(done_frames);
   });
 }
+const char* knh_bank_debug_signature(const knh_bank* bank) { return bank ? bank->debug_signature() : ""; }
 int32_t knh_bank_debug_words(knh_bank* bank, uint32_t* out16) {
   return guarded(bank, [&]() -> int32_t {
     if (!bank || !out16) return KNH_ERR_INVALID_ARGUMENT;

@@ -65,6 +65,7 @@ struct knh_bank {
   virtual int read_done_frames(uint32_t* out) = 0;
   virtual int synchronize() = 0;
   virtual int debug_read(uint32_t* out16) = 0;
+  virtual const char* debug_signature() const { return ""; }  // (a bank cut into ranges: its parts have one each)
   virtual int timing_reset(int enable) = 0;
   virtual int timing_read(double* ms, uint64_t* launches) = 0;
   virtual int collective_timing_read(double* ms, uint64_t* reduces) {

@@ -37,6 +37,7 @@ struct Bank final : knh_bank {
   const knh::JitKernel* jit = nullptr;   // run-time fused kernel (hiprtc) for chains without a pre-built one
   int pipeline_level = 1;                // KNH_PIPELINE
   std::string signature;
+  const char* debug_signature() const override { return signature.c_str(); }
   uint32_t nv = 0;
   long stride = 0;
 

@@ -955,62 +955,49 @@ struct Svf : StageDefaults {
       return r.m0 * v0 + r.m1 * v1 + r.m2 * v2;
     }
   }
-  // f32, exact arithmetic: the same fifteen roundings as tick(), issued as nine and a half instructions per sample.
-  // Independent pairs share a packed instruction -- (a1*ic1, a2*ic1), (a2*v3, a3*v3), (v1, v2), (ic1', ic2'),
-  // (m1*v1, m2*v2), and m0*x of two neighbouring samples (formed in front of each run of eight, outside the asm) -- with
-  // the state kept in aligned register pairs so that no moves are needed.  A wavefront alone
-  // on its SIMD is issue-bound (tools/micro/valu_issue.hip: one instruction per ~5 cycles whatever it is, a packed
-  // f32 op 1.2x that, an s_nop two thirds of it), so the instruction count of this loop IS the block time of the
-  // filter wave.  The order is fixed by hand: the two output adds of sample j-1 sit between the recurrence instructions
-  // of sample j, so no instruction reads the result of the packed
-  // instruction right before it (the compiler's rule for packed f32 results; the hardware turned out not to need the wait
-  // state -- see tick_tile_low below -- but the order costs nothing: the step is its nine issue slots either way).  Halves of a pair cannot be named through asm operands, hence the fixed registers:
-  //   v[100:101] (ic1, ic2)   v[102:103] P1   v[104:105] P2   v[106:107] (v1, v2)   v[108:109] (m1*v1, m2*v2)
-  //   v112 m0*x + m1*v1 of the sample before   v114 v3
+  // f32, exact arithmetic: the same fifteen roundings as tick(), issued as ten instructions per sample.  Independent pairs share
+  // a packed instruction -- (a1*ic1, a2*ic1), (a2*v3, a3*v3), (v1, v2), (ic1', ic2'), (m1*v1, m2*v2) -- with the state kept in
+  // an aligned register pair so that no moves are needed.  A wavefront alone on its SIMD is issue-bound (tools/micro/
+  // valu_issue.hip, svf_low_variants.hip: ~4.15 cycles per instruction whatever it is, an s_nop included), so the instruction
+  // count of this loop IS the block time of the filter wave.  Halves of a pair cannot be named through asm operands, hence the
+  // fixed registers.  (Rounds 1-2 kept packed results away from the instruction right behind them and carried the output's
+  // three terms over to the next sample's step to fill those places -- nine and a half instructions; the hardware needs no
+  // such wait state, and the carried two-float values are what the compiler's subregister renaming pass crashed on once a
+  // second filter path sat beside this one.)
   template <int T>
   static __device__ __forceinline__ void tick_tile_packed(Regs<float>& r, float (&x)[T]) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 ic = {r.ic1, r.ic2};
-    const f2 a12 = {r.a1, r.a2}, a23 = {r.a2, r.a3}, m12 = {r.m1, r.m2}, m00 = {r.m0, r.m0};
-    f2 q = {0.0f, 0.0f};
-    float mprev = 0.0f, first_prev;
     static_assert(T % 8 == 0, "the filter tile is unrolled in blocks of eight samples");
-    // one sample: OUT receives the previous sample's output, IN is this sample's input, MP the previous sample's m0*x
-#define KNH_SVF_STEP(OUT, IN, MP)                                                                                  \
-      "v_pk_mul_f32 v[102:103], %[a12], v[100:101] op_sel_hi:[1,0]\n\t"   /* (a1*ic1, a2*ic1)                 */   \
-      "v_sub_f32 v114, %[x" #IN "], v101\n\t"                             /* v3 = x - ic2                     */   \
+    // Registers, all named and all below v128 (the sixteen-groups-per-workgroup kernels have 128) -- every operand of the asm is
+    // a single 32-bit register; see tick_tile_low for why:
+    //   v[100:101] (ic1, ic2)  v[102:103] P1  v[104:105] P2  v[106:107] (v1, v2)  v[108:109] (m1*v1, m2*v2)  v112 the output sum
+    //   v114 v3  v[116:117] (a1, a2)  v[118:119] (a2, a3)  v[120:121] (m1, m2)  v122 m0
+    float ic1 = r.ic1, ic2 = r.ic2;
+    const float a1 = r.a1, a2 = r.a2, a2b = r.a2, a3 = r.a3, m0 = r.m0, m1 = r.m1, m2 = r.m2;
+#define KNH_SVF_STEP(K)                                                                                            \
+      "v_sub_f32 v114, %[x" #K "], v101\n\t"                              /* v3 = x - ic2                     */   \
+      "v_pk_mul_f32 v[102:103], v[116:117], v[100:101] op_sel_hi:[1,0]\n\t"   /* (a1*ic1, a2*ic1)             */   \
+      "v_pk_mul_f32 v[104:105], v[118:119], v[114:115] op_sel_hi:[1,0]\n\t"   /* (a2*v3, a3*v3)               */   \
       "v_add_f32 v103, v101, v103\n\t"                                    /* ic2 + a2*ic1                     */   \
-      "v_pk_mul_f32 v[104:105], %[a23], v[114:115] op_sel_hi:[1,0]\n\t"   /* (a2*v3, a3*v3)                   */   \
-      "v_add_f32 v112, %[" #MP "], v108\n\t"                              /* previous: m0*x + m1*v1           */   \
       "v_pk_add_f32 v[106:107], v[102:103], v[104:105]\n\t"               /* (v1, v2)                         */   \
-      "v_add_f32 %[y" #OUT "], v112, v109\n\t"                            /* previous: ... + m2*v2 -> output  */   \
+      "v_mul_f32 v112, v122, %[x" #K "]\n\t"                              /* m0*x                             */   \
       "v_pk_fma_f32 v[100:101], v[106:107], 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"    \
-      "v_pk_mul_f32 v[108:109], %[m12], v[106:107]\n\t"                   /* (m1*v1, m2*v2)                   */
+      "v_pk_mul_f32 v[108:109], v[120:121], v[106:107]\n\t"               /* (m1*v1, m2*v2)                   */   \
+      "v_add_f32 v112, v112, v108\n\t"                                    /* m0*x + m1*v1                     */   \
+      "v_add_f32 %[y" #K "], v112, v109\n\t"                              /* ... + m2*v2 -> output            */
 #pragma unroll
     for (int j = 0; j < T; j += 8) {
-      // m0*x of the eight samples, two to an instruction (plain C++: the halves are then ordinary operands)
-      const f2 p01 = m00 * f2{x[j], x[j + 1]}, p23 = m00 * f2{x[j + 2], x[j + 3]}, p45 = m00 * f2{x[j + 4], x[j + 5]},
-               p67 = m00 * f2{x[j + 6], x[j + 7]};
-      // outputs y0..y7 = results of samples j-1 .. j+6 (early-clobber: they are written before later inputs are read)
       float y0, y1, y2, y3, y4, y5, y6, y7;
-      asm volatile(KNH_SVF_STEP(0, 0, mp) KNH_SVF_STEP(1, 1, m0) KNH_SVF_STEP(2, 2, m1) KNH_SVF_STEP(3, 3, m2)
-                   KNH_SVF_STEP(4, 4, m3) KNH_SVF_STEP(5, 5, m4) KNH_SVF_STEP(6, 6, m5) KNH_SVF_STEP(7, 7, m6)
+      asm volatile(KNH_SVF_STEP(0) KNH_SVF_STEP(1) KNH_SVF_STEP(2) KNH_SVF_STEP(3) KNH_SVF_STEP(4) KNH_SVF_STEP(5) KNH_SVF_STEP(6) KNH_SVF_STEP(7)
                    : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3), [y4] "=&v"(y4), [y5] "=&v"(y5),
-                     [y6] "=&v"(y6), [y7] "=&v"(y7), "+{v[100:101]}"(ic), "+{v[108:109]}"(q)
+                     [y6] "=&v"(y6), [y7] "=&v"(y7), "+{v100}"(ic1), "+{v101}"(ic2)
                    : [x0] "v"(x[j]), [x1] "v"(x[j + 1]), [x2] "v"(x[j + 2]), [x3] "v"(x[j + 3]), [x4] "v"(x[j + 4]),
-                     [x5] "v"(x[j + 5]), [x6] "v"(x[j + 6]), [x7] "v"(x[j + 7]), [a12] "v"(a12), [a23] "v"(a23),
-                     [m12] "v"(m12), [mp] "v"(mprev), [m0] "v"(p01.x), [m1] "v"(p01.y), [m2] "v"(p23.x), [m3] "v"(p23.y),
-                     [m4] "v"(p45.x), [m5] "v"(p45.y), [m6] "v"(p67.x)
-                   : "v102", "v103", "v104", "v105", "v106", "v107", "v112", "v114", "v115");
-      mprev = p67.y;
-      if (j > 0) x[j - 1] = y0; else first_prev = y0;  // nothing is pending before the first sample
-      x[j] = y1; x[j + 1] = y2; x[j + 2] = y3; x[j + 3] = y4; x[j + 4] = y5; x[j + 5] = y6; x[j + 6] = y7;
+                     [x5] "v"(x[j + 5]), [x6] "v"(x[j + 6]), [x7] "v"(x[j + 7]), "{v116}"(a1), "{v117}"(a2), "{v118}"(a2b), "{v119}"(a3),
+                     "{v120}"(m1), "{v121}"(m2), "{v122}"(m0)
+                   : "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v112", "v114", "v115");
+      x[j] = y0; x[j + 1] = y1; x[j + 2] = y2; x[j + 3] = y3; x[j + 4] = y4; x[j + 5] = y5; x[j + 6] = y6; x[j + 7] = y7;
     }
 #undef KNH_SVF_STEP
-    asm volatile("s_nop 0\n\tv_add_f32 v112, %[mp], v108\n\ts_nop 0\n\tv_add_f32 %[xout], v112, v109"
-                 : [xout] "=v"(x[T - 1]) : "{v[108:109]}"(q), [mp] "v"(mprev) : "v112");
-    (void)first_prev;
-    r.ic1 = ic.x; r.ic2 = ic.y;
+    r.ic1 = ic1; r.ic2 = ic2;
   }
   // The low-pass output (svf.rs:148-157: m0 = 0, m1 = 0, m2 = 1) without its three multiplies and two adds, bit for bit:
   //   (0*x + 0*v1) + 1*v2 = z + v2 with z = +-0 while x and v1 are finite, and z + v2 = v2 unless v2 = -0;
@@ -1019,10 +1006,9 @@ struct Svf : StageDefaults {
   //   refuses that state and the general step runs.  When x or v1 is not finite the reference returns NaN (0*inf); x not
   //   finite makes v1 = a1*ic1 + a2*(x - ic2) not finite too, so fma(0, v1, v2) -- v2 when v1 is finite, NaN when it is not,
   //   and +0 + v2 = v2 -- is the reference's value in every case, in one instruction.
-  // The step is then seven instructions: v3, (a1*ic1, a2*ic1), (a2*v3, a3*v3), ic2 + a2*ic1, (v1, v2), the output of the
-  // sample before ((v1, v2) alternate between two register pairs, so that it can sit between the packed add and the packed
-  // fma that reads the add's result), (ic1', ic2').  The next sample's first instruction reads the packed fma's result with
-  // nothing in between.  The compiler would put an s_nop there (its hazard table takes op_sel_hi of a packed f32 instruction
+  // The step is then seven instructions: v3, (a1*ic1, a2*ic1), (a2*v3, a3*v3), ic2 + a2*ic1, (v1, v2), the output,
+  // (ic1', ic2').  Packed results are read by the very next instruction (the output reads the packed add's, the next
+  // sample's first instruction the packed fma's).  The compiler would put an s_nop there (its hazard table takes op_sel_hi of a packed f32 instruction
   // for a half-register write: the dst_sel forwarding rule of gfx940); the hardware needs none -- the step with and without
   // it gives the same bits over 1.3e9 samples, and 29.25 against 33.25 cycles per sample for a wavefront alone on its SIMD
   // (tools/micro/svf_low_variants.hip, profiles/r03_micro_svf_low_variants.txt): an s_nop costs an issue slot like any
@@ -1035,42 +1021,35 @@ struct Svf : StageDefaults {
   }
   template <int T>
   static __device__ __forceinline__ void tick_tile_low(Regs<float>& r, float (&x)[T]) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 ic = {r.ic1, r.ic2};
-    const f2 a12 = {r.a1, r.a2}, a23 = {r.a2, r.a3};
-    f2 q = {0.0f, 0.0f};
-    float first_prev;
     static_assert(T % 8 == 0, "the filter tile is unrolled in blocks of eight samples");
-    // one sample: V receives (v1, v2), OUT the output of the sample before, whose (v1, v2) are PL, PH
-#define KNH_SVF_LOW(OUT, IN, V, PL, PH)                                                                            \
-      "v_sub_f32 v114, %[x" #IN "], v101\n\t"                             /* v3 = x - ic2                     */   \
-      "v_pk_mul_f32 v[102:103], %[a12], v[100:101] op_sel_hi:[1,0]\n\t"   /* (a1*ic1, a2*ic1)                 */   \
-      "v_pk_mul_f32 v[104:105], %[a23], v[114:115] op_sel_hi:[1,0]\n\t"   /* (a2*v3, a3*v3)                   */   \
+    // Registers, all named and all below v128: v[100:101] (ic1, ic2)  v[102:103] P1  v[104:105] P2  v[106:107] (v1, v2)  v114 v3
+    // v[116:117] (a1, a2)  v[118:119] (a2, a3).  Every operand of the asm is a single 32-bit register: no 64-bit C++ value is
+    // tied to it.  (With the state and the coefficients as two-float vectors, as in tick_tile_packed, the compiler's "rename
+    // disconnected subregister components" pass crashed on voices with two filters once this step and the general one sat
+    // in one function -- inside hiprtc, and therefore inside the host process.)
+    float ic1 = r.ic1, ic2 = r.ic2;
+    const float a1 = r.a1, a2 = r.a2, a2b = r.a2, a3 = r.a3;
+#define KNH_SVF_LOW(K)                                                                                             \
+      "v_sub_f32 v114, %[x" #K "], v101\n\t"                              /* v3 = x - ic2                     */   \
+      "v_pk_mul_f32 v[102:103], v[116:117], v[100:101] op_sel_hi:[1,0]\n\t"   /* (a1*ic1, a2*ic1)             */   \
+      "v_pk_mul_f32 v[104:105], v[118:119], v[114:115] op_sel_hi:[1,0]\n\t"   /* (a2*v3, a3*v3)               */   \
       "v_add_f32 v103, v101, v103\n\t"                                    /* ic2 + a2*ic1                     */   \
-      "v_pk_add_f32 " V ", v[102:103], v[104:105]\n\t"                    /* (v1, v2)                         */   \
-      "v_fma_f32 %[y" #OUT "], 0, " PL ", " PH "\n\t"                     /* previous: v2 (NaN if v1 is not finite) */ \
-      "v_pk_fma_f32 v[100:101], " V ", 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
-#define KNH_SVF_LOW_A(OUT, IN) KNH_SVF_LOW(OUT, IN, "v[106:107]", "v108", "v109")
-#define KNH_SVF_LOW_B(OUT, IN) KNH_SVF_LOW(OUT, IN, "v[108:109]", "v106", "v107")
+      "v_pk_add_f32 v[106:107], v[102:103], v[104:105]\n\t"               /* (v1, v2)                         */   \
+      "v_fma_f32 %[y" #K "], 0, v106, v107\n\t"                           /* v2 (NaN if v1 is not finite)     */   \
+      "v_pk_fma_f32 v[100:101], v[106:107], 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
 #pragma unroll
     for (int j = 0; j < T; j += 8) {
-      float y0, y1, y2, y3, y4, y5, y6, y7;  // results of samples j-1 .. j+6
-      asm volatile(KNH_SVF_LOW_A(0, 0) KNH_SVF_LOW_B(1, 1) KNH_SVF_LOW_A(2, 2) KNH_SVF_LOW_B(3, 3)
-                   KNH_SVF_LOW_A(4, 4) KNH_SVF_LOW_B(5, 5) KNH_SVF_LOW_A(6, 6) KNH_SVF_LOW_B(7, 7)
+      float y0, y1, y2, y3, y4, y5, y6, y7;
+      asm volatile(KNH_SVF_LOW(0) KNH_SVF_LOW(1) KNH_SVF_LOW(2) KNH_SVF_LOW(3) KNH_SVF_LOW(4) KNH_SVF_LOW(5) KNH_SVF_LOW(6) KNH_SVF_LOW(7)
                    : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3), [y4] "=&v"(y4), [y5] "=&v"(y5),
-                     [y6] "=&v"(y6), [y7] "=&v"(y7), "+{v[100:101]}"(ic), "+{v[108:109]}"(q)
+                     [y6] "=&v"(y6), [y7] "=&v"(y7), "+{v100}"(ic1), "+{v101}"(ic2)
                    : [x0] "v"(x[j]), [x1] "v"(x[j + 1]), [x2] "v"(x[j + 2]), [x3] "v"(x[j + 3]), [x4] "v"(x[j + 4]),
-                     [x5] "v"(x[j + 5]), [x6] "v"(x[j + 6]), [x7] "v"(x[j + 7]), [a12] "v"(a12), [a23] "v"(a23)
+                     [x5] "v"(x[j + 5]), [x6] "v"(x[j + 6]), [x7] "v"(x[j + 7]), "{v116}"(a1), "{v117}"(a2), "{v118}"(a2b), "{v119}"(a3)
                    : "v102", "v103", "v104", "v105", "v106", "v107", "v114", "v115");
-      if (j > 0) x[j - 1] = y0; else first_prev = y0;  // nothing is pending before the first sample
-      x[j] = y1; x[j + 1] = y2; x[j + 2] = y3; x[j + 3] = y4; x[j + 4] = y5; x[j + 5] = y6; x[j + 6] = y7;
+      x[j] = y0; x[j + 1] = y1; x[j + 2] = y2; x[j + 3] = y3; x[j + 4] = y4; x[j + 5] = y5; x[j + 6] = y6; x[j + 7] = y7;
     }
-#undef KNH_SVF_LOW_A
-#undef KNH_SVF_LOW_B
 #undef KNH_SVF_LOW
-    asm volatile("v_fma_f32 %[xout], 0, v108, v109" : [xout] "=v"(x[T - 1]) : "{v[108:109]}"(q));
-    (void)first_prev;
-    r.ic1 = ic.x; r.ic2 = ic.y;
+    r.ic1 = ic1; r.ic2 = ic2;
   }
   // the same in f64: eleven instructions for the general step's fifteen, every operand at least two instructions old
   template <int T>

@@ -1,0 +1,26 @@
+"""Run-time fusion without a GPU: the compile (hiprtc) is host work, so kernels of chains with no pre-built form can be
+compiled here, each in a process of its own (tests/cpp/bin/jit_compile_check) -- a compiler crash would otherwise take the HOST
+process down at knh_bank_init, as one did: the voice of tests/test_gpu_dag.py's seed 175 (two filters in a graph) crashed the
+compiler's subregister renaming pass while the filter's two step encodings carried two-float values across their asm blocks.
+tools/jit_compile_fuzz.py does the same for hundreds of random voices."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "tests", "cpp", "bin", "jit_compile_check")
+
+SIGNATURES = [
+    ("W@_,_,0S@0,_,0*@0,0,0S@0,_,1-@1,0,0X@0,_,0#2", "f32"),   # the voice that crashed the compiler: SinWt -> Svf -> x*x -> Svf -> (a - b) -> limiter
+    ("W@_,_,0S@0,_,0*@0,0,0S@0,_,1-@1,0,0X@0,_,0#2", "f64"),
+    ("WSLSA", "f32"),                                            # a plain chain with two filters and a one-pole between them
+]
+
+
+@pytest.mark.skipif(not os.path.exists(CHECK), reason="tests/cpp/bin/jit_compile_check not built (make -C tests/cpp)")
+@pytest.mark.parametrize("signature,sample_type", SIGNATURES)
+def test_kernels_of_tricky_voices_compile(signature, sample_type):
+    p = subprocess.run([CHECK, signature] + (["f64"] if sample_type == "f64" else []), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=900)
+    assert p.returncode == 0, f"{signature} ({sample_type}): rc {p.returncode}: {p.stdout.decode(errors='replace')[-600:]}"
