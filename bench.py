@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_OPS = 78.6e12        # 157.3 TFLOP/s FP32 vector counts an FMA as 2: 78.6e12 non-fused ops/s
 OPS_PER_UGEN_SAMPLE = 6.0      # ~23 flop + 3 iop + 1 gather per voice-sample / 4 UGens
 # The filter wavefront of the C3 pipeline kernel issues seven VALU instructions per sample of a low-pass filter (four of
-# them packed: Svf::tick_tile_low; the general step of the other eight filter types has nine and a half); a wavefront alone
+# them packed: Svf::tick_tile_low; the general step of the other eight filter types has ten); a wavefront alone
 # on its SIMD needs 29 shader-clock cycles for them (tools/micro/svf_low_variants.hip, profiles/r03_micro_svf_low_variants.txt:
 # ~4.15 per issue slot), 12.2 ns at the 2.4 GHz the chip holds under this load (tools/micro/clock_share.hip).  That is the
 # floor of the kernel's time per sample: the serial filter recurrence of one 64-voice group cannot be spread over more
