@@ -24,3 +24,21 @@ def test_kernels_of_tricky_voices_compile(signature, sample_type):
     p = subprocess.run([CHECK, signature] + (["f64"] if sample_type == "f64" else []), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=900)
     assert p.returncode == 0, f"{signature} ({sample_type}): rc {p.returncode}: {p.stdout.decode(errors='replace')[-600:]}"
+
+
+def test_debug_signature_names_the_chain():
+    """knh_bank_debug_signature: the string run-time fusion starts from (and tools/jit_compile_fuzz.py compiles) -- available
+    without a device, before init."""
+    import numpy as np  # noqa: F401
+    import knaster_amd
+    from knaster_amd import _lib as L, configs
+    from knaster_amd.bank import Stage
+    w = configs.config("C3", n_voices=64)
+    b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE)
+    assert b.debug_signature() == "WmSA"
+    b.close()
+    st = [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SVF), Stage(L.STAGE_MATH_MUL, input=2, input2=2), Stage(L.STAGE_SVF),
+          Stage(L.STAGE_MATH_SUB, input=4, input2=3), Stage(L.STAGE_SAFETY_LIMITER)]
+    b = knaster_amd.VoiceBank(st, 3, L.F32, 1, L.MIX_LEFT_FOLD)
+    assert b.debug_signature() == SIGNATURES[0][0]  # the voice of test_gpu_dag.py's seed 175
+    b.close()
