@@ -15,13 +15,14 @@ SIGNATURES = [
     ("W@_,_,0S@0,_,0*@0,0,0S@0,_,1-@1,0,0X@0,_,0#2", "f32"),   # the voice that crashed the compiler: SinWt -> Svf -> x*x -> Svf -> (a - b) -> limiter
     ("W@_,_,0S@0,_,0*@0,0,0S@0,_,1-@1,0,0X@0,_,0#2", "f64"),
     ("WSLSA", "f32"),                                            # a plain chain with two filters and a one-pole between them
+    ("WSLSA", "f32 pipe"),                                       # ... and as the pipeline knh_bank_init would cut it into
 ]
 
 
 @pytest.mark.skipif(not os.path.exists(CHECK), reason="tests/cpp/bin/jit_compile_check not built (make -C tests/cpp)")
 @pytest.mark.parametrize("signature,sample_type", SIGNATURES)
 def test_kernels_of_tricky_voices_compile(signature, sample_type):
-    p = subprocess.run([CHECK, signature] + (["f64"] if sample_type == "f64" else []), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+    p = subprocess.run([CHECK, signature] + [a for a in sample_type.split() if a != "f32"], cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=900)
     assert p.returncode == 0, f"{signature} ({sample_type}): rc {p.returncode}: {p.stdout.decode(errors='replace')[-600:]}"
 

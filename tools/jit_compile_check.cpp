@@ -2,16 +2,29 @@
 // itself is host work, only loading the result asks for a device.  A compiler crash kills this process, not a host's:
 // tools/jit_compile_fuzz.py runs it over random voices.
 //   make -C tests/cpp bin/jit_compile_check
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
+#include "../include/knaster_hip.h"
 #include "jit.hpp"
+#include "stage_table.hpp"  // partition_chain: how knh_bank_init cuts a plain chain into pipeline groups
 int main(int argc, char** argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: jit_compile_check <signature> [f64] [fma]\n"); return 2; }
-  bool f64 = false, fma = false;
-  for (int i = 2; i < argc; ++i) { f64 = f64 || !std::strcmp(argv[i], "f64"); fma = fma || !std::strcmp(argv[i], "fma"); }
+  if (argc < 2) { std::fprintf(stderr, "usage: jit_compile_check <signature> [f64] [fma] [pipe]\n"); return 2; }
+  bool f64 = false, fma = false, pipe = false;
+  for (int i = 2; i < argc; ++i) { f64 = f64 || !std::strcmp(argv[i], "f64"); fma = fma || !std::strcmp(argv[i], "fma"); pipe = pipe || !std::strcmp(argv[i], "pipe"); }
   std::string err;
-  const knh::JitKernel* k = knh::jit_voice_kernel(argv[1], f64, fma, &err);
+  const knh::JitKernel* k = nullptr;
+  if (pipe) {  // the pipelined form a plain chain of up to 512 voice groups gets at init
+    unsigned cuts[2] = {0, 0};
+    const unsigned n_cuts = partition_chain(argv[1], cuts);
+    k = knh::jit_pipe_kernel(argv[1], cuts, n_cuts, f64, fma, &err);
+  } else {
+    k = knh::jit_voice_kernel(argv[1], f64, fma, &err);
+  }
   if (k) { std::puts("compiled and loaded"); return 0; }
   // with no device the compile is followed by a failing load: that is a successful compile
   if (err.rfind("hipGetDevice", 0) == 0 || err.rfind("hipModuleLoadData", 0) == 0) { std::puts("compiled"); return 0; }

@@ -42,14 +42,16 @@ for seed in range(first, first + seeds):
     st, _ = D.random_dag(rng, int(rng.integers(4, 12)))
     jobs.add((signature(st, L.F32 if seed % 3 else L.F64), "f32" if seed % 3 else "f64"))
     w, _, _, _ = R.random_chain(seed)
-    jobs.add((signature(w.stages, w.sample_type), "f64" if w.sample_type == L.F64 else "f32"))
+    ty = "f64" if w.sample_type == L.F64 else "f32"
+    jobs.add((signature(w.stages, w.sample_type), ty))
+    jobs.add((signature(w.stages, w.sample_type), ty + " pipe"))  # ... and as the pipeline knh_bank_init builds for it
 jobs = sorted(jobs)
 print(len(jobs), "distinct kernels", flush=True)
 
 
 def run(job):
     sig, ty = job
-    p = subprocess.run([check, sig] + (["f64"] if ty == "f64" else []), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800,
+    p = subprocess.run([check, sig] + [a for a in ty.split() if a != "f32"], cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800,
                        preexec_fn=lambda: __import__("resource").setrlimit(__import__("resource").RLIMIT_CORE, (0, 0)))
     return job, p.returncode, p.stdout.decode(errors="replace")[-400:]
 
