@@ -399,7 +399,9 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   // samples evaluated stage by stage in registers per visit: up to 32 (the per-visit costs -- event test, the filter's choice of
   // step, register set-up around its fixed-register code -- are paid a quarter as often as with the eight of rounds 1-2:
   // 53.7 -> 39.9 us per block at 131 072 voices, C4's 65 536 f64 voices 50.5 -> 38.0, C1's one voice 2.43 -> 1.94)
-  constexpr int KT = TN < 32 ? TN : 32;
+  // (a voice of more than sixteen stages -- a graph, as a rule -- keeps the eight-sample visits: every stage's tile code is
+  // unrolled per visit length, and hiprtc needs minutes for a 200-stage voice at 32 + 8 samples where it needs seconds at 8)
+  constexpr int KT = sizeof...(S) > 16 ? kTile : (TN < 32 ? TN : 32);
   constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
                                                 // writes (ds_write_b32) and row reads (ds_read_b128)
   // (one LDS object with the table first: the table at LDS address 0, a table read's address is the masked phase itself)
