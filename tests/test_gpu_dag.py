@@ -192,6 +192,32 @@ def test_random_dag_voices_match_the_oracle(knh, oracle, seed):
     o.close()
 
 
+@pytest.mark.parametrize("seed,n_stages", [(0, 20), (1, 33)])
+def test_larger_random_dag_voices(knh, oracle, seed, n_stages):
+    """Voices of more than sixteen stages keep the whole-chain kernel's eight-sample visits (hiprtc's time grows with the visit
+    length times the stage count): the same bits."""
+    rng = np.random.default_rng(5000 + seed)
+    st, ctor = random_dag(rng, n_stages)
+    n = 70
+    w = configs.Workload(f"bigdag{seed}", st, n, 48, L.F32, 1)
+    w.ctor = {s: np.tile(np.asarray(a, dtype=np.float64), (n, 1)) * (1.0 + 0.01 * np.arange(n)).reshape(n, 1) if st[s].kind == L.STAGE_SIN_WT
+              else np.tile(np.asarray(a, dtype=np.float64), (n, 1)) for s, a in ctor.items()}
+    envs = [i for i, s in enumerate(st) if s.kind == L.STAGE_MUL_ENV_AR]
+    g = make_gpu(knh, w, L.MIX_LEFT_FOLD)
+    o = make_oracle(oracle, w)
+    for b in range(3):
+        for bank in (g, o):
+            if b in (0, 2):
+                for e in envs:
+                    fire_all(bank, n, e, 2)
+        _, gv, _ = g.process_block_voices()
+        _, ov, _, od = o.process_block()
+        assert_bit_equal(gv, ov, f"{n_stages}-stage voice, block {b}")
+        np.testing.assert_array_equal(g.read_done_frames(), od)
+    g.close()
+    o.close()
+
+
 def test_division_and_power_of_two_signals(knh, oracle):
     n = 64
     st = [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_SIN_WT), Stage(L.STAGE_ADD_CONST),          # 3: b + 2 (never near zero)
