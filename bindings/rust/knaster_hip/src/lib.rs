@@ -284,9 +284,6 @@ impl<F: Float, I: Size> UGen for GpuVoiceBank<F, I> {
         InBlock: BlockRead<Sample = F> + ?Sized,
         OutBlock: Block<Sample = F> + ?Sized,
     {
-        // RawContiguousBlock is channel-major and contiguous (knaster_graph/src/block.rs:19-78): the start of
-        // channel 0 is the base of [2][block_size].  The library writes frames
-        // [block_start_offset, block_start_offset + frames_to_process) of both channels.
         if self.init_error.is_some() {
             for ch in 0..2 {
                 for s in output.channel_as_slice_mut(ch).iter_mut() {
@@ -305,7 +302,7 @@ impl<F: Float, I: Size> UGen for GpuVoiceBank<F, I> {
             let (bs, off, ftp) = (self.block_size, ctx.block_start_offset(), ctx.frames_to_process());
             for ch in 0..I::USIZE {
                 let src = input.channel_as_slice(ch);
-                let n = src.len().min(ftp).min(bs - off);
+                let n = src.len().min(ftp).min(bs - off); // `src` starts at the partial block's first frame (block.rs:285-287)
                 self.in_pack[ch * bs + off..ch * bs + off + n].copy_from_slice(&src[..n]);
             }
             for k in 0..self.n_ar {
@@ -322,10 +319,18 @@ impl<F: Float, I: Size> UGen for GpuVoiceBank<F, I> {
                 rt_log!(ctx.logger(); "knaster_hip: knh_bank_set_input failed");
             }
         }
-        let out = output.channel_as_slice_mut(0).as_mut_ptr() as *mut c_void;
+        // One pointer per output channel, each at the first frame THIS call writes: `output` may be the whole
+        // RawContiguousBlock (knaster_graph/src/block.rs:19-78) or, under a splitting wrapper, a PartialBlockMut whose slices
+        // already start at the partial block's offset (knaster_primitives/src/block.rs:307-339, precise_timing.rs:98-110).
+        // ctx.block_start_offset() says where those frames lie in the bank's block; it must not be applied to the pointers
+        // a second time, and the Block trait promises nothing about channel 1 following channel 0 in memory.
+        let out: [*mut c_void; 2] = [
+            output.channel_as_slice_mut(0).as_mut_ptr() as *mut c_void,
+            output.channel_as_slice_mut(1).as_mut_ptr() as *mut c_void,
+        ];
         let mut f = 0u32;
         let rc = unsafe {
-            knh_bank_process_block(self.h, ctx.frames_to_process(), ctx.block_start_offset(), ctx.frame_clock(), out, &mut f)
+            knh_bank_process_block_channels(self.h, ctx.frames_to_process(), ctx.block_start_offset(), ctx.frame_clock(), out.as_ptr(), &mut f)
         };
         if rc != KNH_OK {
             rt_log!(ctx.logger(); "knaster_hip: process_block failed, status ", rc as f64);

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KNH_ABI_VERSION 3
+#define KNH_ABI_VERSION 4
 
 typedef enum knh_status {
   KNH_OK = 0,
@@ -391,6 +391,17 @@ int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* 
  * Blocks until the block is on the host (non-realtime driver only). */
 int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t block_start_offset,
                                uint64_t frame_clock, void* out, uint32_t* out_flags);
+/* The same call for an output block that is handed over as the reference's `Block` trait hands it over: one slice per
+ * channel (knaster_primitives/src/block.rs:33-197, `channel_as_slice_mut(channel)`), with no promise that channel c + 1
+ * follows channel c in memory.  `out_channels[c]` points at the FIRST FRAME THIS CALL WRITES of channel c and
+ * frames_to_process samples are written there.  Under a splitting wrapper (WrPreciseTiming, precise_timing.rs:98-110) the
+ * output is a PartialBlockMut whose slices already start at the partial block's offset (block.rs:307-339) while
+ * ctx.block_start_offset() carries the same offset (BlockMetadata::make_partial, ugen.rs:87-93): a shim passes
+ * `output.channel_as_slice_mut(c).as_mut_ptr()` per channel and the ctx's offset, and nothing is offset twice.
+ * block_start_offset still tells the bank where in its block the frames lie (its frame counter, the in-block delays of
+ * queued changes); it is not applied to the pointers. */
+int32_t knh_bank_process_block_channels(knh_bank* bank, size_t frames_to_process, size_t block_start_offset,
+                                        uint64_t frame_clock, void* const* out_channels, uint32_t* out_flags);
 /* Same, but the mixed block is left in device memory at `out_device`
  * ([out_channels][block_size] of F) and the work is only enqueued on
  * `hip_stream` (a hipStream_t, NULL = the bank's own stream).  Used for the
@@ -460,6 +471,12 @@ int32_t knh_bank_debug_words(knh_bank* bank, uint32_t* out16);
  * knh_bank_init.  Valid while the bank lives; available before init (tools/jit_compile_fuzz.py compiles such strings
  * without a GPU). */
 const char* knh_bank_debug_signature(const knh_bank* bank);
+/* Run-time fusion (chains without a pre-built kernel are fused by hiprtc at knh_bank_init): where this process's kernels have
+ * come from so far -- its in-memory table, the code-object cache on disk (KNH_JIT_CACHE_DIR; default $XDG_CACHE_HOME/knaster_hip,
+ * $HOME/.cache/knaster_hip or /tmp/knaster_hip-<uid>; KNH_JIT_CACHE=0: none), a compile in the helper process (knh_jit_helper
+ * beside the library, or $KNH_JIT_HELPER: a compiler crash there is KNH_ERR_INTERNAL + knh_last_error for the host, never the
+ * host's own death), or a compile in this process (no helper found, or KNH_JIT_INPROCESS=1).  Any pointer may be NULL. */
+void knh_jit_stats(uint64_t* memory_hits, uint64_t* disk_hits, uint64_t* helper_compiles, uint64_t* in_process_compiles);
 /* Wait for everything enqueued by *_device calls. */
 int32_t knh_bank_synchronize(knh_bank* bank);
 

@@ -9,9 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libknaster_hip.so")
+# KNH_LIB: another build of the same library (the stamped diagnostic build, an older one for A/B runs); never a fallback
+LIB_PATH = os.environ.get("KNH_LIB") or os.path.join(_HERE, "csrc", "libknaster_hip.so")
 
-KNH_ABI_VERSION = 3
+KNH_ABI_VERSION = 4
 
 # knh_status
 OK, ERR_INVALID_ARGUMENT, ERR_OUT_OF_RANGE, ERR_UNSUPPORTED_CHAIN, ERR_DEVICE = 0, 1, 2, 3, 4
@@ -79,6 +80,8 @@ PROTOTYPES = {
     "knh_bank_param_apply_many": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "knh_bank_process_block": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "knh_jit_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "knh_bank_process_block_channels": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
     "knh_bank_process_block_device": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]),
     "knh_bank_process_block_voices": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p,
                                                  C.POINTER(C.c_uint32)]),

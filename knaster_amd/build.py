@@ -19,7 +19,8 @@ SOURCES = ["kernels_pipe.hip", "kernels_single.hip", "kernels_wide.hip", "kernel
 # kernels take the longest to compile; side by side they take a third of the time)
 UNITS = [("kernels_pipe.hip", "kernels_pipe_mixer.o", ["-DKNH_PIPE_PART=0"]), ("kernels_pipe.hip", "kernels_pipe_fold.o", ["-DKNH_PIPE_PART=1"]),
          ("kernels_pipe.hip", "kernels_pipe_inplace.o", ["-DKNH_PIPE_PART=2"])] + [(s, s.replace(".hip", ".o"), []) for s in SOURCES[1:]]
-HEADERS = ["stage_table.hpp", "bank_base.hpp", "voice_bank.hpp", "chain_signature.hpp", "voice_stages.hpp", "voice_chain.hpp", "voice_pipe.hpp", "voice_frame.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", "rank_bank.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
+HELPER = os.path.join(CSRC, "knh_jit_helper")  # the process hiprtc runs in (jit_cache.hpp): host code, links hiprtc only
+HEADERS = ["jit_cache.hpp", "stage_table.hpp", "bank_base.hpp", "voice_bank.hpp", "chain_signature.hpp", "voice_stages.hpp", "voice_chain.hpp", "voice_pipe.hpp", "voice_frame.hpp", "voice_dag.hpp", "kernel_registry.hpp", "jit.hpp", "host_shards.hpp", "shard_workers.hpp", "rank_bank.hpp", os.path.join("..", "..", "include", "knaster_hip.h"),
            os.path.join("..", "build.py")]
 FLAGS = [
     "--offload-arch=gfx950",
@@ -41,11 +42,29 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HELPER):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    t = min(os.path.getmtime(LIB), os.path.getmtime(HELPER))
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + ["jit_helper.cpp"]]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_helper(verbose: bool = True) -> str:
+    """csrc/knh_jit_helper: g++ (no device code), hiprtc only -- the compiler's process never holds a GPU."""
+    src = os.path.join(CSRC, "jit_helper.cpp")
+    if os.path.exists(HELPER) and os.path.getmtime(HELPER) >= max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "jit_cache.hpp"))):
+        return HELPER
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), src, "-o", HELPER + ".tmp",
+           "-L" + os.path.join(rocm, "lib"), "-Wl,-rpath," + os.path.join(rocm, "lib"), "-lhiprtc", "-lpthread"]
+    if verbose:
+        print("[knaster_amd.build]", " ".join(cmd), flush=True)
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("building knh_jit_helper failed")
+    os.replace(HELPER + ".tmp", HELPER)
+    return HELPER
 
 
 def write_jit_source() -> None:
@@ -66,17 +85,22 @@ def write_jit_source() -> None:
             f.write(body)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
     """Compile every HIP source for gfx950 (one hipcc per translation unit, side by side) and link them into
-    csrc/libknaster_hip.so; returns its path."""
-    if not force and not needs_build():
+    csrc/libknaster_hip.so; returns its path.  variant "stamps": the diagnostic build with per-wavefront cycle stamps
+    (-DKNH_DAG_STAMPS), kept beside the product as csrc/libknaster_hip_stamps.so (objects in csrc/build_stamps) and loaded
+    with KNH_LIB=<path> -- the product library is never the stamped one."""
+    variant = variant or os.environ.get("KNH_BUILD_VARIANT", "")
+    lib = LIB if not variant else LIB.replace(".so", "_" + variant + ".so")
+    if not force and not variant and not needs_build():
         return LIB
+    build_helper(verbose)
     write_jit_source()
-    extra = ["-DKNH_DAG_STAMPS"] if os.environ.get("KNH_BUILD_STAMPS") == "1" else []  # diagnostic build only
+    extra = ["-DKNH_DAG_STAMPS"] if os.environ.get("KNH_BUILD_STAMPS") == "1" or variant == "stamps" else []  # diagnostic build only
     if os.environ.get("KNH_BUILD_DAG") == "1":  # the experimental five-role pipeline (voice_dag.hpp), not in the default build
         extra.append("-DKNH_WITH_DAG")
     extra += os.environ.get("KNH_EXTRA_FLAGS", "").split()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build" + ("_" + variant if variant else ""))
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     procs = []
@@ -112,16 +136,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc failed building libknaster_hip.so")
-    cmd = [hipcc, *LINK_FLAGS, "-o", LIB + ".tmp", *objs]
+    cmd = [hipcc, *LINK_FLAGS, "-o", lib + ".tmp", *objs]
     if verbose:
         print("[knaster_amd.build]", " ".join(cmd), flush=True)
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("hipcc failed linking libknaster_hip.so")
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, variant=next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")))

@@ -397,7 +397,9 @@ int32_t knh_bank_set_buffer(knh_bank* bank, uint32_t stage, const void* samples,
 int32_t knh_bank_init(knh_bank* bank, uint32_t sample_rate, size_t block_size) {
   return guarded(bank, [&]() -> int32_t {
     if (!bank) return KNH_ERR_INVALID_ARGUMENT;
-    return bank->init(sample_rate, block_size);
+    const int rc = bank->init(sample_rate, block_size);
+    if (rc == KNH_OK) bank->channel_block.assign(static_cast<size_t>(bank->desc.out_channels) * block_size * (bank->desc.sample_type == KNH_F64 ? 8 : 4), 0);
+    return rc;
   });
 }
 uint16_t knh_bank_inputs(const knh_bank* bank) { return bank ? static_cast<uint16_t>(bank->desc.in_channels) : 0; }
@@ -449,6 +451,24 @@ int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t 
     if (!bank) return KNH_ERR_INVALID_ARGUMENT;
     if (!out) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output block");
     return bank->process(1, frames_to_process, block_start_offset, frame_clock, out, nullptr, nullptr, out_flags, nullptr, true);
+  });
+}
+int32_t knh_bank_process_block_channels(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* const* out_channels, uint32_t* out_flags) {
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (!out_channels) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output channels");
+    for (uint32_t c = 0; c < bank->desc.out_channels; ++c)
+      if (!out_channels[c]) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "null output channel");
+    if (!bank->initialised) return bank->fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    // the bank renders frames [offset, offset + n) of its own [channels][block_size] block; each channel's piece then goes
+    // to the slice the caller gave for it, which starts at the first frame of this call
+    unsigned char* blk = bank->channel_block.data();
+    const int rc = bank->process(1, frames_to_process, block_start_offset, frame_clock, blk, nullptr, nullptr, out_flags, nullptr, true);
+    if (rc != KNH_OK) return rc;
+    const size_t word = bank->desc.sample_type == KNH_F64 ? 8 : 4;
+    for (uint32_t c = 0; c < bank->desc.out_channels; ++c)
+      std::memcpy(out_channels[c], blk + (static_cast<size_t>(c) * bank->block_size + block_start_offset) * word, frames_to_process * word);
+    return KNH_OK;
   });
 }
 int32_t knh_bank_process_block_device(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out_device, void* hip_stream) {
@@ -562,6 +582,13 @@ int32_t knh_bank_read_done_frames(knh_bank* bank, uint32_t* done_frames) {
     if (!bank) return KNH_ERR_INVALID_ARGUMENT;
     return bank->read_done_frames(done_frames);
   });
+}
+void knh_jit_stats(uint64_t* memory_hits, uint64_t* disk_hits, uint64_t* helper_compiles, uint64_t* in_process_compiles) {
+  const knh::JitStats st = knh::jit_stats();
+  if (memory_hits) *memory_hits = st.memory_hits;
+  if (disk_hits) *disk_hits = st.disk_hits;
+  if (helper_compiles) *helper_compiles = st.helper_runs;
+  if (in_process_compiles) *in_process_compiles = st.in_process;
 }
 const char* knh_bank_debug_signature(const knh_bank* bank) { return bank ? bank->debug_signature() : ""; }
 int32_t knh_bank_debug_words(knh_bank* bank, uint32_t* out16) {

@@ -22,6 +22,9 @@ struct knh_bank {
   unsigned pipe_head = 0, pipe_count = 0;
   // a stream that is to read the mix of the launch just enqueued waits for whatever sums it across GPUs (rank banks)
   virtual int order_after_collective(void* /*stream*/) { return KNH_OK; }
+  // knh_bank_process_block_channels: the block the bank renders into before its channels go to the caller's slices
+  // ([out_channels][block_size] of F; sized by knh_bank_init, so that the per-block call never allocates)
+  std::vector<unsigned char> channel_block;
   std::string err;
   std::vector<std::string> warnings;
   knh_bank_desc desc{};

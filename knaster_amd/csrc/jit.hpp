@@ -1,6 +1,7 @@
 // jit.hpp -- run-time fusion of chains that have no pre-built kernel: the device header
 // (voice_stages.hpp + voice_chain.hpp, embedded in the library at build time) is handed to hiprtc with the chain's
-// stage list as template arguments, compiled for gfx950 and cached per process.
+// stage list as template arguments, compiled for gfx950 -- in a helper process, so that a compiler crash is a status for the host
+// (jit_cache.hpp) -- and cached per process and on disk.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,7 +15,13 @@ struct JitKernel {
   unsigned block_threads = 64;  // one wavefront, or (groups + 1) wavefronts for a pipelined kernel
 };
 
-// signature: kernel_registry.hpp's one-character-per-stage string.  Returns nullptr and sets *error on failure.
+// Where this process's kernels came from so far (knh_jit_stats): the in-memory table, the code-object cache on disk, a
+// compile in the helper process, a compile in this process (no helper beside the library, or KNH_JIT_INPROCESS=1).
+struct JitStats { unsigned long memory_hits = 0, disk_hits = 0, helper_runs = 0, in_process = 0; };
+JitStats jit_stats();
+
+// signature: kernel_registry.hpp's one-character-per-stage string.  Returns nullptr and sets *error on failure (an error
+// that starts with "JIT_CRASH: " = the compiler died or hung in the helper process: KNH_ERR_INTERNAL, not a bad chain).
 const JitKernel* jit_voice_kernel(const char* signature, bool f64, bool fma, std::string* error);
 
 // The same chain as a wave pipeline: `cuts` holds the index of the first stage of every group after the first

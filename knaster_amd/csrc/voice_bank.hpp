@@ -551,11 +551,11 @@ struct Bank final : knh_bank {
       unsigned cuts[2];
       const unsigned n_cuts = partition_chain(signature, cuts);
       jit = knh::jit_pipe_kernel(signature.c_str(), cuts, n_cuts, sizeof(F) == 8, desc.allow_fma != 0, &why);
-      if (!jit) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' (pipelined) failed: " + why);
+      if (!jit) return fail(why.rfind("JIT_CRASH: ", 0) == 0 ? KNH_ERR_INTERNAL : KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' (pipelined) failed: " + why);
     } else if (!entry && !interp) {  // no pre-built kernel at all
       std::string why;
       jit = knh::jit_voice_kernel(signature.c_str(), sizeof(F) == 8, desc.allow_fma != 0, &why);
-      if (!jit) return fail(KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' failed: " + why);
+      if (!jit) return fail(why.rfind("JIT_CRASH: ", 0) == 0 ? KNH_ERR_INTERNAL : KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' failed: " + why);
     }
     sample_rate = sr;
     block_size = bs;

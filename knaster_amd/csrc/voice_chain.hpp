@@ -34,6 +34,9 @@ struct Chain<F, FMA, BASE> {
   template <typename W> __device__ __forceinline__ void store(W*, long) const {}
   __device__ __forceinline__ F tick(F x, const Ctx&, u32) { return x; }
   template <int T> __device__ __forceinline__ void tick_tile(F (&)[T], const Ctx&, u32) {}
+#ifdef KNH_DAG_STAMPS
+  template <int T> __device__ __forceinline__ void tick_tile_stamped(F (&)[T], const Ctx&, u32, u64*, u64&) {}
+#endif
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
   __device__ __forceinline__ u32 collect_done(u32 acc) const { return acc; }
@@ -74,6 +77,16 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
     S0::template tick_tile<F, FMA, T>(r, x, c, frame0, mark);
     rest.template tick_tile<T>(x, c, frame0);
   }
+#ifdef KNH_DAG_STAMPS  // diagnostic build only: the same walk with the clock read behind every stage (tools/wide_stamps.py)
+  template <int T> __device__ __forceinline__ void tick_tile_stamped(F (&x)[T], const Ctx& c, u32 frame0, u64* acc, u64& t_prev) {
+    S0::template tick_tile<F, FMA, T>(r, x, c, frame0, mark);
+    asm volatile("" : "+v"(x[T - 1]) : : "memory");  // the stage's last sample exists before the clock is read
+    const u64 t = __builtin_amdgcn_s_memtime();
+    acc[0] += t - t_prev;
+    t_prev = t;
+    rest.template tick_tile_stamped<T>(x, c, frame0, acc + 1, t_prev);
+  }
+#endif
   // A tile in which voices change parameters at frames of their own: `cn` holds each voice's registers with its changes
   // applied, `sw` the tile-relative frame at which the voice takes them over (T: never), `touched` the slots its changes
   // address.  A stage none of whose slots is touched in the whole wave runs its ordinary tile code.
@@ -476,6 +489,10 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
 
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   F(*my)[TS] = tile[wave];
+#ifdef KNH_DAG_STAMPS  // diagnostic build only: cycles of this wavefront per stage, per tile store and per fold (tools/wide_stamps.py)
+  u64 st_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_store = 0, st_fold = 0, st_visits = 0;
+  const u64 st_begin = __builtin_amdgcn_s_memtime();
+#endif
   for (u32 b = 0; b < a.n_blocks; ++b, base += a.block_size) {
     ctx.input_block = reinterpret_cast<const F*>(a.input) + (long)b * a.in_channels * a.block_size;
     chain.begin_block(a.frame_begin, ctx);
@@ -492,9 +509,22 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
           F x[KT];
 #pragma unroll
           for (int j = 0; j < KT; ++j) x[j] = (F)0;
+#ifdef KNH_DAG_STAMPS
+          if constexpr (SlotCount<S...>::value == 0 && sizeof...(S) <= 8) {
+            u64 t_prev = __builtin_amdgcn_s_memtime();
+            chain.template tick_tile_stamped<KT>(x, ctx, n, st_stage, t_prev);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) my[j0 + j][lane] = x[j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_store += __builtin_amdgcn_s_memtime() - t_prev;
+            st_visits += 1;
+          } else
+#endif
+          {
           chain.template tick_tile<KT>(x, ctx, n);
 #pragma unroll
           for (int j = 0; j < KT; ++j) my[j0 + j][lane] = x[j];
+          }
           j0 += KT;
         } else if (KT > kTile && j0 + kTile <= len && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + kTile)) {
           F x[kTile];
@@ -522,6 +552,9 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
         pan_gain[wave][1][lane] = gr;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef KNH_DAG_STAMPS
+      const u64 st_f0 = __builtin_amdgcn_s_memtime();
+#endif
       if constexpr (!ChainT::kPan) {
         if ((u32)lane < len) partial_row[n0 + lane] = fold_group<F, 16>(&my[lane][0], 1, nv);
         if (a.voices_out) {
@@ -549,11 +582,27 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef KNH_DAG_STAMPS
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      st_fold += __builtin_amdgcn_s_memtime() - st_f0;
+#endif
     }
     // changes due exactly at the end of the processed range (precise_timing.rs:85-103 runs the
     // change loop once more before breaking out)
     apply_events_upto(base + a.frame_end);
   }
+#ifdef KNH_DAG_STAMPS
+  if (wave_global == 0u && lane == 0) {
+    // cycles per 64 samples of one voice group: [4 .. 11] the stages in chain order, [12] tile stores, [13] folds, [14] everything
+    const u64 samples = (u64)a.n_blocks * (a.frame_end - a.frame_begin);
+    const u64 d = samples > 0 ? samples : 1;
+    for (int k = 0; k < 8; ++k) a.flags[4 + k] = (u32)(st_stage[k] * 64 / d);
+    a.flags[12] = (u32)(st_store * 64 / d);
+    a.flags[13] = (u32)(st_fold * 64 / d);
+    a.flags[14] = (u32)((__builtin_amdgcn_s_memtime() - st_begin) * 64 / d);
+    a.flags[15] = (u32)(st_visits * KT * 64 / d);  // share of the samples that took the stamped (whole-visit) path, x 64
+  }
+#endif
 
   u32 done_frame = 0xFFFFFFFFu;
   if constexpr (SlotCount<S...>::value > 0) {  // a graph-shaped voice: its envelopes in the reference's task order, when that is not list order

@@ -35,6 +35,50 @@ enum class Value { Float, Trigger, Integer, Bool };  // ParameterValue, paramete
 
 inline knh_stage_desc stage(uint16_t kind) { return knh_stage_desc{kind, 0, 0, 0, 0, 0}; }  // lib.rs: stage()
 
+// ---- the reference's block views, as the shim sees them -------------------------------------------------------------
+// What `process_block` is handed is a `Block` / `BlockRead` (knaster_primitives/src/block.rs:33-263): per channel a slice,
+// `channel_as_slice[_mut](ch)`, and nothing else -- no base pointer, no promise that channel c + 1 follows channel c.
+template <typename F> struct Slice { F* ptr; size_t len; };
+// RawContiguousBlock (knaster_graph/src/block.rs:19-78): the graph's output buffer of a node, channel-major and contiguous
+template <typename F> struct ContiguousBlock {
+  F* base; size_t n_channels, bs;
+  Slice<F> channel_as_slice_mut(size_t ch) { return {base + ch * bs, bs}; }
+  size_t channels() const { return n_channels; }
+  size_t block_size() const { return bs; }
+  // Block::partial_mut (block.rs:190-196)
+  template <typename Self = ContiguousBlock> auto partial_mut(size_t start_offset, size_t length);
+};
+// PartialBlockMut (block.rs:307-339): `&mut block.channel_as_slice_mut(ch)[start_offset .. start_offset + length]` -- its
+// slices START AT THE OFFSET, and a partial view of a partial view adds the offsets up
+template <typename F, typename B> struct PartialBlockMut {
+  B* block; size_t start_offset, length;
+  Slice<F> channel_as_slice_mut(size_t ch) { Slice<F> s = block->channel_as_slice_mut(ch); return {s.ptr + start_offset, length}; }
+  size_t channels() const { return block->channels(); }
+  size_t block_size() const { return length; }
+  PartialBlockMut<F, PartialBlockMut> partial_mut(size_t off, size_t len) { return {this, off, len}; }
+};
+template <typename F> template <typename Self> auto ContiguousBlock<F>::partial_mut(size_t start_offset, size_t length) {
+  return PartialBlockMut<F, ContiguousBlock<F>>{this, start_offset, length};
+}
+// RawAggregateBlockRead (knaster_graph/src/block.rs:158-197): one pointer per input channel
+template <typename F> struct AggregateBlockRead {
+  const F* const* ch; size_t n_channels, bs;
+  Slice<const F> channel_as_slice(size_t c) const { return {ch[c], bs}; }
+};
+// PartialBlock (block.rs:269-302)
+template <typename F, typename B> struct PartialBlock {
+  const B* block; size_t start_offset, length;
+  Slice<const F> channel_as_slice(size_t c) const { Slice<const F> s = block->channel_as_slice(c); return {s.ptr + start_offset, length}; }
+};
+// BlockMetadata::make_partial (knaster_core/src/ugen.rs:87-93): offset and clock move on, the frame count is the partial one
+inline AudioCtx make_partial(const AudioCtx& c, size_t start_offset, size_t length) {
+  AudioCtx p = c;
+  p.block_start_offset = c.block_start_offset + start_offset;
+  p.frames_to_process = length;
+  p.frame_clock = c.frame_clock + start_offset;
+  return p;
+}
+
 template <typename F, unsigned INPUTS = 0>
 class GpuVoiceBank {
  public:
@@ -87,18 +131,25 @@ class GpuVoiceBank {
     block_size_ = block_size;
     in_pack_.assign((INPUTS + n_ar_) * block_size, F(0));
   }
-  // lib.rs: UGen::process_block -> [knh_bank_set_input] knh_bank_process_block
-  //   input: INPUTS channel pointers (the reference's RawAggregateBlockRead: one pointer per channel, block.rs:158-197),
-  //   output: contiguous channel-major [2][block_size] (RawContiguousBlock, block.rs:19-78)
-  int32_t process_block(AudioCtx& ctx, UGenFlags& flags, const F* const* input, F* output) {
+  // lib.rs: UGen::process_block -> [knh_bank_set_input] knh_bank_process_block_channels
+  //   input / output: the reference's block views above -- whole blocks from Task::run (task.rs:25-31), partial ones from a
+  //   splitting wrapper (precise_timing.rs:98-110).
+  template <typename InBlock, typename OutBlock>
+  int32_t process_block(AudioCtx& ctx, UGenFlags& flags, const InBlock& input, OutBlock& output) {
     if (!init_error_.empty()) {
-      std::memset(output, 0, 2 * block_size_ * sizeof(F));
+      for (size_t ch = 0; ch < 2; ++ch) {
+        Slice<F> s = output.channel_as_slice_mut(ch);
+        std::memset(s.ptr, 0, s.len * sizeof(F));
+      }
       return KNH_ERR_NOT_INITIALISED;
     }
     const size_t n_in = INPUTS + n_ar_;
     if (n_in > 0) {
       const size_t bs = block_size_, off = ctx.block_start_offset, ftp = ctx.frames_to_process;
-      for (size_t ch = 0; ch < INPUTS; ++ch) std::memcpy(&in_pack_[ch * bs + off], input[ch], std::min(ftp, bs - off) * sizeof(F));
+      for (size_t ch = 0; ch < INPUTS; ++ch) {
+        Slice<const F> src = input.channel_as_slice(ch);
+        std::memcpy(&in_pack_[ch * bs + off], src.ptr, std::min(std::min(src.len, ftp), bs - off) * sizeof(F));
+      }
       for (size_t k = 0; k < n_ar_; ++k) {
         F* dst = &in_pack_[(INPUTS + k) * bs];
         if (!ar_bufs_[k]) std::memset(dst, 0, bs * sizeof(F));
@@ -107,9 +158,16 @@ class GpuVoiceBank {
       (void)knh_bank_set_input(h_, 1, in_pack_.data());
     }
     uint32_t f = 0;
-    const int32_t rc = knh_bank_process_block(h_, ctx.frames_to_process, ctx.block_start_offset, ctx.frame_clock, output, &f);
+    void* out[2] = {output.channel_as_slice_mut(0).ptr, output.channel_as_slice_mut(1).ptr};
+    const int32_t rc = knh_bank_process_block_channels(h_, ctx.frames_to_process, ctx.block_start_offset, ctx.frame_clock, out, &f);
     if (f & KNH_FLAG_ALL_DONE) flags.mark_done(0);
     return rc;
+  }
+  // whole blocks as Task::run builds them: INPUTS channel pointers, one contiguous [2][block_size] output
+  int32_t process_block(AudioCtx& ctx, UGenFlags& flags, const F* const* input, F* output) {
+    AggregateBlockRead<F> in{input, INPUTS, block_size_};
+    ContiguousBlock<F> out{output, 2, block_size_};
+    return process_block(ctx, flags, in, out);
   }
   // lib.rs: UGen::param_apply -> knh_bank_param_apply
   int32_t param_apply(AudioCtx&, size_t index, Value kind, double f = 0.0, int64_t i = 0) {

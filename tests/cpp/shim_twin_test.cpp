@@ -154,28 +154,92 @@ static void gpu_c3_block_by_block_equals_one_launch() {
   CHECK(peak > 1e-4f);
 }
 
-// A partial block, then the rest (what a splitting wrapper around the node would ask for, ugen.rs:87-93): same samples
+// The bank under a splitting wrapper, called the way WrPreciseTiming::process_block calls the UGen it wraps
+// (knaster_core_dsp/src/wrappers_core/precise_timing.rs:65-114): for a change due at frame 40 of a 64-frame block,
+//   output.partial_mut(0, 40) + org_block.make_partial(0, 40), then output.partial_mut(40, 24) + make_partial(40, 24)
+// -- PartialBlockMut views whose slices START at the offset (knaster_primitives/src/block.rs:307-339) beside a ctx that
+// carries the same offset (ugen.rs:87-93).  Same samples as the whole block, nothing written outside the views.
+// `legacy` runs the shim's logic of rounds 1-3 (the start of channel 0's slice taken for the base of the block AND
+// block_start_offset handed on) against the same views: it writes frames [2 off, 2 off + n) and runs past the end of channel
+// 1 -- the test must be able to tell (the output buffer has a guard zone behind it for exactly that).
+static int32_t legacy_process_block(knh_bank* h, const AudioCtx& ctx, float* channel0_slice_start) {
+  uint32_t f = 0;
+  return knh_bank_process_block(h, ctx.frames_to_process, ctx.block_start_offset, ctx.frame_clock, channel0_slice_start, &f);
+}
 static void gpu_partial_blocks() {
-  const int N = 70, B = 64;
-  GpuVoiceBank<float> a(c3_chain(), N, c3_ctor(N)), b(c3_chain(), N, c3_ctor(N));
+  const int N = 70, B = 64, GUARD = 64;
+  GpuVoiceBank<float> a(c3_chain(), N, c3_ctor(N)), b(c3_chain(), N, c3_ctor(N)), old(c3_chain(), N, c3_ctor(N));
   a.init(48000, B);
   b.init(48000, B);
+  old.init(48000, B);
   AudioCtx ctx;
   UGenFlags flags;
   for (int v = 0; v < N; ++v) {
     a.param_apply(ctx, a.index(v, 3, "t_restart"), Value::Trigger);
     b.param_apply(ctx, b.index(v, 3, "t_restart"), Value::Trigger);
+    old.param_apply(ctx, old.index(v, 3, "t_restart"), Value::Trigger);
   }
-  std::vector<float> whole(2 * B), parts(2 * B, -7.f);
+  std::vector<float> whole(2 * B), parts(2 * B + GUARD), legacy(2 * B + GUARD);
+  bool legacy_differs = false, legacy_overruns = false;
+  AggregateBlockRead<float> no_input{nullptr, 0, size_t(B)};
   for (int blk = 0; blk < 3; ++blk) {
     ctx.block_start_offset = 0; ctx.frames_to_process = B;
     CHECK(a.process_block(ctx, flags, nullptr, whole.data()) == KNH_OK);
-    ctx.block_start_offset = 0; ctx.frames_to_process = 40;
-    CHECK(b.process_block(ctx, flags, nullptr, parts.data()) == KNH_OK);
-    ctx.block_start_offset = 40; ctx.frames_to_process = 24;
-    CHECK(b.process_block(ctx, flags, nullptr, parts.data()) == KNH_OK);
+    std::fill(parts.begin(), parts.end(), -7.f);
+    std::fill(legacy.begin(), legacy.end(), -7.f);
+    ContiguousBlock<float> out{parts.data(), 2, size_t(B)}, out_old{legacy.data(), 2, size_t(B)};
+    const size_t cuts[3][2] = {{0, 40}, {40, 24}, {0, 0}};
+    for (int part = 0; part < 2; ++part) {
+      const size_t off = cuts[part][0], len = cuts[part][1];
+      auto view = out.partial_mut(off, len);                                  // precise_timing.rs:103
+      AudioCtx pctx = make_partial(ctx, off, len);                            // precise_timing.rs:104-105
+      PartialBlock<float, AggregateBlockRead<float>> in_view{&no_input, off, len};  // precise_timing.rs:102
+      CHECK(b.process_block(pctx, flags, in_view, view) == KNH_OK);
+      auto view_old = out_old.partial_mut(off, len);
+      CHECK(legacy_process_block(old.raw(), pctx, view_old.channel_as_slice_mut(0).ptr) == KNH_OK);
+    }
     CHECK(std::memcmp(whole.data(), parts.data(), whole.size() * sizeof(float)) == 0);
+    for (int g = 0; g < GUARD; ++g) CHECK(parts[2 * B + g] == -7.f);  // nothing behind channel 1
+    legacy_differs = legacy_differs || std::memcmp(whole.data(), legacy.data(), whole.size() * sizeof(float)) != 0;
+    for (int g = 0; g < GUARD; ++g) legacy_overruns = legacy_overruns || legacy[2 * B + g] != -7.f;
     ctx.frame_clock += B;
+  }
+  CHECK(legacy_differs);   // the old logic puts the second part at frames [80, 104) of a 64-frame channel ...
+  CHECK(legacy_overruns);  // ... i.e. past the end of channel 1
+  // a partial view of a partial view (a splitting wrapper inside another): offsets add up on both sides
+  {
+    ctx.block_start_offset = 0; ctx.frames_to_process = B;
+    CHECK(a.process_block(ctx, flags, nullptr, whole.data()) == KNH_OK);
+    std::fill(parts.begin(), parts.end(), -7.f);
+    ContiguousBlock<float> out{parts.data(), 2, size_t(B)};
+    auto first = out.partial_mut(0, 16);
+    AudioCtx c0 = make_partial(ctx, 0, 16);
+    PartialBlock<float, AggregateBlockRead<float>> in0{&no_input, 0, 16};
+    CHECK(b.process_block(c0, flags, in0, first) == KNH_OK);
+    auto rest = out.partial_mut(16, 48);
+    AudioCtx c1 = make_partial(ctx, 16, 48);
+    auto rest_a = rest.partial_mut(0, 20);
+    auto rest_b = rest.partial_mut(20, 28);
+    AudioCtx c1a = make_partial(c1, 0, 20), c1b = make_partial(c1, 20, 28);
+    CHECK(c1b.block_start_offset == 36 && c1b.frame_clock == ctx.frame_clock + 36);
+    PartialBlock<float, AggregateBlockRead<float>> in1{&no_input, 16, 20}, in2{&no_input, 36, 28};
+    CHECK(b.process_block(c1a, flags, in1, rest_a) == KNH_OK);
+    CHECK(b.process_block(c1b, flags, in2, rest_b) == KNH_OK);
+    CHECK(std::memcmp(whole.data(), parts.data(), whole.size() * sizeof(float)) == 0);
+    for (int g = 0; g < GUARD; ++g) CHECK(parts[2 * B + g] == -7.f);
+  }
+  // channels that do not follow each other in memory (the Block trait promises one slice per channel, nothing more)
+  {
+    ctx.frame_clock += B;
+    CHECK(a.process_block(ctx, flags, nullptr, whole.data()) == KNH_OK);
+    std::vector<float> left(B, -7.f), right(B, -7.f);
+    struct TwoBuffers {
+      float* ch[2]; size_t bs;
+      Slice<float> channel_as_slice_mut(size_t c) { return {ch[c], bs}; }
+    } apart{{right.data(), left.data()}, size_t(B)};  // channel 0 BEHIND channel 1
+    CHECK(b.process_block(ctx, flags, no_input, apart) == KNH_OK);
+    CHECK(std::memcmp(whole.data(), right.data(), B * sizeof(float)) == 0);
+    CHECK(std::memcmp(whole.data() + B, left.data(), B * sizeof(float)) == 0);
   }
 }
 

@@ -155,6 +155,65 @@ def test_two_ranks_in_one_process_partition_the_voices(knh):
         b.close()
 
 
+def test_eight_ranks_in_one_process_split_c4(knh):
+    """BASELINE.json's C4 split as north_star splits it -- 65 536 f64 voices, 8 ranks x 8 192 -- with all eight ranks in THIS
+    process (a reduce function that leaves the buffers alone): every rank renders exactly the contiguous range
+    knh_shard_voice_range gives it, from the same global parameter stream (calls for the other ranks' voices dropped), and the
+    eight partial mixes add up to the one-GPU bank's mix.  What depends on the NUMBER of ranks (ranges, routing, the reduce's
+    shape and root) is exercised without the hardware; the RCCL sum itself is one ncclReduce (test_rccl_communicator_with_one_rank)."""
+    n, bs, world = 65536, 512, 8
+    w = configs.config("C4", n_voices=n, block_size=bs)
+    assert w.sample_type == L.F64
+    seen = []
+
+    def no_reduce(_user, buf, count, sample_type, root, stream):
+        seen.append((count, sample_type, root))
+        return 0
+    ranks = [_bank(knh, w, rank=r, world=world, reduce_fn=no_reduce) for r in range(world)]
+    plain = _bank(knh, w)
+    ranges = [knh.shard_voice_range(n, r, world) for r in range(world)]
+    assert ranges == [(r * 8192, 8192) for r in range(world)]
+    own = {}
+    for r in (0, 3, 7):  # three of the ranges as plain banks of their own
+        lo, cnt = ranges[r]
+        ws = configs.config("C4", n_voices=n, block_size=bs)
+        ws.n_voices = cnt
+        ws.ctor = {s: a[lo:lo + cnt] for s, a in w.ctor.items()}
+        own[r] = _bank(knh, ws)
+    v = np.arange(n, dtype=np.uint32)
+    cut = 300.0 + (v[::3] % 1000)  # new SvfFilter cutoffs for every third voice (below Nyquist, unlike _script's at this size)
+    for launch in range(2):
+        for b in ranks + [plain]:  # the same GLOBAL parameter stream to every rank
+            if launch == 0:
+                fire_all(b, n, *w.restart)
+                b.param_apply_many(v[::3], 2, 0, L.VALUE_FLOAT, cut, block_offset=1)
+            if launch == 1:
+                b.param_apply_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER, block_offset=2)
+                b.param_apply(n - 1, 0, 0, 777.0)
+        for r, b in own.items():  # the same events in local indices
+            lo, cnt = ranges[r]
+            vl = np.arange(cnt, dtype=np.uint32)
+            if launch == 0:
+                fire_all(b, cnt, *w.restart)
+                g = v[::3]
+                g = g[(g >= lo) & (g < lo + cnt)]
+                b.param_apply_many(g - lo, 2, 0, L.VALUE_FLOAT, 300.0 + (g % 1000), block_offset=1)
+            if launch == 1:
+                b.param_apply_many(vl, w.release[0], w.release[1], L.VALUE_TRIGGER, block_offset=2)
+                if lo <= n - 1 < lo + cnt:
+                    b.param_apply(n - 1 - lo, 0, 0, 777.0)
+        outs = [b.process_blocks(3)[0] for b in ranks]
+        want, _ = plain.process_blocks(3)
+        for r, b in own.items():
+            assert_bit_equal(outs[r], b.process_blocks(3)[0], f"rank {r} launch {launch}: its own range, nothing else")
+        total = np.sum(np.stack(outs).astype(np.float64), axis=0)
+        assert np.isfinite(want).all() and np.max(np.abs(total - want)) <= 1e-12 and np.abs(want).max() > 1e-4
+    assert len(seen) == 2 * world and all(s == (3 * 2 * bs, 1, 0) for s in seen)
+    assert all(b.ranks() == world for b in ranks)
+    for b in ranks + [plain] + list(own.values()):
+        b.close()
+
+
 def test_rccl_communicator_with_one_rank(knh):
     """The RCCL path itself, with the one rank a one-GPU box allows: id, ncclCommInitRank, ncclCommCount, an in-place
     ncclReduce on the communicator's stream ordered after the producer stream, the waits."""
