@@ -31,6 +31,7 @@ struct Rccl {
   decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
   std::string error;
@@ -56,6 +57,7 @@ Rccl* rccl() {
     r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.Reduce = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
   });
@@ -233,6 +235,29 @@ int32_t knh_comm_reduce_sum(knh_comm* c, void* buf, size_t count, uint32_t sampl
   });
 }
 
+// The minimum over all ranks of one status word (1 = this rank is fine), on the communicator's stream, waited for: how the
+// ranks of a bank agree at the end of knh_bank_init that EVERY rank's own voices came up -- a rank that failed and left
+// would otherwise leave the others blocked in their first ncclReduce.  Not part of the C ABI (rank_bank.hpp calls it).
+int32_t knh_comm_all_min(knh_comm* c, int32_t value, int32_t* out) {
+  return comm_guarded(c, [&]() -> int32_t {
+    if (!c || !out) return KNH_ERR_INVALID_ARGUMENT;
+    *out = value;
+    if (c->world <= 1) return KNH_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipSetDevice failed");
+    int32_t* d = nullptr;
+    if (hipMalloc(&d, sizeof(int32_t)) != hipSuccess) return c->fail(KNH_ERR_DEVICE, "hipMalloc failed");
+    int32_t rc_out = KNH_OK;
+    if (hipMemcpyAsync(d, &value, sizeof value, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc_out = c->fail(KNH_ERR_DEVICE, "hipMemcpyAsync failed");
+    if (rc_out == KNH_OK) {
+      const ncclResult_t rc = rccl()->AllReduce(d, d, 1, ncclInt32, ncclMin, c->comm, c->stream);
+      if (rc != ncclSuccess) rc_out = c->fail(KNH_ERR_DEVICE, std::string("ncclAllReduce: ") + rccl()->GetErrorString(rc));
+    }
+    if (rc_out == KNH_OK && (hipMemcpyAsync(out, d, sizeof value, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+      rc_out = c->fail(KNH_ERR_DEVICE, "reading the agreed status failed");
+    (void)hipFree(d);
+    return rc_out;
+  });
+}
 int32_t knh_comm_wait_buffer(knh_comm* c, const void* buf, void* stream) {
   return comm_guarded(c, [&]() -> int32_t {
     if (!c) return KNH_ERR_INVALID_ARGUMENT;

@@ -13,6 +13,7 @@ struct JitKernel {
   hipFunction_t fn = nullptr;  // voice_kernel<F, FMA, 1, Stages...> or voice_pipe_kernel<F, FMA, Group<...>...>
   std::string lowered_name;
   unsigned block_threads = 64;  // one wavefront, or (groups + 1) wavefronts for a pipelined kernel
+  unsigned groups_per_workgroup = 1;  // 64-voice groups one workgroup renders (whole-chain wavefronts: 4, 8 or 16 of them)
 };
 
 // Where this process's kernels came from so far (knh_jit_stats): the in-memory table, the code-object cache on disk, a
@@ -22,7 +23,9 @@ JitStats jit_stats();
 
 // signature: kernel_registry.hpp's one-character-per-stage string.  Returns nullptr and sets *error on failure (an error
 // that starts with "JIT_CRASH: " = the compiler died or hung in the helper process: KNH_ERR_INTERNAL, not a bad chain).
-const JitKernel* jit_voice_kernel(const char* signature, bool f64, bool fma, std::string* error);
+// waves: 1 = the one-wavefront kernel; 4 / 8 / 16 = that many whole-chain wavefronts (64-voice groups) per workgroup, sharing
+// one staged sine table: the form of banks with more groups than the pipeline covers (voice_chain.hpp, voice_kernel's WAVES).
+const JitKernel* jit_voice_kernel(const char* signature, bool f64, bool fma, std::string* error, unsigned waves = 1);
 
 // The same chain as a wave pipeline: `cuts` holds the index of the first stage of every group after the first
 // (ascending, inside the signature), e.g. "WmSA" with cuts {2, 3} = Group<W,m>, Group<S>, Group<A>.

@@ -51,6 +51,8 @@ struct EventResolveArgs {
   DevRec* dev_recs;         // [n_recs]: the records in device memory (the counting kernel copies them: one pass over PCIe)
   u32* out_start;           // [n_voices + 1]: the launch's ev_start
   Event* out_events;        // [host events + value records]
+  u32* overflow;            // mapped pinned host word: set when a change found its node's WrPreciseTiming queue full and was dropped
+                            // (the reference logs "Not enough space for scheduled changes", precise_timing.rs:129-134; so does the host)
 };
 }  // namespace knh_dev
 

@@ -210,7 +210,11 @@ __global__ void __launch_bounds__(64) ev_resolve_kernel(EventResolveArgs a) {
       continue;
     }
     Q& qq = q[S.widx < kMaxWrapped ? S.widx : 0];
-    if (qq.taken >= S.dcpb) { qq.taken = S.dcpb + 1u; continue; }  // the queue was full when this change arrived (:129-134)
+    if (qq.taken >= S.dcpb) {  // the queue was full when this change arrived (:129-134): dropped, and the host is told (once per launch is enough)
+      if (qq.taken == S.dcpb && a.overflow) *a.overflow = 1u;
+      qq.taken = S.dcpb + 1u;
+      continue;
+    }
     qq.taken += 1u;
     if (qq.blocked) continue;  // behind a change that is not due in this block: never reached
     const u32 due = armed > qq.at ? armed : qq.at;

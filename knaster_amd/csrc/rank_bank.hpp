@@ -10,6 +10,9 @@
 // function the host supplies (tests run two ranks on one GPU that way, where RCCL refuses to put two ranks).
 // Reduction order across ranks is RCCL's, not the reference's left fold: covered by the mix tolerance, like the tree mix.
 #pragma once
+// comm.hip: the minimum over all ranks of one status word (an internal helper beside the C ABI's knh_comm_* functions)
+extern "C" int32_t knh_comm_all_min(knh_comm* comm, int32_t value, int32_t* out);
+
 
 namespace {
 
@@ -93,16 +96,28 @@ struct RankBank final : knh_bank {
       if (own_stream) { (void)hipStreamDestroy(own_stream); own_stream = nullptr; }
       return rc;
     };
-    // the communicator first: creating it is a collective of all ranks, and a rank whose own voices then fail to come up
-    // must not leave the others waiting in it
+    // the communicator first: creating it is a collective of all ranks; the ranks then agree, over it, that every one of
+    // them brought its own voices up (below) before any of them calls the bank initialised
     if (world > 1 && !custom) {
       int rc = knh_comm_create(rank, world, comm_id, device, &comm);
       if (rc != KNH_OK) return undo(fail(rc, std::string("knh_comm_create: ") + knh_comm_last_error(nullptr)));
       if (knh_comm_world(comm) != world) return undo(fail(KNH_ERR_DEVICE, "RCCL reports a different number of ranks than the host asked for"));
     }
-    if (local) {
-      int rc = local->init(sr, bs);
-      if (rc != KNH_OK) return undo(adopt(rc));
+    int local_rc = KNH_OK;
+    if (local) local_rc = local->init(sr, bs);
+    if (local_rc != KNH_OK) adopt(local_rc);
+    if (comm) {
+      // every rank says whether its own voices came up, and every rank learns whether all did: a rank that failed and left
+      // would leave the others blocked in their first ncclReduce.  (A host-supplied reduce function has no such channel: there
+      // the host takes every rank down when one rank's init fails.)
+      int32_t all_ok = 0;
+      const std::string mine_err = err;
+      const int rc = knh_comm_all_min(comm, local_rc == KNH_OK ? 1 : 0, &all_ok);
+      if (rc != KNH_OK) return undo(fail(rc, std::string("agreeing on knh_bank_init across the ranks: ") + knh_comm_last_error(comm)));
+      if (local_rc != KNH_OK) { err = mine_err; return undo(local_rc); }
+      if (!all_ok) return undo(fail(KNH_ERR_DEVICE, "knh_bank_init failed on another rank of this bank: no rank keeps it"));
+    } else if (local_rc != KNH_OK) {
+      return undo(local_rc);
     }
     sample_rate = sr;
     block_size = bs;

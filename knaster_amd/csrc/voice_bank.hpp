@@ -143,6 +143,7 @@ struct Bank final : knh_bank {
   size_t d_out_cap2[2] = {0, 0};
   unsigned out_parity = 0;
   int out_in_use = -1;                        // the set the voice kernel being launched reads
+  uint32_t* h_ev_overflow = nullptr;          // mapped pinned: a resolver kernel found a change queue full (looked at by the next process call)
   static bool dev_resolvable_kind(uint16_t kind) {
     switch (kind) {
       case KNH_STAGE_SIN_WT: case KNH_STAGE_SIN_NUMERIC: case KNH_STAGE_MUL_ENV_ASR: case KNH_STAGE_MUL_ENV_AR:
@@ -252,6 +253,7 @@ struct Bank final : knh_bank {
     ra.dev_recs = d_recs;
     ra.out_start = d_out_start2[set];
     ra.out_events = d_out_events2[set];
+    ra.overflow = h_ev_overflow;
     KNH_HIP(knh::launch_resolve_events(ra, ev_stream));
     KNH_HIP(hipEventRecord(recs_done[b], ev_stream));  // the records are read, and the lists complete: one event says both
     recs_busy[b] = true;
@@ -320,11 +322,15 @@ struct Bank final : knh_bank {
 
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
+    // everything that may still read or write this bank's memory has finished before any of it is freed: the bank's own
+    // stream, the resolver's (its kernels read the pinned record and event lists), and the stream the last launch was given
     if (own_stream) (void)hipStreamSynchronize(own_stream);
+    if (ev_stream) (void)hipStreamSynchronize(ev_stream);
+    if (flags_stream_set && flags_stream != own_stream) (void)hipStreamSynchronize(flags_stream);
     void* dev_ptrs[] = {d_state, d_sine, d_seg_table, d_delay, d_buffer, d_partials, d_out, d_voices, d_done, d_flags, d_input, d_prog, d_sin_slots, d_fold_count};
     for (void* p : dev_ptrs)
       if (p) (void)hipFree(p);
-    void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out, h_input, h_done};
+    void* host_ptrs[] = {h_ev_start2[0], h_ev_start2[1], h_events2[0], h_events2[1], h_out, h_input, h_done, h_ev_overflow};
     for (void* p : host_ptrs)
       if (p) (void)hipHostFree(p);
     for (hipEvent_t e : list_done)
@@ -554,7 +560,15 @@ struct Bank final : knh_bank {
       if (!jit) return fail(why.rfind("JIT_CRASH: ", 0) == 0 ? KNH_ERR_INTERNAL : KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' (pipelined) failed: " + why);
     } else if (!entry && !interp) {  // no pre-built kernel at all
       std::string why;
-      jit = knh::jit_voice_kernel(signature.c_str(), sizeof(F) == 8, desc.allow_fma != 0, &why);
+      // Beyond the pipeline's reach (more than 512 voice groups) a fused chain runs as whole-chain wavefronts sharing a staged
+      // sine table, four to a workgroup (one per SIMD) up to 1 024 groups, eight beyond -- the forms of the pre-built
+      // chains (make_bank); round 3 gave every fused voice group a workgroup, and a 64 KiB table staging, of its own.
+      // A voice that is a graph keeps the one-wavefront form (its signals' registers leave no room to share a SIMD).
+      // KNH_JIT_WAVES=1|4|8|16 overrides (tests: the filter's steps at one, two and four wavefronts per SIMD).
+      unsigned jw = !signature_is_dag(signature) && n_groups > 512 ? (n_groups <= 1024 ? 4u : 8u) : 1u;
+      if (const char* e = std::getenv("KNH_JIT_WAVES")) { const int v = std::atoi(e); if ((v == 1 || v == 4 || v == 8 || v == 16) && !signature_is_dag(signature)) jw = static_cast<unsigned>(v); }
+      if (sizeof(F) == 8 && jw == 16) jw = 8;  // (sixteen f64 tiles do not fit beside the table)
+      jit = knh::jit_voice_kernel(signature.c_str(), sizeof(F) == 8, desc.allow_fma != 0, &why, jw);
       if (!jit) return fail(why.rfind("JIT_CRASH: ", 0) == 0 ? KNH_ERR_INTERNAL : KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' failed: " + why);
     }
     sample_rate = sr;
@@ -888,6 +902,8 @@ struct Bank final : knh_bank {
       if (dev_events) {
         KNH_HIP(hipMalloc(&d_stages, ds.size() * sizeof(knh_dev::DevStage)));
         KNH_HIP(hipMemcpy(d_stages, ds.data(), ds.size() * sizeof(knh_dev::DevStage), hipMemcpyHostToDevice));
+        KNH_HIP(hipHostMalloc(&h_ev_overflow, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *h_ev_overflow = 0u;
         KNH_HIP(hipMalloc(&d_armed, static_cast<size_t>(n_params_total) * nv * sizeof(uint16_t)));
         KNH_HIP(hipMemset(d_armed, 0, static_cast<size_t>(n_params_total) * nv * sizeof(uint16_t)));
         KNH_HIP(hipMalloc(&d_ev_cnt, static_cast<size_t>(nv) * 3 * sizeof(uint32_t)));
@@ -1567,6 +1583,10 @@ struct Bank final : knh_bank {
     if (n_blocks > 1 && voices_host) return fail(KNH_ERR_INVALID_ARGUMENT, "per-voice output is only available for single blocks");
     KNH_HIP(hipSetDevice(device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : own_stream;
+    if (h_ev_overflow && __atomic_load_n(h_ev_overflow, __ATOMIC_RELAXED) != 0u) {  // a resolver kernel of an earlier launch dropped a change
+      __atomic_store_n(h_ev_overflow, 0u, __ATOMIC_RELAXED);
+      warn("Not enough space for scheduled changes in WrPreciseTiming, change ignored");
+    }
     const uint32_t fb = static_cast<uint32_t>(offset), fe = static_cast<uint32_t>(offset + ftp);
     // Assemble the launch's state patches block by block, in the order the reference would apply them.
     for (uint32_t b = 0; b < n_blocks; ++b) {

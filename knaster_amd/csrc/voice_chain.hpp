@@ -400,33 +400,150 @@ __device__ __forceinline__ void fold_group_pan(const F* col, int st, const F* gl
   else tree_cols_pan<F, 64, false, B>(col, st, gl, gr, gst, nv, l, r);
 }
 
-// LDS: sine table (64 KiB, only if a stage uses it) + one [TN][68] transpose tile per wave.
-// WAVES = wavefronts (64-voice groups) per workgroup sharing the table: 1 for small banks, 4 or 8 when
+// ---------------------------------------------------------------------------
+// The wavefront's subtree of KNH_MIX_TREE WITHOUT a trip through LDS (round 4; the whole-chain kernels): a butterfly over the
+// lanes.  Every lane holds N consecutive frames of its voice in registers.  At level k the lane meets the lane that holds the
+// sibling subtree -- the voice whose index differs in bit k -- keeps one half of its frames, hands the other half over, and
+// adds what it receives: after level k it holds level-k + 1 nodes for half as many frames.  Once a lane is down to one frame
+// the remaining levels are plain exchanges (both lanes form the same sum).  The additions are those of tree_reduce, operands
+// possibly swapped (IEEE addition commutes): the same bits.
+// Which lanes meet is a matter of what the hardware exchanges in one instruction, so the voices of a wavefront are dealt to
+// its lanes accordingly (fold_voice_of_lane): voice bit 0 <-> lanes l and l ^ 32 (v_permlane32_swap), bit 1 <-> l ^ 16
+// (v_permlane16_swap), bit 2 <-> l ^ 15 (DPP row_mirror), bit 3 <-> l ^ 7 (row_half_mirror), bit 4 <-> l ^ 2, bit 5 <-> l ^ 1
+// (quad_perm).  The state rows are read and written with that permutation: still one coalesced 256-byte access per row.
+// Measured before (profiles/r04_wide_stamps_*): the tile's LDS stores and the column-wise fold were 3 650 of the 13 000 cycles an
+// f64 wavefront spends per 64 samples (1 800 of 8 500 in f32), on half-empty wavefronts (a 32-frame tile has 32 columns).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 fold_voice_of_lane(u32 l) {
+  const u32 b0 = (l >> 5) & 1u, b1 = (l >> 4) & 1u, b2 = (l >> 3) & 1u, b3 = ((l >> 2) ^ (l >> 3)) & 1u, b4 = ((l >> 1) ^ (l >> 2)) & 1u, b5 = (l ^ (l >> 2)) & 1u;
+  return b0 | (b1 << 1) | (b2 << 2) | (b3 << 3) | (b4 << 4) | (b5 << 5);
+}
+// what the lane's partner of level K holds in `v` (K = 0, 1 are done with the swap instructions below: not here)
+template <int K, typename F> __device__ __forceinline__ F fold_from_partner(F v) {
+  static_assert(K >= 2 && K <= 5, "levels 2..5 are DPP exchanges");
+  constexpr int ctrl = K == 2 ? 0x140 /* row_mirror */ : K == 3 ? 0x141 /* row_half_mirror */ : K == 4 ? 0x4E /* quad_perm [2,3,0,1] */ : 0xB1 /* quad_perm [1,0,3,2] */;
+  return __builtin_amdgcn_update_dpp((F)0, v, ctrl, 0xF, 0xF, true);
+}
+// lanes whose voice has bit 0 (bit 1) set hold X = the partner's X... : a's upper rows swapped with b's lower rows.  After it,
+// in EVERY lane, a and b are the two values of one frame -- the lane's own and its partner's -- for the half the lane keeps.
+template <int K> __device__ __forceinline__ void fold_swap(float& a, float& b) {
+  static_assert(K == 0 || K == 1, "levels 0 and 1 are the swap instructions");
+  typedef u32 v2 __attribute__((ext_vector_type(2)));
+  const v2 r = K == 0 ? __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(u32, a), __builtin_bit_cast(u32, b), false, false)
+                      : __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(u32, a), __builtin_bit_cast(u32, b), false, false);
+  // (the elements go through scalars of their own: __builtin_bit_cast applied to r[1] directly reads r[0] with this compiler)
+  const u32 r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+template <int K> __device__ __forceinline__ void fold_swap(double& a, double& b) {
+  typedef u32 v2 __attribute__((ext_vector_type(2)));
+  const u64 ua = __builtin_bit_cast(u64, a), ub = __builtin_bit_cast(u64, b);
+  const v2 lo = K == 0 ? __builtin_amdgcn_permlane32_swap((u32)ua, (u32)ub, false, false) : __builtin_amdgcn_permlane16_swap((u32)ua, (u32)ub, false, false);
+  const v2 hi = K == 0 ? __builtin_amdgcn_permlane32_swap((u32)(ua >> 32), (u32)(ub >> 32), false, false)
+                       : __builtin_amdgcn_permlane16_swap((u32)(ua >> 32), (u32)(ub >> 32), false, false);
+  a = __builtin_bit_cast(double, (u64)lo[0] | ((u64)hi[0] << 32));
+  b = __builtin_bit_cast(double, (u64)lo[1] | ((u64)hi[1] << 32));
+}
+// One lane's view of the fold: its voice index inside the wavefront, and per level whether its own subtree and its sibling's
+// hold any live voice (a node without a right neighbour passes through; a dead right-hand lane takes over what its live
+// partner hands it, so that every lane ends with the sum for the frame it owns).
+struct FoldLane {
+  u32 v;   // voice index in the wavefront (0..63) of this lane
+  u32 nv;  // live voices of the wavefront
+  template <int K> __device__ __forceinline__ bool bit() const { return ((v >> K) & 1u) != 0u; }
+  template <int K> __device__ __forceinline__ bool own() const { return ((v >> K) << K) < nv; }
+  template <int K> __device__ __forceinline__ bool sibling() const { return (((v >> K) ^ 1u) << K) < nv; }
+};
+template <int K, bool FULL, typename F> __device__ __forceinline__ F fold_join(const FoldLane& fl, F keep, F recv) {
+  const F sum = keep + recv;
+  if (FULL) return sum;
+  return fl.own<K>() ? (fl.sibling<K>() ? sum : keep) : recv;
+}
+template <int K, int N, bool FULL, typename F> struct FoldLevels {
+  // x[0..N): N frames of level-K nodes.  Returns the lane's sum over all 64 voices for the frame it ends up owning.
+  static __device__ __forceinline__ F run(const FoldLane& fl, F (&x)[N]) {
+    if constexpr (K == 6) {
+      static_assert(N == 1, "six levels fold 64 lanes");
+      return x[0];
+    } else if constexpr (N == 1) {  // down to one frame: both lanes of a pair form the same sum
+      F recv;
+      if constexpr (K <= 1) {
+        // (the swap hands the upper lanes' `a` to the lower lanes' `b` and back: with a = b = x both lanes see both values)
+        F a = x[0], b = x[0];
+        fold_swap<K>(a, b);
+        recv = fl.bit<K>() ? a : b;
+      } else {
+        recv = fold_from_partner<K>(x[0]);
+      }
+      F y[1] = {fold_join<K, FULL>(fl, x[0], recv)};
+      return FoldLevels<K + 1, 1, FULL, F>::run(fl, y);
+    } else {
+      F y[N / 2];
+      if constexpr (K <= 1) {
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+          F a = x[k], b = x[k + N / 2];
+          fold_swap<K>(a, b);  // lanes without the bit: a = own lower-half frame, b = the partner's; with it: b = own upper-half frame, a = the partner's
+          if (FULL) y[k] = a + b;
+          else y[k] = fold_join<K, false>(fl, fl.bit<K>() ? b : a, fl.bit<K>() ? a : b);
+        }
+      } else {
+        const bool up = fl.bit<K>();
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+          const F keep = up ? x[k + N / 2] : x[k];
+          const F give = up ? x[k] : x[k + N / 2];
+          y[k] = fold_join<K, FULL>(fl, keep, fold_from_partner<K>(give));
+        }
+      }
+      return FoldLevels<K + 1, N / 2, FULL, F>::run(fl, y);
+    }
+  }
+};
+// the frame of x[0..N) a lane owns after the fold (N a power of two <= 64), and whether it is the lane that writes it (of the
+// lanes that end with the same frame -- N < 64 -- the one whose remaining voice bits are zero)
+template <int N> __device__ __forceinline__ u32 fold_frame_of(u32 v, bool& writer) {
+  u32 f = 0;
+  int n = N, k = 0;
+#pragma unroll
+  for (; n > 1; n >>= 1, ++k) f += ((v >> k) & 1u) * (u32)(n >> 1);
+  writer = (v >> k) == 0u;
+  return f;
+}
+template <int N, typename F> __device__ __forceinline__ F wave_tree_fold(const FoldLane& fl, F (&x)[N]) {
+  if (__builtin_expect(fl.nv == 64u, 1)) return FoldLevels<0, N, true, F>::run(fl, x);
+  // the last wavefront of a bank whose voice count is not a multiple of 64: its eighteen lane masks (own / sibling / bit per
+  // level) are formed here, behind a barrier the optimiser cannot hoist them across -- kept live through the kernel's main
+  // loop they were spilled, and read back lane by lane, on the full wavefronts' path too
+  FoldLane cold = fl;
+  asm volatile("" : "+v"(cold.v), "+v"(cold.nv));
+  return FoldLevels<0, N, false, F>::run(cold, x);
+}
+
+// LDS: the sine table (64 KiB, only if a stage uses it) + eight rows of 64 samples per wavefront for the sample-by-sample path.
+// WAVES = wavefronts (64-voice groups) per workgroup sharing the table: 1 for small banks, 4, 8 or 16 when
 // the bank has more 64-voice groups than the chip has SIMDs to give each its own (throughput regime).
+// The voices' samples never leave the registers on the fast path: each visit's frames are folded over the wavefront's
+// voices by wave_tree_fold (above) and the sums go straight to the wavefront's partial row.
 template <typename F, bool FMA, int WAVES, typename... S>
 __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a) {
   typedef typename ChainSelect<(SlotCount<S...>::value > 0), F, FMA, S...>::type ChainT;
   typedef typename WordOf<F>::type W;
-  // frames per reduce tile: sized so that WAVES tiles + the sine table fit the CU's 160 KiB of LDS
-  constexpr int TN = (sizeof(F) == 4 ? 64 : 32) / (WAVES >= 16 ? 4 : (WAVES >= 8 ? 2 : 1));
-  // samples evaluated stage by stage in registers per visit: up to 32 (the per-visit costs -- event test, the filter's choice of
-  // step, register set-up around its fixed-register code -- are paid a quarter as often as with the eight of rounds 1-2:
-  // 53.7 -> 39.9 us per block at 131 072 voices, C4's 65 536 f64 voices 50.5 -> 38.0, C1's one voice 2.43 -> 1.94)
+  // samples evaluated stage by stage in registers per visit: 32 (the per-visit costs -- event test, the filter's choice of step,
+  // register set-up around its fixed-register code -- are paid a quarter as often as with the eight of rounds 1-2:
+  // 53.7 -> 39.9 us per block at 131 072 voices, C4's 65 536 f64 voices 50.5 -> 38.0, C1's one voice 2.43 -> 1.94); sixteen
+  // wavefronts per workgroup have 128 registers each: 16 samples in f32, 8 in f64
   // (a voice of more than sixteen stages -- a graph, as a rule -- keeps the eight-sample visits: every stage's tile code is
   // unrolled per visit length, and hiprtc needs minutes for a 200-stage voice at 32 + 8 samples where it needs seconds at 8)
-  constexpr int KT = sizeof...(S) > 16 ? kTile : (TN < 32 ? TN : 32);
-  constexpr int TS = 68;                        // row stride: 16-B aligned rows, conflict-free column
-                                                // writes (ds_write_b32) and row reads (ds_read_b128)
+  constexpr int KT = sizeof...(S) > 16 ? kTile : (WAVES >= 16 ? (sizeof(F) == 4 ? 16 : 8) : 32);
   // (one LDS object with the table first: the table at LDS address 0, a table read's address is the masked phase itself)
   struct Lds {
     float sine[ChainT::kUsesSine ? 16384 : 4];
-    __attribute__((aligned(16))) F tile[WAVES][TN][TS];
-    __attribute__((aligned(16))) F pan_gain[ChainT::kPan ? WAVES : 1][2][ChainT::kPan ? 64 : 1];  // [wave][left, right][voice]
+    __attribute__((aligned(16))) F slow[WAVES][kTile][64];  // the sample-by-sample path's samples, [frame][lane]
   };
   __shared__ Lds lds;
   auto& sine = lds.sine;
-  auto& tile = lds.tile;
-  auto& pan_gain = lds.pan_gain;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -460,8 +577,12 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   const u32 v0 = wave_global * 64u;
   if (v0 >= a.n_voices) return;
   const u32 nv = a.n_voices - v0 < 64u ? a.n_voices - v0 : 64u;  // live voices in this wave
-  const bool live = (u32)lane < nv;
-  const u32 voice = live ? v0 + lane : v0 + nv - 1;  // idle lanes shadow the last live voice, never store
+  // the wavefront's voices are dealt to its lanes the way the fold exchanges them (fold_voice_of_lane)
+  FoldLane fl;
+  fl.v = fold_voice_of_lane((u32)lane);
+  fl.nv = nv;
+  const bool live = fl.v < nv;
+  const u32 voice = live ? v0 + fl.v : v0 + nv - 1;  // idle lanes shadow the last live voice, never store
 
   ChainT chain;
   chain.load(a.state + voice, a.stride);
@@ -488,104 +609,100 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   };
 
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
-  F(*my)[TS] = tile[wave];
-#ifdef KNH_DAG_STAMPS  // diagnostic build only: cycles of this wavefront per stage, per tile store and per fold (tools/wide_stamps.py)
-  u64 st_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_store = 0, st_fold = 0, st_visits = 0;
+#ifdef KNH_DAG_STAMPS  // diagnostic build only: cycles of this wavefront per stage and per fold (tools/wide_stamps.py)
+  u64 st_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_fold = 0, st_visits = 0;
   const u64 st_begin = __builtin_amdgcn_s_memtime();
 #endif
+  F pan_l = (F)0, pan_r = (F)0;
   for (u32 b = 0; b < a.n_blocks; ++b, base += a.block_size) {
     ctx.input_block = reinterpret_cast<const F*>(a.input) + (long)b * a.in_channels * a.block_size;
     chain.begin_block(a.frame_begin, ctx);
-    F* partial_row = a.partials + ((long)b * n_waves_total + wave_global) * a.block_size;
-    for (u32 n0 = a.frame_begin; n0 < a.frame_end; n0 += TN) {
-      const u32 len = a.frame_end - n0 < (u32)TN ? a.frame_end - n0 : (u32)TN;
-      // visits of KT samples where a whole one fits and no voice of the wavefront has a change inside it, of eight samples
-      // where that holds for eight (the rest of a tile that is not a multiple of KT long, the neighbourhood of a change),
-      // sample by sample (changes applied in front of their frame) for what is left
-      for (u32 j0 = 0; j0 < len;) {
-        const u32 n = n0 + j0;
-        apply_events_upto(base + n);
-        if (j0 + KT <= len && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + KT)) {
-          F x[KT];
-#pragma unroll
-          for (int j = 0; j < KT; ++j) x[j] = (F)0;
-#ifdef KNH_DAG_STAMPS
-          if constexpr (SlotCount<S...>::value == 0 && sizeof...(S) <= 8) {
-            u64 t_prev = __builtin_amdgcn_s_memtime();
-            chain.template tick_tile_stamped<KT>(x, ctx, n, st_stage, t_prev);
-#pragma unroll
-            for (int j = 0; j < KT; ++j) my[j0 + j][lane] = x[j];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            st_store += __builtin_amdgcn_s_memtime() - t_prev;
-            st_visits += 1;
-          } else
-#endif
-          {
-          chain.template tick_tile<KT>(x, ctx, n);
-#pragma unroll
-          for (int j = 0; j < KT; ++j) my[j0 + j][lane] = x[j];
-          }
-          j0 += KT;
-        } else if (KT > kTile && j0 + kTile <= len && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + kTile)) {
-          F x[kTile];
-#pragma unroll
-          for (int j = 0; j < kTile; ++j) x[j] = (F)0;
-          chain.template tick_tile<kTile>(x, ctx, n);
-#pragma unroll
-          for (int j = 0; j < kTile; ++j) my[j0 + j][lane] = x[j];
-          j0 += kTile;
-        } else {
-          const u32 m = len - j0 < (u32)kTile ? len - j0 : (u32)kTile;
-          for (u32 j = 0; j < m; ++j) {
-            apply_events_upto(base + n + j);
-            my[j0 + j][lane] = chain.tick((F)0, ctx, n + j);
-          }
-          j0 += m;
-        }
-      }
-      // Transposed reduce: lane j folds frame j over the wave's voices in voice order.
-      // (same-wave LDS traffic: program order is enough, no barrier needed)
-      if constexpr (ChainT::kPan) {
-        F gl = (F)0, gr = (F)0;
-        chain.pan_gains(gl, gr);
-        pan_gain[wave][0][lane] = gl;
-        pan_gain[wave][1][lane] = gr;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // a chain that ends in Pan2 has a left and a right partial row per wavefront: [block][channel][wavefront][frame]
+    F* const row0 = a.partials + ((long)b * (ChainT::kPan ? 2 : 1) * n_waves_total + wave_global) * a.block_size;
+    F* const row1 = row0 + (long)n_waves_total * a.block_size;
+    // m of the V frames x[0..V) from frame n on are real: fold them over the wavefront's voices, one sum per frame
+    auto emit = [&](auto& x, u32 n, u32 m) {
+      constexpr int V = (int)(sizeof(x) / sizeof(x[0]));
 #ifdef KNH_DAG_STAMPS
       const u64 st_f0 = __builtin_amdgcn_s_memtime();
 #endif
+      bool writer;
+      const u32 f = fold_frame_of<V>(fl.v, writer);
       if constexpr (!ChainT::kPan) {
-        if ((u32)lane < len) partial_row[n0 + lane] = fold_group<F, 16>(&my[lane][0], 1, nv);
-        if (a.voices_out) {
-          for (u32 v = 0; v < nv; ++v)
-            if ((u32)lane < len) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = my[lane][v];
+        if (a.voices_out && live) {  // (parity / debug output, single blocks only: every lane its own voice's row)
+#pragma unroll
+          for (int j = 0; j < V; ++j)
+            if ((u32)j < m) a.voices_out[(long)voice * a.block_size + n + j] = x[j];
         }
+        const F total = wave_tree_fold<V>(fl, x);
+        if (writer && f < m) row0[n + f] = total;
       } else {
-        // Pan2: each voice's sample times its two gains (pan.rs:36), then one sum per channel
-        if ((u32)lane < len) {
-          const F* gl = pan_gain[wave][0];
-          const F* gr = pan_gain[wave][1];
-          F accl, accr;
-          fold_group_pan<F, 16>(&my[lane][0], 1, gl, gr, 1, nv, accl, accr);
-          F* pl = a.partials + (((long)b * 2 + 0) * n_waves_total + wave_global) * a.block_size;
-          F* pr = a.partials + (((long)b * 2 + 1) * n_waves_total + wave_global) * a.block_size;
-          pl[n0 + lane] = accl;
-          pr[n0 + lane] = accr;
-          if (a.voices_out) {
-            for (u32 v = 0; v < nv; ++v) {
-              const F t = my[lane][v];
-              a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = t * gl[v];
-              a.voices_out[((long)a.n_voices + v0 + v) * a.block_size + n0 + lane] = t * gr[v];
+        // Pan2 (pan.rs:31-36): each voice's sample times its two gains (the product is rounded), then one sum per channel
+        chain.pan_gains(pan_l, pan_r);
+        F xl[V], xr[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { xl[j] = x[j] * pan_l; xr[j] = x[j] * pan_r; }
+        if (a.voices_out && live) {
+#pragma unroll
+          for (int j = 0; j < V; ++j)
+            if ((u32)j < m) {
+              a.voices_out[(long)voice * a.block_size + n + j] = xl[j];
+              a.voices_out[((long)a.n_voices + voice) * a.block_size + n + j] = xr[j];
             }
-          }
         }
+        const F tl = wave_tree_fold<V>(fl, xl);
+        const F tr = wave_tree_fold<V>(fl, xr);
+        if (writer && f < m) { row0[n + f] = tl; row1[n + f] = tr; }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #ifdef KNH_DAG_STAMPS
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       st_fold += __builtin_amdgcn_s_memtime() - st_f0;
 #endif
+    };
+    // visits of KT samples where a whole one fits and no voice of the wavefront has a change inside it, of eight samples
+    // where that holds for eight (the rest of a block that is not a multiple of KT long, the neighbourhood of a change),
+    // sample by sample (changes applied in front of their frame) for what is left
+    for (u32 n = a.frame_begin; n < a.frame_end;) {
+      const u32 left = a.frame_end - n;
+      apply_events_upto(base + n);
+      if (left >= (u32)KT && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + KT)) {
+        F x[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) x[j] = (F)0;
+#ifdef KNH_DAG_STAMPS
+        if constexpr (SlotCount<S...>::value == 0 && sizeof...(S) <= 8) {
+          u64 t_prev = __builtin_amdgcn_s_memtime();
+          chain.template tick_tile_stamped<KT>(x, ctx, n, st_stage, t_prev);
+          st_visits += 1;
+        } else
+#endif
+        chain.template tick_tile<KT>(x, ctx, n);
+        emit(x, n, (u32)KT);
+        n += KT;
+      } else if (KT > kTile && left >= (u32)kTile && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + kTile)) {
+        F x[kTile];
+#pragma unroll
+        for (int j = 0; j < kTile; ++j) x[j] = (F)0;
+        chain.template tick_tile<kTile>(x, ctx, n);
+        emit(x, n, (u32)kTile);
+        n += kTile;
+      } else {
+        // (through eight rows of LDS, written with a run-time index: the register tile is never indexed dynamically, which
+        // would put it -- the fast path's too -- in scratch memory; same-wave LDS traffic, program order is enough)
+        const u32 m = left < (u32)kTile ? left : (u32)kTile;
+        F(*rows)[64] = lds.slow[wave];
+        for (u32 j = 0; j < m; ++j) {
+          apply_events_upto(base + n + j);
+          rows[j][lane] = chain.tick((F)0, ctx, n + j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        F x[kTile];
+#pragma unroll
+        for (int j = 0; j < kTile; ++j) x[j] = (u32)j < m ? rows[j][lane] : (F)0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        emit(x, n, m);
+        n += m;
+      }
     }
     // changes due exactly at the end of the processed range (precise_timing.rs:85-103 runs the
     // change loop once more before breaking out)
@@ -593,11 +710,12 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   }
 #ifdef KNH_DAG_STAMPS
   if (wave_global == 0u && lane == 0) {
-    // cycles per 64 samples of one voice group: [4 .. 11] the stages in chain order, [12] tile stores, [13] folds, [14] everything
+    // cycles per 64 samples of one voice group: [4 .. 11] the stages in chain order, [13] the folds (partial-row stores
+    // included), [14] everything
     const u64 samples = (u64)a.n_blocks * (a.frame_end - a.frame_begin);
     const u64 d = samples > 0 ? samples : 1;
     for (int k = 0; k < 8; ++k) a.flags[4 + k] = (u32)(st_stage[k] * 64 / d);
-    a.flags[12] = (u32)(st_store * 64 / d);
+    a.flags[12] = 0u;
     a.flags[13] = (u32)(st_fold * 64 / d);
     a.flags[14] = (u32)((__builtin_amdgcn_s_memtime() - st_begin) * 64 / d);
     a.flags[15] = (u32)(st_visits * KT * 64 / d);  // share of the samples that took the stamped (whole-visit) path, x 64

@@ -964,9 +964,26 @@ struct Svf : StageDefaults {
   // three terms over to the next sample's step to fill those places -- nine and a half instructions; the hardware needs no
   // such wait state, and the carried two-float values are what the compiler's subregister renaming pass crashed on once a
   // second filter path sat beside this one.)
+  // KNH_SVF_NOP=1 (a -D of the build, KNH_EXTRA_FLAGS; for run-time fused kernels the environment variable of the same name
+  // at knh_bank_init): the wait state the compiler's hazard table would put between a packed-f32 instruction and an
+  // instruction that reads its result goes back in, at the three places where the hand-written steps have none.  The default
+  // build relies on the hardware needing none (measured: same bits, profiles/r03_micro_svf_low_variants.txt); the switch is
+  // what a part or a ROCm on which that stops holding is diagnosed with -- tests/test_gpu_properties.py::
+  // test_svf_steps_with_and_without_the_wait_state compares the two bit for bit at one, two and four wavefronts per SIMD.
+#ifdef KNH_SVF_NOP
+#define KNH_SVF_WAIT "s_nop 0\n\t"
+#else
+#define KNH_SVF_WAIT
+#endif
+  // The fixed registers v100 .. v122 of the two steps below need a kernel with at least 123 VGPRs: every kernel form has 128 or
+  // more (the 1 024-thread sixteen-groups form exactly 128: __launch_bounds__(1024) on a CU with 512 VGPRs per SIMD lane set);
+  // a form with a smaller budget (more than 1 024 threads per workgroup does not exist; a waves-per-SIMD attribute above 4
+  // would be one) must not include them.
+  static constexpr int kHighestFixedVgpr = 122;
   template <int T>
   static __device__ __forceinline__ void tick_tile_packed(Regs<float>& r, float (&x)[T]) {
     static_assert(T % 8 == 0, "the filter tile is unrolled in blocks of eight samples");
+    static_assert(kHighestFixedVgpr < 128, "the fixed registers stay inside the smallest register budget of any kernel form (128: __launch_bounds__(1024))");
     // Registers, all named and all below v128 (the sixteen-groups-per-workgroup kernels have 128) -- every operand of the asm is
     // a single 32-bit register; see tick_tile_low for why:
     //   v[100:101] (ic1, ic2)  v[102:103] P1  v[104:105] P2  v[106:107] (v1, v2)  v[108:109] (m1*v1, m2*v2)  v112 the output sum
@@ -982,6 +999,7 @@ struct Svf : StageDefaults {
       "v_mul_f32 v112, v122, %[x" #K "]\n\t"                              /* m0*x                             */   \
       "v_pk_fma_f32 v[100:101], v[106:107], 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"    \
       "v_pk_mul_f32 v[108:109], v[120:121], v[106:107]\n\t"               /* (m1*v1, m2*v2)                   */   \
+      KNH_SVF_WAIT                                                                                                     \
       "v_add_f32 v112, v112, v108\n\t"                                    /* m0*x + m1*v1                     */   \
       "v_add_f32 %[y" #K "], v112, v109\n\t"                              /* ... + m2*v2 -> output            */
 #pragma unroll
@@ -1035,8 +1053,10 @@ struct Svf : StageDefaults {
       "v_pk_mul_f32 v[104:105], v[118:119], v[114:115] op_sel_hi:[1,0]\n\t"   /* (a2*v3, a3*v3)               */   \
       "v_add_f32 v103, v101, v103\n\t"                                    /* ic2 + a2*ic1                     */   \
       "v_pk_add_f32 v[106:107], v[102:103], v[104:105]\n\t"               /* (v1, v2)                         */   \
+      KNH_SVF_WAIT                                                                                                     \
       "v_fma_f32 %[y" #K "], 0, v106, v107\n\t"                           /* v2 (NaN if v1 is not finite)     */   \
-      "v_pk_fma_f32 v[100:101], v[106:107], 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+      "v_pk_fma_f32 v[100:101], v[106:107], 2.0, v[100:101] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"    \
+      KNH_SVF_WAIT
 #pragma unroll
     for (int j = 0; j < T; j += 8) {
       float y0, y1, y2, y3, y4, y5, y6, y7;

@@ -49,10 +49,19 @@ jobs = sorted(jobs)
 print(len(jobs), "distinct kernels", flush=True)
 
 
+# No core files from a crashing compiler: the limit is set once, here, and inherited (preexec_fn is not safe with threads).
+# No device for the children: with none visible, loading the compiled kernel fails right behind the compile, which is all
+# this tool wants -- wherever it runs, it is a compile-only check and never a crowd of processes on one GPU.
+# The compiles run in the library's own process here (KNH_JIT_INPROCESS=1, no caches): this tool IS the helper process.
+import resource
+resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+CHILD_ENV = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", KNH_JIT_INPROCESS="1", KNH_JIT_CACHE="0", AMD_COMGR_CACHE="0")
+
+
 def run(job):
     sig, ty = job
     p = subprocess.run([check, sig] + [a for a in ty.split() if a != "f32"], cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800,
-                       preexec_fn=lambda: __import__("resource").setrlimit(__import__("resource").RLIMIT_CORE, (0, 0)))
+                       env=CHILD_ENV)
     return job, p.returncode, p.stdout.decode(errors="replace")[-400:]
 
 
