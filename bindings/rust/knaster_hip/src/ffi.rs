@@ -155,6 +155,8 @@ unsafe extern "C" {
     pub fn knh_bank_param_apply_many(bank: *mut knh_bank, count: usize, voices: *const u32, stages: *const u32, params: *const u32, kinds: *const u32, fvalues: *const f64, ivalues: *const i64, delays: *const u16) -> i32;
     pub fn knh_bank_process_block(bank: *mut knh_bank, frames_to_process: usize, block_start_offset: usize, frame_clock: u64, out: *mut c_void, out_flags: *mut u32) -> i32;
     pub fn knh_jit_stats(memory_hits: *mut u64, disk_hits: *mut u64, helper_compiles: *mut u64, in_process_compiles: *mut u64);
+    pub fn knh_bank_resident_stats(bank: *mut knh_bank, calls: *mut u64, launches: *mut u64) -> i32;
+    pub fn knh_bank_resident_trace(bank: *mut knh_bank, ticks5: *mut u64) -> i32;
     pub fn knh_bank_process_block_channels(bank: *mut knh_bank, frames_to_process: usize, block_start_offset: usize, frame_clock: u64, out_channels: *const *mut c_void, out_flags: *mut u32) -> i32;
     pub fn knh_bank_process_block_device(bank: *mut knh_bank, frames_to_process: usize, block_start_offset: usize, frame_clock: u64, out_device: *mut c_void, hip_stream: *mut c_void) -> i32;
     pub fn knh_bank_process_block_voices(bank: *mut knh_bank, frames_to_process: usize, block_start_offset: usize, frame_clock: u64, out: *mut c_void, voices_out: *mut c_void, out_flags: *mut u32) -> i32;

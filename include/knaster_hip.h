@@ -402,6 +402,20 @@ int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t 
  * queued changes); it is not applied to the pointers. */
 int32_t knh_bank_process_block_channels(knh_bank* bank, size_t frames_to_process, size_t block_start_offset,
                                         uint64_t frame_clock, void* const* out_channels, uint32_t* out_flags);
+/* How knh_bank_process_block[_channels] -- the call the reference makes once per block -- is served (round 4).  Where the bank's
+ * kernel form allows it (the pipelined forms: up to 256 voice groups, KNH_MIX_TREE, no bank inputs) the first such call
+ * launches a RESIDENT kernel: it keeps the voices' state in registers and the sine table in LDS between calls, takes each
+ * call as one command word the host stores, mixes across its workgroups itself and writes the block into host memory -- no
+ * launch, no staging, no second kernel per call.  It leaves when anything else needs the device state or the device (any
+ * other entry point of this bank that reads state or launches; another bank launching on the device) or when the host has
+ * not called for KNH_RESIDENT_IDLE_US microseconds (default 5 000; every wait on the device is bounded by a clock), and the
+ * next call launches it again.  Results are those of a launch per call, bit for bit.  KNH_RESIDENT=0: a launch per call.
+ * calls: process calls served by a resident kernel so far; launches: how many times one was launched.  Either may be NULL. */
+int32_t knh_bank_resident_stats(knh_bank* bank, uint64_t* calls, uint64_t* launches);
+/* Diagnostics of the last call a resident kernel served, on the device's constant 100 MHz clock (ticks of 10 ns): [0] the
+ * voice kernel saw the command, [1] the fold server's root did, [2] the first tile's rows had all arrived, [3] the last
+ * tile's, [4] the root had written the block and the flags.  Zeros when no resident kernel has served a call. */
+int32_t knh_bank_resident_trace(knh_bank* bank, uint64_t* ticks5);
 /* Same, but the mixed block is left in device memory at `out_device`
  * ([out_channels][block_size] of F) and the work is only enqueued on
  * `hip_stream` (a hipStream_t, NULL = the bank's own stream).  Used for the

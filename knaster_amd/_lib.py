@@ -81,6 +81,8 @@ PROTOTYPES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "knh_bank_process_block": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]),
     "knh_jit_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "knh_bank_resident_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "knh_bank_resident_trace": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "knh_bank_process_block_channels": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
     "knh_bank_process_block_device": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]),
     "knh_bank_process_block_voices": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p,

@@ -279,6 +279,12 @@ class VoiceBank:
         """the chain as the device code names it (knh_bank_debug_signature)"""
         return self._lib.knh_bank_debug_signature(self._h).decode()
 
+    def resident_stats(self):
+        """(calls served by a resident kernel, times one was launched): knh_bank_resident_stats"""
+        c, n = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.knh_bank_resident_stats(self._h, C.byref(c), C.byref(n)))
+        return int(c.value), int(n.value)
+
     def debug_words(self) -> np.ndarray:
         d = np.zeros(16, dtype=np.uint32)
         self._check(self._lib.knh_bank_debug_words(self._h, d.ctypes.data_as(C.c_void_p)))

@@ -19,9 +19,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/knaster_hip.h"
@@ -468,6 +470,20 @@ int32_t knh_bank_process_block_channels(knh_bank* bank, size_t frames_to_process
     const size_t word = bank->desc.sample_type == KNH_F64 ? 8 : 4;
     for (uint32_t c = 0; c < bank->desc.out_channels; ++c)
       std::memcpy(out_channels[c], blk + (static_cast<size_t>(c) * bank->block_size + block_start_offset) * word, frames_to_process * word);
+    return KNH_OK;
+  });
+}
+int32_t knh_bank_resident_stats(knh_bank* bank, uint64_t* calls, uint64_t* launches) {
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    bank->resident_stats(calls, launches);
+    return KNH_OK;
+  });
+}
+int32_t knh_bank_resident_trace(knh_bank* bank, uint64_t* ticks5) {
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank || !ticks5) return KNH_ERR_INVALID_ARGUMENT;
+    bank->resident_trace(ticks5);
     return KNH_OK;
   });
 }

@@ -77,6 +77,8 @@ struct knh_bank {
     return KNH_OK;
   }
   virtual uint32_t ranks() const { return 1; }
+  virtual void resident_stats(uint64_t* calls, uint64_t* launches) { if (calls) *calls = 0; if (launches) *launches = 0; }
+  virtual void resident_trace(uint64_t* five) { for (int k = 0; k < 5; ++k) five[k] = 0; }
 
   int fail(int code, const std::string& msg) {
     err = msg;

@@ -74,6 +74,7 @@ struct PipeEntry {
   int n_groups;
   int form;  // knh_dev::PIPE_MIXER (32-sample tiles, f64: 16), PIPE_FOLD or PIPE_INPLACE (64-sample tiles, f64: 32): voice_pipe.hpp
   int gpw;   // 64-voice groups per workgroup: 1, or 2 (PIPE_INPLACE with the short tiles; for banks of more groups than CUs)
+  int long_tiles;  // 1: PipeTile<F>::big frames per tile (64, f64: 32), 0: PipeTile<F>::value (32, f64: 16)
   VoiceLaunchFn<float> f32[2];
   VoiceLaunchFn<double> f64[2];
 };
@@ -111,6 +112,8 @@ const KernelEntry* kernel_at(int i);
 // tree = false: exact left fold of the rows in order; tree = true: 16-ary two-level fold (deterministic)
 // zero_flags (or null): two words the kernel also clears -- the flag set of the bank's next launch
 // host (or null): `out` is mapped pinned host memory and the kernel signals the host when it is written (knh_dev::HostDone)
+hipError_t launch_res_server_f32(const knh_dev::ResServerArgs<float>& a, hipStream_t s);
+hipError_t launch_res_server_f64(const knh_dev::ResServerArgs<double>& a, hipStream_t s);
 hipError_t launch_fold_f32(bool tree, const float* rows, unsigned n_rows, unsigned row_len, unsigned frame_begin,
                            unsigned frame_end, float* out, unsigned channels, unsigned out_stride, unsigned n_blocks, bool accumulate,
                            unsigned* zero_flags, hipStream_t s, const knh_dev::HostDone* host = nullptr);

@@ -73,6 +73,16 @@ hipError_t launch_fold_f64(bool tree, const double* rows, unsigned n_rows, unsig
 }
 
 
+// the fold server of a resident launch (voice_chain.hpp, res_fold_server): four wavefronts per 32 partial rows + four for the root
+hipError_t launch_res_server_f32(const knh_dev::ResServerArgs<float>& a, hipStream_t s) {
+  hipLaunchKernelGGL((res_fold_server<float>), dim3((a.n_rows + 31u) / 32u + 1u), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_res_server_f64(const knh_dev::ResServerArgs<double>& a, hipStream_t s) {
+  hipLaunchKernelGGL((res_fold_server<double>), dim3((a.n_rows + 31u) / 32u + 1u), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 template <typename F>
 __global__ void __launch_bounds__(256) sum_shards_kernel(const F* shards, unsigned n_shards, size_t shard_stride, size_t n,
                                                          unsigned block_size, unsigned frame_begin, unsigned frame_end, F* out,

@@ -37,13 +37,13 @@ static hipError_t launch_pipe_wide_tile(const VoiceKernelArgs<F>& args, unsigned
   return hipGetLastError();
 }
 #define KNH_PIPE_FAN(sig, n, ...)                                                                                       \
-  {sig, n, PIPE_MIXER, 1, {launch_pipe_wide_tile<float, false, __VA_ARGS__>, launch_pipe_wide_tile<float, true, __VA_ARGS__>}, \
+  {sig, n, PIPE_MIXER, 1, 1, {launch_pipe_wide_tile<float, false, __VA_ARGS__>, launch_pipe_wide_tile<float, true, __VA_ARGS__>}, \
    {launch_pipe_wide_tile<double, false, __VA_ARGS__>, launch_pipe_wide_tile<double, true, __VA_ARGS__>}}
 #define KNH_PIPE_AS(sig, n, form, ...)                                                               \
-  {sig, n, form, 1, {launch_pipe<float, false, form, __VA_ARGS__>, launch_pipe<float, true, form, __VA_ARGS__>}, \
+  {sig, n, form, 1, form != PIPE_MIXER ? 1 : 0, {launch_pipe<float, false, form, __VA_ARGS__>, launch_pipe<float, true, form, __VA_ARGS__>}, \
    {launch_pipe<double, false, form, __VA_ARGS__>, launch_pipe<double, true, form, __VA_ARGS__>}}
 #define KNH_PIPE_PAIR_AS(sig, n, ...)                                                                \
-  {sig, n, PIPE_INPLACE, 2, {launch_pipe_pair<float, false, __VA_ARGS__>, launch_pipe_pair<float, true, __VA_ARGS__>}, \
+  {sig, n, PIPE_INPLACE, 2, 0, {launch_pipe_pair<float, false, __VA_ARGS__>, launch_pipe_pair<float, true, __VA_ARGS__>}, \
    {launch_pipe_pair<double, false, __VA_ARGS__>, launch_pipe_pair<double, true, __VA_ARGS__>}},
 // This file is compiled once per form (KNH_PIPE_PART = PIPE_MIXER, PIPE_FOLD, PIPE_INPLACE: build.py), each time with the
 // table of that form's kernels; find_pipe() lives in the PIPE_MIXER part and looks through all three.

@@ -14,6 +14,20 @@ namespace {
       return fail(KNH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
   } while (0)
 
+// ---- resident launches (voice_chain.hpp, Resident) -----------------------------------------------------------------------
+// A resident kernel keeps every CU's LDS: another bank's launch on the same device could not start beside it.  So there is at
+// most one per device, and whoever is about to launch anything there asks it to leave first.  One mutex guards every
+// transition (a bank is single-caller, but two banks may belong to two threads).
+struct ResidentSlot {
+  std::mutex mu;
+  knh_bank* owner[64] = {};
+  void (*leave[64])(knh_bank*) = {};
+};
+inline ResidentSlot& resident_slot() {
+  static ResidentSlot s;
+  return s;
+}
+
 template <typename F>
 struct Bank final : knh_bank {
   typedef typename knh_dev::WordOf<F>::type W;
@@ -313,6 +327,302 @@ struct Bank final : knh_bank {
   uint32_t* d_fold_count = nullptr;  // device: workgroups of the fold kernel that are through
   uint32_t done_epoch = 0;
   bool mapped_out = true;
+  // ---- the per-block call on a resident launch (voice_chain.hpp, Resident) ------------------------------------------------
+  // knh_bank_process_block -- the call the reference makes once per block (Task::run, knaster_graph/src/task.rs:25-31) -- of
+  // a bank on the pipelined kernel form with a mixer wavefront: the first such call launches the kernel, and it stays until
+  // something else needs the device state (any other entry point that reads it or launches), another bank launches on the
+  // device, or the host stays away for KNH_RESIDENT_IDLE_US (default 5 000).  KNH_RESIDENT=0: never (a launch per call).
+  int res_policy = -1;                 // -1 not decided, 0 never, 1 where possible
+  bool res_on = false;                 // a resident kernel is running (or has ended by itself) on own_stream
+  uint32_t res_epoch = 0;              // the last epoch handed out (24 bits)
+  uint64_t* res_bell = nullptr;        // the command word as the host writes it ...
+  uint64_t* res_bell_dev = nullptr;    // ... and as the kernel reads it (the same fine-grained device word behind a large BAR; else mapped pinned memory)
+  bool res_bell_is_device = false;
+  uint64_t* d_res_relay = nullptr;
+  uint64_t *d_res_rows = nullptr, *d_res_wg_flags = nullptr, *d_res_group_rows = nullptr, *d_res_group_flags = nullptr;  // granules (voice_chain.hpp)
+  uint32_t *d_res_arrivals = nullptr, *d_res_group_arrivals = nullptr;
+  hipStream_t res_stream = nullptr;    // the fold server runs beside the voice kernel
+  F* h_res_out = nullptr;              // mapped pinned: [channels][block_size]
+  uint32_t* h_res_done = nullptr;      // mapped pinned: epoch, done count, running count
+  uint32_t res_max_tiles = 0;
+  uint32_t res_cooldown = 0;           // calls to sit out after another bank asked this one to leave
+  uint64_t res_idle_ticks = 500000;    // 5 ms of the 100 MHz clock
+  uint64_t res_calls = 0, res_launches = 0;
+  void resident_stats(uint64_t* calls, uint64_t* launches) override { if (calls) *calls = res_calls; if (launches) *launches = res_launches; }
+  // diagnostics: the last call's milestones on the device clock (ticks of 10 ns): the voice kernel saw the command, the fold
+  // server's root did, its first tile was complete, its last tile was, it had written everything
+  void resident_trace(uint64_t* five) override {
+    for (int k = 0; k < 5; ++k) five[k] = 0;
+    if (!h_res_done) return;
+    for (int k = 0; k < 5; ++k) std::memcpy(&five[k], h_res_done + 8 + 2 * k, 8);
+  }
+  bool res_possible() const {
+    // the pipelined forms with a mixer wavefront and one voice group per workgroup (each workgroup a CU's LDS to itself: at
+    // most one per CU, so a bank of up to 256 groups), tree mix, no bank inputs (their upload rides in a stream)
+    if (!pipe || pipe_pair || dag || wide_waves != 0 || interp || jit) return false;
+    if (pipe->form == 1 /* PIPE_FOLD: no mixer wavefront */ || pipe->gpw != 1) return false;
+    if (desc.mix_mode != KNH_MIX_TREE || uses_input) return false;
+    if ((nv + 63u) / 64u > 256u || block_size > 4096) return false;
+    return true;
+  }
+  // frames per tile of the bank's pipelined kernel form (voice_pipe.hpp, PipeTile: the forms with the long tiles, and the
+  // Fan pipelines, 64 -- f64: 32; the mixer form 32 / 16)
+  uint32_t res_tile_frames() const {
+    const bool big = pipe && pipe->long_tiles != 0;
+    return sizeof(F) == 8 ? (big ? 32u : 16u) : (big ? 64u : 32u);
+  }
+  static hipError_t launch_res_server(const knh_dev::ResServerArgs<float>& a, hipStream_t s) { return knh::launch_res_server_f32(a, s); }
+  static hipError_t launch_res_server(const knh_dev::ResServerArgs<double>& a, hipStream_t s) { return knh::launch_res_server_f64(a, s); }
+  static void res_leave_thunk(knh_bank* b) { static_cast<Bank<F>*>(b)->res_leave_locked(true); }
+  // the caller holds resident_slot().mu
+  int res_leave_locked(bool evicted) {
+    if (!res_on) return KNH_OK;
+    KNH_HIP(hipSetDevice(device));
+    res_epoch = (res_epoch + 1u) & 0xFFFFFFu;
+    const uint64_t cmd = static_cast<uint64_t>(res_epoch) | (1ull << 58);
+    __atomic_store_n(res_bell, cmd, __ATOMIC_RELEASE);
+#if defined(__x86_64__)
+    if (res_bell_is_device) __builtin_ia32_sfence();
+#endif
+    hipError_t e = hipStreamSynchronize(own_stream);  // (bounded on the device side: every wait of the kernels is)
+    const hipError_t e2 = hipStreamSynchronize(res_stream);
+    if (e == hipSuccess) e = e2;
+    res_on = false;
+    ResidentSlot& rs = resident_slot();
+    if (device >= 0 && device < 64 && rs.owner[device] == this) { rs.owner[device] = nullptr; rs.leave[device] = nullptr; }
+    if (evicted) res_cooldown = 256;
+    if (e != hipSuccess) return fail(KNH_ERR_DEVICE, std::string("the resident kernel ended with an error: ") + hipGetErrorString(e));
+    return KNH_OK;
+  }
+  int res_leave() {
+    if (!res_on) return KNH_OK;
+    std::lock_guard<std::mutex> lock(resident_slot().mu);
+    return res_leave_locked(false);
+  }
+  // before anything is launched on this device by this bank: no other bank's resident kernel is in the way
+  void res_make_room() {
+    ResidentSlot& rs = resident_slot();
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lock(rs.mu);
+    if (rs.owner[device] && rs.owner[device] != this) rs.leave[device](rs.owner[device]);
+  }
+  int res_alloc() {
+    if (h_res_done) return KNH_OK;
+    KNH_HIP(hipSetDevice(device));
+    int large_bar = 0;
+    (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device);
+    const char* be = std::getenv("KNH_RESIDENT_BELL");  // "host": the command word in pinned host memory whatever the BAR
+    if (large_bar && !(be && be[0] == 'h')) {
+      void* p = nullptr;
+      if (hipExtMallocWithFlags(&p, 64, hipDeviceMallocFinegrained) == hipSuccess && p) {
+        KNH_HIP(hipMemset(p, 0xFF, 64));
+        KNH_HIP(hipDeviceSynchronize());
+        res_bell = res_bell_dev = static_cast<uint64_t*>(p);
+        res_bell_is_device = true;
+      }
+    }
+    if (!res_bell) {
+      KNH_HIP(hipHostMalloc(&res_bell, 64, hipHostMallocMapped | hipHostMallocCoherent));
+      res_bell_dev = res_bell;
+      *res_bell = ~0ull;
+    }
+    res_max_tiles = static_cast<uint32_t>((block_size + res_tile_frames() - 1) / res_tile_frames());
+    {
+      // granules: every one starts with a tag no call will ever carry (all ones)
+      const size_t w = sizeof(F) == 8 ? 2 : 1, rows = (nv + 63) / 64;
+      const size_t n_rows = static_cast<size_t>(res_max_tiles) * 2 * rows * 64 * w, n_group = static_cast<size_t>(res_max_tiles) * 2 * 8 * 64 * w;
+      KNH_HIP(hipMalloc(&d_res_rows, n_rows * 8));
+      KNH_HIP(hipMemset(d_res_rows, 0xFF, n_rows * 8));
+      KNH_HIP(hipMalloc(&d_res_group_rows, n_group * 8));
+      KNH_HIP(hipMemset(d_res_group_rows, 0xFF, n_group * 8));
+      KNH_HIP(hipMalloc(&d_res_wg_flags, rows * 8));
+      KNH_HIP(hipMemset(d_res_wg_flags, 0xFF, rows * 8));
+      KNH_HIP(hipMalloc(&d_res_group_flags, 64));
+      KNH_HIP(hipMemset(d_res_group_flags, 0xFF, 64));
+      KNH_HIP(hipMalloc(&d_res_arrivals, (static_cast<size_t>(res_max_tiles) + 1) * 8 * sizeof(uint32_t)));
+      KNH_HIP(hipMemset(d_res_arrivals, 0, (static_cast<size_t>(res_max_tiles) + 1) * 8 * sizeof(uint32_t)));
+      KNH_HIP(hipMalloc(&d_res_group_arrivals, (static_cast<size_t>(res_max_tiles) + 1) * sizeof(uint32_t)));
+      KNH_HIP(hipMemset(d_res_group_arrivals, 0, (static_cast<size_t>(res_max_tiles) + 1) * sizeof(uint32_t)));
+      // The fold server must run BESIDE the voice kernel, so it must not sit behind it in one hardware queue (the runtime
+      // multiplexes streams onto a few).  A stream of another priority gets a queue of its own; res_launch checks that both
+      // kernels have started before anything relies on it.
+      int prio_low = 0, prio_high = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+      if (hipStreamCreateWithPriority(&res_stream, hipStreamNonBlocking, prio_high) != hipSuccess) KNH_HIP(hipStreamCreateWithFlags(&res_stream, hipStreamNonBlocking));
+    }
+    KNH_HIP(hipMalloc(&d_res_relay, 64));
+    KNH_HIP(hipMemset(d_res_relay, 0xFF, 64));
+    KNH_HIP(hipHostMalloc(&h_res_out, desc.out_channels * block_size * sizeof(F), hipHostMallocMapped | hipHostMallocCoherent));
+    KNH_HIP(hipHostMalloc(&h_res_done, 256, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h_res_done, 0, 256);
+    h_res_done[0] = 0xFFFFFFFFu; h_res_done[1] = 0u; h_res_done[2] = 0u; h_res_done[4] = 0xFFFFFFFFu; h_res_done[5] = 0xFFFFFFFFu;
+    KNH_HIP(hipDeviceSynchronize());
+    if (const char* e = std::getenv("KNH_RESIDENT_IDLE_US")) { const long us = std::atol(e); if (us >= 50 && us <= 2000000) res_idle_ticks = static_cast<uint64_t>(us) * 100u; }
+    return KNH_OK;
+  }
+  void fill_launch_args(VoiceKernelArgs<F>& a, uint32_t n_blocks, uint32_t fb, uint32_t fe) {
+    a.state = d_state;
+    a.stride = stride;
+    a.n_voices = nv;
+    a.env_ranks = env_ranks;
+    a.block_size = static_cast<uint32_t>(block_size);
+    a.n_blocks = n_blocks;
+    a.frame_begin = fb;
+    a.frame_end = fe;
+    a.sine_table = d_sine;
+    a.f2pi = f2pi;
+    a.sample_rate = sample_rate;
+    a.seg_table = d_seg_table;
+    a.seg_max = seg_max;
+    a.delay_ring = d_delay;
+    a.delay_stride = delay_stride;
+    a.buffer = d_buffer;
+    a.buffer_frames = static_cast<uint32_t>(h_buffer.size());
+    a.input = nullptr;
+    a.in_channels = desc.in_channels;
+    a.ev_start = nullptr;
+    a.events = nullptr;
+    a.partials = d_partials;
+    a.voices_out = nullptr;
+    a.done_frames = d_done;
+    a.flags = d_flags;
+    a.res = knh_dev::Resident{};
+  }
+  // the caller holds resident_slot().mu; the command word already carries `first_epoch`'s command or will
+  static bool res_debug() { static const bool on = std::getenv("KNH_DEBUG_RES") != nullptr; return on; }
+  int res_launch(uint32_t first_epoch) {
+    if (res_debug()) std::fprintf(stderr, "[knh resident] launch, first epoch %u, %u voices, tile %u frames\n", first_epoch, nv, res_tile_frames());
+    VoiceKernelArgs<F> a;
+    fill_launch_args(a, 1, 0, static_cast<uint32_t>(block_size));
+    a.flags = d_flags + 32;  // (a third set: the two the ordinary launches alternate stay as their fold kernels left them)
+    a.res.bell = reinterpret_cast<const knh_dev::u64*>(res_bell_dev);
+    a.res.relay = reinterpret_cast<knh_dev::u64*>(d_res_relay);
+    a.res.rows = reinterpret_cast<knh_dev::u64*>(d_res_rows);
+    a.res.wg_flags = reinterpret_cast<knh_dev::u64*>(d_res_wg_flags);
+    for (int k = 0; k < 2; ++k) { a.res.ev_start[k] = h_ev_start2[k]; a.res.events[k] = h_events2[k]; }
+    a.res.idle_ticks = res_idle_ticks;
+    a.res.host_started = h_res_done + 4;
+    a.res.first_epoch = first_epoch;
+    a.res.max_tiles = res_max_tiles;
+    {  // the fold server first: a handful of wavefronts that will sit beside the voice kernel's workgroups
+      knh_dev::ResServerArgs<F> sa{};
+      sa.relay = reinterpret_cast<const knh_dev::u64*>(d_res_relay);
+      sa.rows = reinterpret_cast<const knh_dev::u64*>(d_res_rows);
+      sa.wg_flags = reinterpret_cast<const knh_dev::u64*>(d_res_wg_flags);
+      sa.group_rows = reinterpret_cast<knh_dev::u64*>(d_res_group_rows);
+      sa.group_flags = reinterpret_cast<knh_dev::u64*>(d_res_group_flags);
+      sa.host_out = h_res_out;
+      sa.host_done = h_res_done;
+      sa.idle_ticks = res_idle_ticks;
+      sa.first_epoch = first_epoch;
+      sa.n_rows = (nv + 63) / 64;
+      sa.planes = pan ? 2u : 1u;
+      sa.out_channels = desc.out_channels;
+      sa.block_size = static_cast<uint32_t>(block_size);
+      sa.tile_frames = res_tile_frames();
+      KNH_HIP(launch_res_server(sa, res_stream));
+    }
+    KNH_HIP(launch_voice(a, (nv + 63) / 64, own_stream));
+    res_on = true;
+    res_launches += 1;
+    ResidentSlot& rs = resident_slot();
+    if (device >= 0 && device < 64) { rs.owner[device] = this; rs.leave[device] = &Bank<F>::res_leave_thunk; }
+    // Both kernels are running?  (If the two streams share a hardware queue, the second kernel waits for the first to END --
+    // which, for kernels that wait for each other's work, is never in time.  Then this bank keeps to a launch per call.)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+      if (__atomic_load_n(&h_res_done[4], __ATOMIC_ACQUIRE) == first_epoch && __atomic_load_n(&h_res_done[5], __ATOMIC_ACQUIRE) == first_epoch) break;
+      if ((spin & 0xFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
+        if (res_debug()) std::fprintf(stderr, "[knh resident] handshake failed: voice %u server %u (want %u)\n", h_res_done[4], h_res_done[5], first_epoch);
+        res_policy = 0;
+        warn("the resident voice kernel and its fold server did not start side by side (a shared hardware queue?): this bank launches per call");
+        int rc = res_leave_locked(false);
+        return rc != KNH_OK ? rc : KNH_ERR_UNSUPPORTED_CHAIN;  // (res_call: fall back to an ordinary launch)
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    return KNH_OK;
+  }
+  // One block through the resident kernel: frames [fb, fe) of the block into out_host ([channels][block_size], written at
+  // their place).  The event list of the call (if any) is the pinned list upload_events has just made.
+  int res_call(uint32_t fb, uint32_t fe, bool have_events, void* out_host, uint32_t* out_flags) {
+    ResidentSlot& rs = resident_slot();
+    std::lock_guard<std::mutex> lock(rs.mu);
+    KNH_HIP(hipSetDevice(device));
+    if (device >= 0 && device < 64 && rs.owner[device] && rs.owner[device] != this) rs.leave[device](rs.owner[device]);
+    const uint64_t payload = (static_cast<uint64_t>(fb) << 24) | (static_cast<uint64_t>(fe) << 40) | (have_events ? 1ull << 56 : 0ull) |
+                             (have_events && list_in_use == 1 ? 1ull << 57 : 0ull);
+    if (have_events && list_in_use >= 0) { list_busy[list_in_use] = false; list_in_use = -1; }  // (no stream order to keep: the call is over when this returns)
+    uint32_t epoch = 0;
+    auto ring = [&]() -> int {  // the next epoch's command; a kernel to take it if there is none
+      res_epoch = (res_epoch + 1u) & 0xFFFFFFu;
+      epoch = res_epoch;
+      if (!res_on) { int rc = res_launch(epoch); if (rc != KNH_OK) return rc; }  // (KNH_ERR_UNSUPPORTED_CHAIN: no resident launch for this bank after all)
+#if defined(__x86_64__)
+      __builtin_ia32_sfence();  // the event list is in memory before the word that announces it
+#endif
+      __atomic_store_n(res_bell, static_cast<uint64_t>(epoch) | payload, __ATOMIC_RELEASE);
+#if defined(__x86_64__)
+      if (res_bell_is_device) __builtin_ia32_sfence();
+#endif
+      return KNH_OK;
+    };
+    { int rc = ring(); if (rc != KNH_OK) return rc; }
+    res_calls += 1;
+    volatile uint32_t* ep = h_res_done;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 1;; ++spin) {
+      if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == epoch) break;
+      if ((spin & 0x3FFFu) == 0) {
+        const hipError_t q = hipStreamQuery(own_stream);
+        if (q == hipSuccess) {
+          // The kernel has ended by itself (the host was away for longer than its patience) just as this command was written.
+          // Its workgroup 0 left "leave" in the relay under THIS epoch, so the command goes out again under the next one, to a
+          // new launch.
+          if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == epoch) break;
+          if (res_debug()) std::fprintf(stderr, "[knh resident] the kernel ended without answering epoch %u (done word %u, %.3f ms into the call, server stream %s; root wavefronts at %x %x %x %x)\n", epoch, h_res_done[0],
+                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), hipStreamQuery(res_stream) == hipSuccess ? "idle" : "busy",
+                                        h_res_done[20], h_res_done[21], h_res_done[22], h_res_done[23]);
+          // (its fold server has then heard "leave" over the relay too.  A server that is still busy was in the middle of a
+          // call: the voice kernel took the command, and taking it again would render the block twice.)
+          hipError_t qs = hipStreamQuery(res_stream);
+          for (int k = 0; k < 200 && qs == hipErrorNotReady; ++k) { std::this_thread::sleep_for(std::chrono::microseconds(500)); qs = hipStreamQuery(res_stream); }
+          res_on = false;
+          if (qs != hipSuccess) {
+            res_policy = 0;
+            (void)res_leave_locked(false);
+            return fail(KNH_ERR_DEVICE, "the resident voice kernel ended in the middle of a call (its mix never arrived)");
+          }
+          int rc = ring();
+          if (rc != KNH_OK) return rc;
+        } else if (q != hipErrorNotReady) {
+          res_on = false;
+          return fail(KNH_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+          return fail(KNH_ERR_DEVICE, "the resident kernel did not answer within 10 s");
+        }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    const size_t n = fe - fb;
+    for (uint32_t c = 0; c < desc.out_channels; ++c)
+      std::memcpy(static_cast<F*>(out_host) + c * block_size + fb, h_res_out + c * block_size + fb, n * sizeof(F));
+    if (out_flags) {
+      uint32_t fl = 0;
+      if (h_res_done[1]) fl |= KNH_FLAG_ANY_DONE;
+      bool has_env = false;
+      for (const StageInfo& st : stages) has_env = has_env || st.kind == KNH_STAGE_MUL_ENV_ASR || st.kind == KNH_STAGE_MUL_ENV_AR || st.kind == KNH_STAGE_MUL_ENVELOPE ||
+                          st.kind == KNH_STAGE_BUFFER_READER;
+      if (has_env && h_res_done[2] == 0) fl |= KNH_FLAG_ALL_DONE;
+      *out_flags = fl;
+    }
+    return KNH_OK;
+  }
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_pool;
@@ -322,6 +632,15 @@ struct Bank final : knh_bank {
 
   ~Bank() override {
     if (device >= 0) (void)hipSetDevice(device);
+    (void)res_leave();
+    {
+      void* rdev[] = {res_bell_is_device ? static_cast<void*>(res_bell) : nullptr, d_res_relay, d_res_rows, d_res_wg_flags, d_res_group_rows, d_res_group_flags, d_res_arrivals, d_res_group_arrivals};
+      if (res_stream) { (void)hipStreamSynchronize(res_stream); (void)hipStreamDestroy(res_stream); }
+      void* rhost[] = {res_bell_is_device ? nullptr : static_cast<void*>(res_bell), h_res_out, h_res_done};
+      if (own_stream) (void)hipStreamSynchronize(own_stream);
+      for (void* p : rdev) if (p) (void)hipFree(p);
+      for (void* p : rhost) if (p) (void)hipHostFree(p);
+    }
     // everything that may still read or write this bank's memory has finished before any of it is freed: the bank's own
     // stream, the resolver's (its kernels read the pinned record and event lists), and the stream the last launch was given
     if (own_stream) (void)hipStreamSynchronize(own_stream);
@@ -858,10 +1177,14 @@ struct Bank final : knh_bank {
     KNH_HIP(hipMalloc(&d_done, static_cast<size_t>(nv) * sizeof(uint32_t)));
     KNH_HIP(hipMemset(d_done, 0xFF, static_cast<size_t>(nv) * sizeof(uint32_t)));
     // two sets of 16 words, used by alternate launches: the fold kernel of a launch clears the other set's counters
-    KNH_HIP(hipMalloc(&d_flags, 32 * sizeof(uint32_t)));
-    KNH_HIP(hipMemset(d_flags, 0, 32 * sizeof(uint32_t)));
+    KNH_HIP(hipMalloc(&d_flags, 48 * sizeof(uint32_t)));  // (+ a third set: a resident launch's diagnostics)
+    KNH_HIP(hipMemset(d_flags, 0, 48 * sizeof(uint32_t)));
     for (int b = 0; b < 2; ++b) {
       KNH_HIP(hipHostMalloc(&h_ev_start2[b], (static_cast<size_t>(nv) + 2) * sizeof(uint32_t)));
+      // room for two events per voice from the start: a list that has to grow later costs a resident kernel its place (it knows
+      // the lists by their addresses)
+      h_events_cap2[b] = std::max<size_t>(2048, 2 * static_cast<size_t>(nv));
+      KNH_HIP(hipHostMalloc(&h_events2[b], h_events_cap2[b] * sizeof(Event)));
       KNH_HIP(hipEventCreateWithFlags(&list_done[b], hipEventDisableTiming));
     }
     KNH_HIP(hipHostMalloc(&h_out, desc.out_channels * bs * sizeof(F) + 2 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1538,6 +1861,7 @@ struct Bank final : knh_bank {
       list_busy[lb] = false;
     }
     if (total > h_events_cap2[lb]) {
+      { int rl = res_leave(); if (rl != KNH_OK) return rl; }  // (a resident kernel knows the list by its address)
       size_t cap = std::max<size_t>(total, 1024) * 2;
       if (h_events2[lb]) KNH_HIP(hipHostFree(h_events2[lb]));
       h_events2[lb] = nullptr;
@@ -1625,6 +1949,30 @@ struct Bank final : knh_bank {
         }
       }
     }
+    // The call the reference makes -- one whole or partial block into host memory, blocking -- on a resident launch where the
+    // bank's kernel form has one (res_possible); anything else first asks a resident kernel (this bank's, or another bank's
+    // on this device) to leave: it would be in the way of the launch, and it holds the voices' state in its registers.
+    {
+      if (res_policy < 0) {
+        const char* e = std::getenv("KNH_RESIDENT");
+        res_policy = e && e[0] == '0' ? 0 : 1;
+      }
+      const bool res_ok = res_policy == 1 && sync && out_host && !out_device && !voices_host && !stream && n_blocks == 1 && fe > fb && mapped_out &&
+                          !accumulate && !timing && !(dev_events && n_recs > 0) && res_possible();
+      if (res_ok && res_cooldown == 0) {
+        rc = res_alloc();
+        if (rc != KNH_OK) return rc;
+        const int held_list = list_in_use;
+        rc = res_call(fb, fe, have_events, out_host, out_flags);
+        if (rc != KNH_ERR_UNSUPPORTED_CHAIN) return rc;
+        list_in_use = held_list;  // the kernels would not run side by side: this call, and the bank from now on, takes the launch per call
+        if (held_list >= 0) list_busy[held_list] = false;
+      }
+      if (res_cooldown) --res_cooldown;
+      rc = res_leave();
+      if (rc != KNH_OK) return rc;
+      res_make_room();
+    }
     const bool want_voices = voices_host != nullptr || (desc.mix_mode == KNH_MIX_LEFT_FOLD);
     if (desc.mix_mode == KNH_MIX_LEFT_FOLD && n_blocks > 1)
       return fail(KNH_ERR_INVALID_ARGUMENT, "KNH_MIX_LEFT_FOLD processes one block per call");
@@ -1658,23 +2006,7 @@ struct Bank final : knh_bank {
     flags_parity ^= 1u;
     flags_last = flags_now;
     VoiceKernelArgs<F> a;
-    a.state = d_state;
-    a.stride = stride;
-    a.n_voices = nv;
-    a.env_ranks = env_ranks;
-    a.block_size = static_cast<uint32_t>(block_size);
-    a.n_blocks = n_blocks;
-    a.frame_begin = fb;
-    a.frame_end = fe;
-    a.sine_table = d_sine;
-    a.f2pi = f2pi;
-    a.sample_rate = sample_rate;
-    a.seg_table = d_seg_table;
-    a.seg_max = seg_max;
-    a.delay_ring = d_delay;
-    a.delay_stride = delay_stride;
-    a.buffer = d_buffer;
-    a.buffer_frames = static_cast<uint32_t>(h_buffer.size());
+    fill_launch_args(a, n_blocks, fb, fe);
     a.input = nullptr;
     a.in_channels = desc.in_channels;
     if (uses_input) {
@@ -1845,6 +2177,7 @@ struct Bank final : knh_bank {
   int read_done_frames(uint32_t* out) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
     if (!out) return fail(KNH_ERR_INVALID_ARGUMENT, "null output");
+    { int rl = res_leave(); if (rl != KNH_OK) return rl; }  // (a resident kernel's stores reach the copy engine when it ends)
     KNH_HIP(hipSetDevice(device));
     KNH_HIP(hipStreamSynchronize(own_stream));
     KNH_HIP(hipMemcpy(out, d_done, static_cast<size_t>(nv) * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1852,6 +2185,7 @@ struct Bank final : knh_bank {
   }
   int debug_read(uint32_t* out16) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    { int rl = res_leave(); if (rl != KNH_OK) return rl; }
     KNH_HIP(hipSetDevice(device));
     KNH_HIP(hipDeviceSynchronize());
     KNH_HIP(hipMemcpy(out16, flags_last ? flags_last : d_flags, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1859,6 +2193,7 @@ struct Bank final : knh_bank {
   }
   int synchronize() override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    { int rl = res_leave(); if (rl != KNH_OK) return rl; }
     KNH_HIP(hipSetDevice(device));
     KNH_HIP(hipDeviceSynchronize());
     return KNH_OK;
@@ -1876,6 +2211,7 @@ struct Bank final : knh_bank {
   }
   int timing_reset(int enable) override {
     if (!initialised) return fail(KNH_ERR_NOT_INITIALISED, "bank not initialised");
+    { int rl = res_leave(); if (rl != KNH_OK) return rl; }  // (kernel time is measured launch by launch: a timed bank launches per call)
     KNH_HIP(hipSetDevice(device));
     int rc = timing_collect();
     if (rc != KNH_OK) return rc;

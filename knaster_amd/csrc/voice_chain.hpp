@@ -40,6 +40,7 @@ struct Chain<F, FMA, BASE> {
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
   __device__ __forceinline__ u32 collect_done(u32 acc) const { return acc; }
+  __device__ __forceinline__ void reset_marks() {}
   __device__ __forceinline__ void begin_block(u32, const Ctx&) {}
 };
 template <typename F, bool FMA, int BASE, typename S0, typename... Rest>
@@ -111,6 +112,8 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
     if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
     return rest.collect_done(acc);
   }
+  // a resident launch reports the marks of each CALL (an ordinary launch: of the launch)
+  __device__ __forceinline__ void reset_marks() { mark = 0xFFFFFFFFu; rest.reset_marks(); }
   __device__ __forceinline__ void pan_gains(F& l, F& rg) const {
     if constexpr (IsPan<S0>::value) { l = r.l; rg = r.r; }
     else rest.pan_gains(l, rg);
@@ -300,6 +303,95 @@ template <typename F, bool FMA, typename... S> struct ChainSelect<true, F, FMA, 
 // ---------------------------------------------------------------------------
 // Kernel arguments
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// A RESIDENT launch (round 4): the call the reference makes is UGen::process_block once per block (Task::run,
+// knaster_graph/src/task.rs:25-31).  As one launch per call that costs a kernel launch, the sine table's staging, the state's
+// trip from HBM and back and the pipeline's fill -- 22 us of kernel for 11 us of work, plus a second launch for the fold
+// (profiles/r03_per_block_twin_c3.json).  A resident launch stays on its CUs between calls: the state stays in registers, the
+// table in LDS, and a call is a COMMAND WORD the host stores and the kernel picks up:
+//   bits 0-23 epoch (the kernel expects them in order), 24-39 frame_begin, 40-55 frame_end, 56 the block has host-made events,
+//   57 which of the two event lists, 58 leave (store the state and end).
+// Workgroup 0 polls the word the host writes and republishes it in device memory for the others (one reader across PCIe / the
+// fabric instead of 256: profiles/r04_micro_doorbell.txt).  Every wait is bounded by the constant-rate clock: a kernel whose
+// host has gone quiet for `idle_ticks` ends by itself -- the host, finding the stream idle, launches again.
+// The mix leaves the device without a second launch too: every workgroup stores its partial row of a 64-frame tile as granules
+// (below) and goes on -- it never waits for anybody; a second, small resident kernel (res_fold_server, one wavefront per 32
+// rows and one for the root) watches the granules arrive, continues the bank's pairwise sum over them (32 rows, then up to 8
+// of those: the same binary tree as fold_tree_kernel, same bits) and writes each tile into mapped pinned host memory, the
+// call's flags and its epoch behind the last one.
+// ---------------------------------------------------------------------------
+struct Resident {
+  const u64* bell;          // the command word the host stores (device memory it reaches through the BAR, or mapped pinned host memory); null: an ordinary launch
+  u64* relay;               // device: the command as workgroup 0 republishes it
+  u64* rows;                // device: the workgroups' partial rows as granules, [tile][plane][workgroup][64 frames][W] (W = 1, f64: 2)
+  u64* wg_flags;            // device: [workgroup] one granule: voices that marked done | voices still running << 8
+  const u32* ev_start[2];   // the two alternating host-made event lists (pinned host memory)
+  const Event* events[2];
+  u64 idle_ticks;           // workgroup 0's patience without a command (s_memrealtime ticks, 10 ns)
+  u32* host_started;        // mapped pinned host word: workgroup 0 stores first_epoch there when it starts (the host checks that the
+                            // voice kernel and the fold server really run side by side before it relies on them)
+  u32 first_epoch;          // the epoch of the first command this launch takes
+  u32 max_tiles;
+};
+// A GRANULE is one naturally aligned 8-byte word {32 bits of data, 32-bit tag} written by ONE store and read by ONE load
+// (8-byte device-scope atomics on both sides): whoever reads the tag it is waiting for has the data that was stored with it --
+// no flag, no counter, no fence, one trip through the memory system (MI355X_MICROARCH.md, hand-off price list: "handoff-1to1").
+// tag = epoch << 8 | tile (255: the call's flag granules).  An f32 sample is one granule, an f64 sample two (low and high word).
+__device__ __forceinline__ u32 res_tag(u32 epoch, u32 tile) { return (epoch << 8) | (tile & 0xFFu); }
+__device__ __forceinline__ void res_put(u64* g, u32 data, u32 tag) { __hip_atomic_store(g, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 res_get(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename F> struct ResWords { static constexpr int value = sizeof(F) == 8 ? 2 : 1; };
+__device__ __forceinline__ void res_put_sample(u64* g, float v, u32 tag) { res_put(g, __builtin_bit_cast(u32, v), tag); }
+__device__ __forceinline__ void res_put_sample(u64* g, double v, u32 tag) {
+  const u64 b = __builtin_bit_cast(u64, v);
+  res_put(g, (u32)b, tag);
+  res_put(g + 1, (u32)(b >> 32), tag);
+}
+enum : u64 { RES_EPOCH_MASK = 0xFFFFFFull, RES_HAS_EVENTS = 1ull << 56, RES_LIST = 1ull << 57, RES_LEAVE = 1ull << 58 };
+struct ResCall {  // one command, unpacked
+  u32 epoch, frame_begin, frame_end;
+  bool has_events, leave;
+  u32 list;
+};
+__device__ __forceinline__ ResCall res_unpack(u64 c) {
+  ResCall r;
+  r.epoch = (u32)(c & RES_EPOCH_MASK);
+  r.frame_begin = (u32)((c >> 24) & 0xFFFFu);
+  r.frame_end = (u32)((c >> 40) & 0xFFFFu);
+  r.has_events = (c & RES_HAS_EVENTS) != 0ull;
+  r.list = (c & RES_LIST) ? 1u : 0u;
+  r.leave = (c & RES_LEAVE) != 0ull;
+  return r;
+}
+// Every wavefront of the workgroup calls this between two calls; `slot` = two words of LDS.  Wavefront 0's lane 0 waits for
+// the command with epoch `expect` (workgroup 0: from the host's word, and passes it on; the others: from the relay), bounded.
+__device__ __forceinline__ ResCall res_wait(const Resident& r, u32 expect, u32* slot, int wave_all, int lane) {
+  if (wave_all == 0 && lane == 0) {
+    const bool leader = blockIdx.x == 0u;
+    if (leader && expect == r.first_epoch) __hip_atomic_store(r.host_started, r.first_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    const u64 patience = leader ? r.idle_ticks : 2ull * r.idle_ticks + 5000000ull;  // (the others outwait workgroup 0: they hear of its leaving through the relay)
+    u64 c;
+    for (;;) {
+      c = leader ? __hip_atomic_load(r.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((u32)(c & RES_EPOCH_MASK) == expect) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { c = RES_LEAVE | (u64)expect; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (leader) {
+      __hip_atomic_store(r.relay, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (diagnostics, knh_bank_resident_trace: when the command was seen, on the device's 100 MHz clock)
+      __hip_atomic_store(reinterpret_cast<u64*>(r.host_started + 4), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    slot[0] = (u32)c;
+    slot[1] = (u32)(c >> 32);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const u64 c = (u64)slot[0] | ((u64)slot[1] << 32);
+  return res_unpack(c);
+}
 template <typename F>
 struct VoiceKernelArgs {
   typename WordOf<F>::type* state;  // [n_slots][stride]
@@ -328,6 +420,7 @@ struct VoiceKernelArgs {
                                     // order) in the reference's task order (graph.rs calculate_node_order); 0: list order is task order
   u32* done_frames;                 // [n_voices]
   u32* flags;                       // [0] |= any-done, [1] += voices whose last envelope is not Stopped
+  Resident res;                     // res.bell != null: a resident launch (one block per command; frame_begin / frame_end / ev_start / events come with each command)
 };
 
 constexpr int kWave = 64;
@@ -398,6 +491,185 @@ template <typename F, int B>
 __device__ __forceinline__ void fold_group_pan(const F* col, int st, const F* gl, const F* gr, int gst, u32 nv, F& l, F& r) {
   if (nv == 64u) tree_cols_pan<F, 64, true, B>(col, st, gl, gr, gst, nv, l, r);
   else tree_cols_pan<F, 64, false, B>(col, st, gl, gr, gst, nv, l, r);
+}
+
+// ---------------------------------------------------------------------------
+// A resident launch's mix (see Resident): the fold server.  Workgroup k < n_groups folds rows [32 k, 32 k + 32) of every tile
+// (lane = frame of the tile): it reads the 32 granules of its frame until all carry the tag of (call, tile), sums them as
+// tree_reduce does, and passes the node on as a granule of its own -- or, alone (a bank of up to 32 voice groups), writes the
+// host's block itself.  Workgroup n_groups is the root: up to 8 group granules per frame -> the host's block, and behind a
+// call's last tile the flags and the epoch.  Waits are polls with a clock-bounded patience like the voice kernel's; the
+// command comes from the same relay word.
+// ---------------------------------------------------------------------------
+template <typename F>
+struct ResServerArgs {
+  const u64* relay;
+  const u64* rows;       // [tile][plane][row][64][W]
+  const u64* wg_flags;   // [row]
+  u64* group_rows;       // [tile][plane][8][64][W]
+  u64* group_flags;      // [8]
+  F* host_out;           // mapped pinned host memory: [channels][block_size]
+  u32* host_done;        // mapped pinned: [0] epoch of the last finished call, [1] voices that marked done, [2] voices still running,
+                         // [5] first_epoch once the server's first workgroup runs; [8..9] the voice kernel saw the call's command,
+                         // [10..11] the root did, [12..13] tile 0's rows (root: nodes) had all arrived, [14..15] the last tile's,
+                         // [16..17] the root had written the last tile and the flags (device clock, 10 ns)
+  u64 idle_ticks;
+  u32 first_epoch, n_rows, planes, out_channels, block_size, tile_frames;
+};
+template <typename F> __device__ __forceinline__ bool res_read_sample(const u64* g, u32 tag, F& out);
+template <> __device__ __forceinline__ bool res_read_sample<float>(const u64* g, u32 tag, float& out) {
+  const u64 w = res_get(g);
+  out = __builtin_bit_cast(float, (u32)w);
+  return (u32)(w >> 32) == tag;
+}
+template <> __device__ __forceinline__ bool res_read_sample<double>(const u64* g, u32 tag, double& out) {
+  const u64 lo = res_get(g), hi = res_get(g + 1);
+  out = __builtin_bit_cast(double, (u64)(u32)lo | ((u64)(u32)hi << 32));
+  return (u32)(lo >> 32) == tag && (u32)(hi >> 32) == tag;
+}
+// Four wavefronts per workgroup, wavefront w taking tiles w, w + 4, ..: a tile costs its folder two trips through the memory
+// system (the probe that finds it complete, the read of its 32 granules per frame, all in flight together) -- about 3 us --
+// and the voice kernel turns one out every 1.4.  At most 168 registers each, so that a server wavefront fits on a SIMD BESIDE a
+// voice wavefront, which takes 300 of the 512 (with the compiler's free choice a first version took 247, and the CUs it sat
+// on had no room for their voice workgroup).
+template <typename F>
+__global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
+  constexpr int W = ResWords<F>::value;
+  constexpr u32 NW = 4u;
+  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const u32 n_g = (a.n_rows + 31u) / 32u;
+  const bool root = blockIdx.x == n_g;
+  const bool alone = n_g == 1u;  // one group: its folder is the root
+  if (root && alone) return;
+  const bool writes_host = root || alone;
+  const u32 g = blockIdx.x;
+  const u32 in_g = root ? n_g : (a.n_rows - g * 32u < 32u ? a.n_rows - g * 32u : 32u);
+  u32 expect = a.first_epoch;
+  const u64 patience = 2ull * a.idle_ticks + 5000000ull;
+  if (blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(&a.host_done[5], a.first_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_setprio(0);  // (the voice wavefronts raise theirs: a server wavefront shares its SIMD with one of them and, launched first, is the older)
+  for (;;) {
+    // the call
+    u64 c;
+    {
+      const u64 t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        c = __hip_atomic_load(a.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((u32)(c & RES_EPOCH_MASK) == expect) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { c = RES_LEAVE; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    const ResCall call = res_unpack(c);
+    if (call.leave) return;
+    expect = (expect + 1u) & (u32)RES_EPOCH_MASK;
+    const u32 n_frames = call.frame_end - call.frame_begin;
+    const u32 n_tiles = (n_frames + a.tile_frames - 1u) / a.tile_frames;
+    const bool tracer = writes_host && lane == 0u;  // diagnostics: the device clock at the call's milestones (host_done[10..])
+    if (tracer && wv == 0u) __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 10), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // Tiles wv, wv + NW, ..; the call's flag granules -- summed the same way -- are "tile" n_tiles in that dealing, so that the
+    // wavefront they fall to works on them beside the one that has the last tile.  Then a barrier of the workgroup, behind
+    // which everything this workgroup writes to the host is written, and the epoch.
+    for (u32 t = wv; t <= n_tiles; t += NW) {
+      const bool flags_pass = t == n_tiles;
+      const u32 tag = res_tag(call.epoch, flags_pass ? 255u : t);
+      const u32 rel = t * a.tile_frames;
+      const u32 len = flags_pass ? 1u : (n_frames - rel < a.tile_frames ? n_frames - rel : a.tile_frames);
+      const bool mine = lane < len;
+      bool gave_up = false;
+      for (u32 p = 0; p < (flags_pass ? 1u : a.planes); ++p) {
+        // where this wavefront's granules come from: row k's granule of frame 0 is base[k * stride]
+        const u64* base;
+        long stride;  // granules between one row's granule of a frame and the next row's
+        if (flags_pass) { base = root ? a.group_flags : a.wg_flags + g * 32u; stride = 1; }
+        else if (root) { base = a.group_rows + (((long)t * a.planes + p) * 8) * 64 * W; stride = 64 * W; }
+        else { base = a.rows + (((long)t * a.planes + p) * a.n_rows + g * 32u) * 64 * W; stride = 64 * W; }
+        const u64* const src = flags_pass ? base : base + (long)lane * W;  // this lane's frame
+        // First a PROBE: one granule of every row (frame 0's; lane k watches row k), asleep in between -- a wavefront that read
+        // all 32 x 64 granules in a loop took the issue slots of the voice wavefront it shares a SIMD with, and counters the
+        // workgroups added to became hot lines in the memory system.  Each probed line is written by one workgroup and read
+        // by one lane.  A row's other frames may land a moment later: the tags decide, below.
+        if (writes_host && lane == 0u) __hip_atomic_store(&a.host_done[20 + wv], 0x100u | (t << 16) | (p << 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (diagnostics: where each wavefront is)
+        if (p == 0u) {
+          const u64 tc = __builtin_amdgcn_s_memrealtime();
+          for (;;) {
+            bool there = true;
+            if (lane < in_g) there = (u32)(res_get(base + (long)lane * stride) >> 32) == tag;
+            if (__builtin_amdgcn_ballot_w64(!there) == 0ull) break;
+            if (__builtin_amdgcn_s_memrealtime() - tc > patience) { gave_up = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+          }
+          if (gave_up) break;
+          if (tracer && t == 0u) __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 12), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (tracer && t + 1u == n_tiles) __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 14), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (writes_host && lane == 0u) __hip_atomic_store(&a.host_done[20 + wv], 0x200u | (t << 16) | (p << 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // then every row's granule(s) of this lane's frame, all requested before any is looked at
+        u64 w[32 * W];
+        bool all = !mine;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_ballot_w64(!all) != 0ull) {
+          if (!all) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+#pragma unroll
+              for (int j = 0; j < W; ++j)  // (a flag granule is one word whatever the sample type)
+                w[k * W + j] = (u32)k < in_g && !(flags_pass && j > 0) ? res_get(src + (long)k * stride + j) : ((u64)tag << 32);
+            }
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 32 * W; ++k) ok = ok && (u32)(w[k] >> 32) == tag;
+            all = ok;
+          }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { gave_up = true; break; }
+        }
+        if (gave_up) break;
+        if (!mine) continue;
+        if (flags_pass) {
+          u32 n_done = 0, n_run = 0;
+          // (workgroup granules: counts in bits 0-7 and 8-15; group granules: bits 0-15 and 16-31)
+#pragma unroll
+          for (int k = 0; k < 32; ++k) {
+            const u32 d = (u32)k < in_g ? (u32)w[k * W] : 0u;
+            n_done += root ? (d & 0xFFFFu) : (d & 0xFFu);
+            n_run += root ? (d >> 16) : ((d >> 8) & 0xFFu);
+          }
+          if (writes_host) {
+            __hip_atomic_store(&a.host_done[1], n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&a.host_done[2], n_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          } else {
+            res_put(a.group_flags + g, n_done | (n_run << 16), tag);
+          }
+        } else {
+          F v[32];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) {
+            if constexpr (W == 1) v[k] = (F)__builtin_bit_cast(float, (u32)w[k]);
+            else v[k] = (F)__builtin_bit_cast(double, (u64)(u32)w[2 * k] | ((u64)(u32)w[2 * k + (W - 1)] << 32));
+          }
+          const F node = in_g == 32u ? tree_reduce<F, 32, true>(v, 1u, 32u) : tree_reduce<F, 32, false>(v, 1u, in_g);
+          if (writes_host) {
+            // the root, straight into the host's block: a mono mix goes to every channel, a Pan2 chain's planes are the channels
+            F* const out = a.host_out + call.frame_begin + rel + lane;
+            if (a.planes == 2u) __hip_atomic_store(out + (long)p * a.block_size, node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else for (u32 ch = 0; ch < a.out_channels; ++ch) __hip_atomic_store(out + (long)ch * a.block_size, node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          } else {
+            res_put_sample(a.group_rows + ((((long)t * a.planes + p) * 8 + g) * 64 + lane) * W, node, tag);
+          }
+        }
+      }
+      if (gave_up) return;  // (the voice kernel went away in mid-call: nothing to wait for; a wavefront that has ended no longer counts at the barrier)
+    }
+    if (writes_host) {
+      if (lane == 0u) __hip_atomic_store(&a.host_done[20 + wv], 0x300u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what this wavefront wrote to the host's block (and flags) is there
+      __syncthreads();                                   // ... and what the others wrote
+      if (threadIdx.x == 0u) {
+        __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 16), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.host_done[0], call.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

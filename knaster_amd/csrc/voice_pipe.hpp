@@ -106,18 +106,27 @@ template <typename F> struct PipeShared {
   // during which the wave -- and at the next barrier its whole pipeline -- stands still).  ev_lds_n == 0: read in place.
   const Event* ev_lds;
   u32 ev_lds_first, ev_lds_n;
+  // a resident launch (voice_chain.hpp, Resident): two words for the command, and where the stage groups leave what the
+  // mixer wavefront reports per call: [group wavefront][lane] the group's done mark, then [lane] "the voice's last envelope is running"
+  u32* res_slot;
+  u32* res_marks;
 };
 
 template <typename F, bool FMA, int T, bool PAN>
 __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 n_waves_total,
-                                               int blk, u32 n0, u32 len, u32 v0, u32 nv);
+                                               int blk, u32 n0, u32 len, u32 v0, u32 nv, u32 res_tile = 0u, u32 res_epoch = 0u);
 
 // One stage group = one wavefront.  I: group index, NG: number of chain groups (mixer excluded),
 // LAST_ENV: index of the group holding the chain's last envelope stage (-1: none).
 // MODE PIPE_FOLD: the last group also folds its tile over the voices (what pipe_run_mixer does in a wavefront of its own
 // otherwise): it stores the tile in a buffer no other wavefront touches and reads it back column-wise.
 template <typename F, bool FMA, int T, int MODE, int NG, int I, int BASE, int LAST_ENV, typename G>
-__device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv, int fan_i) {
+__device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv, int fan_i, int wave_all) {
+  // (a resident launch: the frame range and the event list are each call's)
+  const bool resident = a.res.bell != nullptr;
+  u32 res_expect = a.res.first_epoch;
+  u32 fbeg = a.frame_begin, fend = a.frame_end;
+  const u32* evs = a.ev_start;
   typedef typename GroupChain<F, FMA, BASE, G>::type ChainT;
   typedef typename WordOf<F>::type W;
   constexpr bool FOLDS = MODE == PIPE_FOLD && I == NG - 1;
@@ -151,17 +160,24 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   // The voice's next event waits in registers, whole: one 16-byte read per event (the list may sit in pinned host
   // memory, a PCIe round trip away), issued as soon as the event before it has been applied.
   u32 ev_i = 0, ev_end = 0;
-  if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
   Event nxt;
   nxt.frame = 0xFFFFFFFFu; nxt.slot_op = 0u; nxt.bits = 0ull;
   const bool ev_staged = sh.ev_lds_n != 0u;  // uniform: two plain loads (LDS / global, spelled with their address spaces), never a flat one
   typedef __attribute__((address_space(3))) const Event* lds_ev_t;
   typedef __attribute__((address_space(1))) const Event* glb_ev_t;
   const lds_ev_t ev_l = (lds_ev_t)sh.ev_lds;
-  const glb_ev_t ev_g = (glb_ev_t)a.events;
+  glb_ev_t ev_g = (glb_ev_t)a.events;
   auto fetch = [&](u32 i) -> Event {
     Event e;
     if (ev_staged) { e.frame = ev_l[i - sh.ev_lds_first].frame; e.slot_op = ev_l[i - sh.ev_lds_first].slot_op; e.bits = ev_l[i - sh.ev_lds_first].bits; }
+    else if (resident) {
+      // a resident launch reads lists the host has rewritten since the kernel started: no kernel boundary has emptied this
+      // CU's L1, so the loads say "system scope" themselves
+      const Event* q = (const Event*)ev_g + i;
+      e.frame = __hip_atomic_load(&q->frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      e.slot_op = __hip_atomic_load(&q->slot_op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      e.bits = __hip_atomic_load(&q->bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     else { e.frame = ev_g[i].frame; e.slot_op = ev_g[i].slot_op; e.bits = ev_g[i].bits; }
     return e;
   };
@@ -170,7 +186,6 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   // tile reads that were just issued; the wait belongs where the event is fetched, not where its frame is looked at).
   u32 next_frame = 0xFFFFFFFFu;
   auto note_next = [&]() { asm volatile("v_mov_b32 %0, %1" : "=v"(next_frame) : "v"(nxt.frame)); };
-  if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
   u32 base = 0;  // absolute frame of the current block's frame 0
   auto apply_events_upto = [&](u32 n_abs) {
     while (__builtin_expect(next_frame <= n_abs, 0)) {
@@ -184,9 +199,29 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       else { nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu; }
     }
   };
+  u32 done_frame = 0xFFFFFFFFu;
+  for (;;) {  // one pass per call of a resident launch; an ordinary launch makes one
+  if (resident) {
+    const ResCall call = res_wait(a.res, res_expect, sh.res_slot, wave_all, lane);
+    if (call.leave) break;
+    res_expect = (res_expect + 1u) & (u32)RES_EPOCH_MASK;
+    fbeg = call.frame_begin;
+    fend = call.frame_end;
+    evs = call.has_events ? a.res.ev_start[call.list] : nullptr;
+    ev_g = (glb_ev_t)a.res.events[call.list];
+    chain.reset_marks();
+  }
+  ev_i = 0; ev_end = 0;
+  nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu;
+  if (evs) {
+    if (resident) { ev_i = __hip_atomic_load(&evs[voice], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ev_end = __hip_atomic_load(&evs[voice + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    else { ev_i = evs[voice]; ev_end = evs[voice + 1]; }
+  }
+  if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
+  base = 0;
 
   // The pipeline runs continuously over all blocks of the launch: global tile g = (block, tile in block).
-  const u32 n_frames = a.frame_end - a.frame_begin;
+  const u32 n_frames = fend - fbeg;
   const int tpb = (int)((n_frames + T - 1) / T);           // tiles per block
   const int n_tiles = tpb * (int)a.n_blocks;
   const int n_steps = n_tiles + NG - (MODE == PIPE_FOLD ? 1 : 0);
@@ -220,10 +255,10 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       }
       if (ti == 0) {
         ctx.input_block = reinterpret_cast<const F*>(a.input) + (long)blk * a.in_channels * a.block_size;
-        chain.begin_block(a.frame_begin, ctx);
+        chain.begin_block(fbeg, ctx);
       }
-      const u32 n_tile = a.frame_begin + (u32)ti * T;
-      const u32 m_tile = a.frame_end - n_tile < (u32)T ? a.frame_end - n_tile : (u32)T;
+      const u32 n_tile = fbeg + (u32)ti * T;
+      const u32 m_tile = fend - n_tile < (u32)T ? fend - n_tile : (u32)T;
       const u32 n = n_tile + fo;                                                            // the window's first frame
       const u32 m = m_tile > fo ? (m_tile - fo < (u32)TW ? m_tile - fo : (u32)TW) : 0u;     // frames of it inside the block
       apply_events_upto(base + n);  // (a Fan wavefront: also the changes inside the part of the tile before its window)
@@ -385,10 +420,14 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
       const u64 t2 = __builtin_amdgcn_s_memtime();
 #endif
       if (++ti == tpb) {  // block finished for this group
-        apply_events_upto(base + a.frame_end);  // changes due exactly at the end (precise_timing.rs:85-103)
+        apply_events_upto(base + fend);  // changes due exactly at the end (precise_timing.rs:85-103)
         ti = 0;
         ++blk;
         base += a.block_size;
+        if (resident) {  // what the mixer wavefront reports for this call (it folds this tile one or more steps from now)
+          sh.res_marks[wave_all * 64 + lane] = chain.collect_done(0xFFFFFFFFu);
+          if (GroupInfo<G>::has_env && I == LAST_ENV) sh.res_marks[15 * 64 + lane] = live && !chain.last_env_stopped(false) ? 1u : 0u;
+        }
       }
 #if defined(KNH_DAG_STAMPS) || defined(KNH_TILE_FENCES)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -410,9 +449,11 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
     else if (MODE != PIPE_FOLD && I == 1) { a.flags[14] = (u32)(busy_tick / d); a.flags[15] = (u32)((busy - busy_in - busy_out - busy_tick) / d); }  // group 1: its arithmetic / its tile stores
   }
 #endif
+  done_frame = chain.collect_done(0xFFFFFFFFu);  // this group's envelopes; the kernel (a resident launch: the mixer wavefront) combines the groups in order
+  if (!resident) break;
+  }  // calls
   if (live) chain.store(a.state + voice, a.stride);
-  const u32 done_frame = chain.collect_done(0xFFFFFFFFu);  // this group's envelopes; the kernel combines the groups in order
-  if (GroupInfo<G>::has_env && I == LAST_ENV) {
+  if (!resident && GroupInfo<G>::has_env && I == LAST_ENV) {
     const bool running = live && !chain.last_env_stopped(false);
     const u64 br = __builtin_amdgcn_ballot_w64(running);
     if (lane == 0 && br) atomicAdd(&a.flags[1], (u32)__builtin_popcountll(br));
@@ -423,14 +464,18 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
 // Lane j folds frame j of a finished tile over the wave's voices: the wavefront's subtree of the bank's pairwise sum
 // (tree_reduce in voice_chain.hpp).  The tile is stored voice-major ([voice][T], the common edge format), so a read of one
 // voice's row by lanes 0..T-1 is conflict-free and the transposition costs nothing; all reads go out before the first add.
+// (a resident launch: the sums leave as granules for the fold server, tile `res_tile` of call `res_epoch`: voice_chain.hpp)
 template <typename F, bool FMA, int T, bool PAN>
 __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 n_waves_total,
-                                               int blk, u32 n0, u32 len, u32 v0, u32 nv) {
+                                               int blk, u32 n0, u32 len, u32 v0, u32 nv, u32 res_tile, u32 res_epoch) {
   constexpr int ST = EdgeLayout<F, T>::stride;
   if ((u32)lane < len) {
     const F* col = tile + lane;
     if constexpr (!PAN) {
-      a.partials[((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane] = fold_group<F, 64>(col, ST, nv);
+      F* const row = a.partials + ((long)blk * n_waves_total + wave_global) * a.block_size + n0 + lane;
+      const F sum = fold_group<F, 64>(col, ST, nv);
+      if (a.res.bell) res_put_sample(a.res.rows + (((long)res_tile * n_waves_total + wave_global) * 64 + lane) * ResWords<F>::value, sum, res_tag(res_epoch, res_tile));
+      else *row = sum;
       if (a.voices_out) {
         for (u32 v = 0; v < nv; ++v) a.voices_out[(long)(v0 + v) * a.block_size + n0 + lane] = col[v * ST];
       }
@@ -440,8 +485,12 @@ __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelA
       const F* gain = tile + T;
       F accl, accr;
       fold_group_pan<F, 64>(col, ST, gain, gain + 1, ST, nv, accl, accr);
-      a.partials[(((long)blk * 2 + 0) * n_waves_total + wave_global) * a.block_size + n0 + lane] = accl;
-      a.partials[(((long)blk * 2 + 1) * n_waves_total + wave_global) * a.block_size + n0 + lane] = accr;
+      F* const rl = a.partials + (((long)blk * 2 + 0) * n_waves_total + wave_global) * a.block_size + n0 + lane;
+      F* const rr = a.partials + (((long)blk * 2 + 1) * n_waves_total + wave_global) * a.block_size + n0 + lane;
+      if (a.res.bell) {
+        res_put_sample(a.res.rows + ((((long)res_tile * 2 + 0) * n_waves_total + wave_global) * 64 + lane) * ResWords<F>::value, accl, res_tag(res_epoch, res_tile));
+        res_put_sample(a.res.rows + ((((long)res_tile * 2 + 1) * n_waves_total + wave_global) * 64 + lane) * ResWords<F>::value, accr, res_tag(res_epoch, res_tile));
+      } else { *rl = accl; *rr = accr; }
       if (a.voices_out) {
         for (u32 v = 0; v < nv; ++v) {
           const F t = col[v * ST];
@@ -453,15 +502,30 @@ __device__ __forceinline__ void pipe_fold_tile(const F* tile, const VoiceKernelA
   }
 }
 
-// The mixer wavefront: folds the tile the last chain group finished in the previous step.
-template <typename F, bool FMA, int T, int MODE, int NG, bool PAN>
+// The mixer wavefront: folds the tile the last chain group finished in the previous step.  In a resident launch it also takes
+// the workgroup's row to the fold server as granules and, with a call's last tile, reports the call's done marks
+// and flags.  CHAINW = wavefronts that run stage groups; HAS_ENV: some group holds an envelope.
+template <typename F, bool FMA, int T, int MODE, int NG, bool PAN, int CHAINW, bool HAS_ENV>
 __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global,
-                                               u32 v0, u32 nv) {
-  const u32 n_frames = a.frame_end - a.frame_begin;
+                                               u32 v0, u32 nv, int wave_all) {
+  u32 fbeg = a.frame_begin, fend = a.frame_end;
+  const bool resident = a.res.bell != nullptr;
+  u32 res_expect = a.res.first_epoch;
+  const u32 n_waves_total = (a.n_voices + 63u) / 64u;
+  for (;;) {  // one pass per call of a resident launch
+  ResCall call;
+  call.epoch = 0u;
+  if (resident) {
+    call = res_wait(a.res, res_expect, sh.res_slot, wave_all, lane);
+    if (call.leave) break;
+    res_expect = (res_expect + 1u) & (u32)RES_EPOCH_MASK;
+    fbeg = call.frame_begin;
+    fend = call.frame_end;
+  }
+  const u32 n_frames = fend - fbeg;
   const int tpb = (int)((n_frames + T - 1) / T);
   const int n_tiles = tpb * (int)a.n_blocks;
   const int n_steps = n_tiles + NG;
-  const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   int blk = 0, ti = 0;
 #ifdef KNH_DAG_STAMPS
   u64 busy = 0;
@@ -475,27 +539,47 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
       const u32 rel = (u32)ti * T;
       const u32 len = n_frames - rel < (u32)T ? n_frames - rel : (u32)T;
       const F* tile = sh.edge + (long)EdgeMap<MODE, NG>::mixer_tile(g) * EdgeLayout<F, T>::tile;
-      pipe_fold_tile<F, FMA, T, PAN>(tile, a, lane, wave_global, n_waves_total, blk, a.frame_begin + rel, len, v0, nv);
+      pipe_fold_tile<F, FMA, T, PAN>(tile, a, lane, wave_global, n_waves_total, blk, fbeg + rel, len, v0, nv, (u32)g, call.epoch);
+      if (resident && g == n_tiles - 1) {
+        // the call's last tile: every stage group is through with the call (its marks are in LDS since its last step's
+        // barrier).  mark_done of a voice = that of the last node in task order that set one: the groups in chain order.
+        u32 n_done = 0u, n_run = 0u;
+        if (HAS_ENV) {
+          u32 d = 0xFFFFFFFFu;
+#pragma unroll
+          for (int w = 0; w < CHAINW; ++w) d = sh.res_marks[w * 64 + lane] != 0xFFFFFFFFu ? sh.res_marks[w * 64 + lane] : d;
+          const bool live = (u32)lane < nv;
+          if (live) a.done_frames[v0 + lane] = d;
+          n_done = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && d != 0xFFFFFFFFu));
+          n_run = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && sh.res_marks[15 * 64 + lane] != 0u));
+        }
+        if (lane == 0) res_put(a.res.wg_flags + wave_global, n_done | (n_run << 8), res_tag(call.epoch, 255u));
+      }
       if (++ti == tpb) { ti = 0; ++blk; }
 #ifdef KNH_DAG_STAMPS
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       busy += __builtin_amdgcn_s_memtime() - t0;
 #endif
     }
-    pipe_barrier();
+    // (a resident launch: the mixer's granules are write-through stores nobody in the workgroup waits for; the step barrier only
+    // has to order its LDS reads -- the workgroup-scope release of pipe_barrier would also wait for those stores to be acknowledged)
+    if (resident) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else pipe_barrier();
   }
 #ifdef KNH_DAG_STAMPS
   if (wave_global == 0u && lane == 0) a.flags[4 + NG] = (u32)(busy / (u64)(n_tiles > 0 ? n_tiles : 1));
 #endif
+  if (!resident) break;
+  }  // calls
 }
 
 // W0: the first wavefront of group I (a Fan group takes several)
 template <typename F, bool FMA, int T, int MODE, int NG, int I, int BASE, int W0, int LAST_ENV, typename G, typename... Rest>
-__device__ __forceinline__ u32 pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv) {
+__device__ __forceinline__ u32 pipe_dispatch(int wave, const PipeShared<F>& sh, const VoiceKernelArgs<F>& a, int lane, u32 wave_global, u32 v0, u32 nv, int wave_all) {
   constexpr int KF = GroupInfo<G>::fan_for(T);
-  if (wave >= W0 && wave < W0 + KF) return pipe_run_group<F, FMA, T, MODE, NG, I, BASE, LAST_ENV, G>(sh, a, lane, wave_global, v0, nv, wave - W0);
+  if (wave >= W0 && wave < W0 + KF) return pipe_run_group<F, FMA, T, MODE, NG, I, BASE, LAST_ENV, G>(sh, a, lane, wave_global, v0, nv, wave - W0, wave_all);
   if constexpr (sizeof...(Rest) > 0)
-    return pipe_dispatch<F, FMA, T, MODE, NG, I + 1, BASE + GroupInfo<G>::slots, W0 + KF, LAST_ENV, Rest...>(wave, sh, a, lane, wave_global, v0, nv);
+    return pipe_dispatch<F, FMA, T, MODE, NG, I + 1, BASE + GroupInfo<G>::slots, W0 + KF, LAST_ENV, Rest...>(wave, sh, a, lane, wave_global, v0, nv, wave_all);
   return 0xFFFFFFFFu;
 }
 // wavefronts of a pipeline: one per group (K per Fan group), plus the mixer unless the last group folds
@@ -531,7 +615,7 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
   // (the edge before it has three buffers instead)
   constexpr long kEdgeElems = (long)EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile;  // per voice group
   // what is left of the CU's 160 KiB holds the workgroup's events (16 bytes each), up to 2 048 of them
-  constexpr long kLdsFree = 160 * 1024 - 1024 - (long)sizeof(float) * (kSine ? 16384 : 4) - (long)sizeof(F) * GPW * kEdgeElems;
+  constexpr long kLdsFree = 160 * 1024 - 1024 - 4096 - 64 - (long)sizeof(float) * (kSine ? 16384 : 4) - (long)sizeof(F) * GPW * kEdgeElems;
 #ifndef KNH_EVCAP_MAX
 #define KNH_EVCAP_MAX 2048
 #endif
@@ -542,6 +626,8 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
     float sine[kSine ? 16384 : 4];
     __attribute__((aligned(16))) F edge[GPW * kEdgeElems];
     __attribute__((aligned(16))) Event ev_stage[kEvCap > 0 ? kEvCap : 1];
+    u32 res_marks[16 * 64];  // a resident launch: the groups' done marks and running flags of the call (PipeShared)
+    u32 res_slot[16];        // ... and its command word
   };
   __shared__ Lds lds;
   float* const sine = lds.sine;
@@ -557,7 +643,7 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
   // instructions (tools/micro/valu_issue.hip: with two waves on a SIMD scalar ops keep their rate, packed f32 ops do not).
   const int wave = GPW > 1 ? (wave_all + (grp ? WAVES / 2 : 0)) % WAVES : wave_all;
   u32 ev_first = 0, ev_count = 0;
-  if (kEvCap > 0 && a.ev_start) {  // (the groups' voices are neighbours: one contiguous piece of the list, which is sorted by voice)
+  if (kEvCap > 0 && a.ev_start && !a.res.bell) {  // (the groups' voices are neighbours: one contiguous piece of the list, which is sorted by voice)
     const u32 gv0 = blockIdx.x * (u32)(GPW * 64);
     const u32 gnv = a.n_voices - gv0 < (u32)(GPW * 64) ? a.n_voices - gv0 : (u32)(GPW * 64);
     ev_first = a.ev_start[gv0];
@@ -576,12 +662,17 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  // a resident launch shares its SIMDs with the fold server's wavefronts (older, and so the winners of every issue slot both
+  // want): the voice wavefronts take the higher priority
+  if (a.res.bell) __builtin_amdgcn_s_setprio(3);
   PipeShared<F> sh;
   sh.sine = sine;
   sh.edge = edge + (long)grp * kEdgeElems;
   sh.ev_lds = ev_stage;
   sh.ev_lds_first = ev_first;
   sh.ev_lds_n = ev_count;
+  sh.res_slot = lds.res_slot;
+  sh.res_marks = lds.res_marks;
   const u32 wave_global = blockIdx.x * (u32)GPW + (u32)grp;  // the 64-voice group of the bank
   const u32 v0 = wave_global * 64u;
   const bool dead = GPW > 1 && v0 >= a.n_voices;  // the last workgroup of a bank with an odd number of voice groups
@@ -594,10 +685,12 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
     const int n_steps = (int)((n_frames + T - 1) / T) * (int)a.n_blocks + NG - (MODE == PIPE_FOLD ? 1 : 0);
     for (int s = 0; s < n_steps; ++s) pipe_barrier();
   } else if (wave == CHAINW) {
-    pipe_run_mixer<F, FMA, T, MODE, NG, kPan>(sh, a, lane, wave_global, v0, nv);
+    constexpr bool kAnyEnvM = (false || ... || GroupInfo<Gs>::has_env);
+    pipe_run_mixer<F, FMA, T, MODE, NG, kPan, CHAINW, kAnyEnvM>(sh, a, lane, wave_global, v0, nv, wave_all);
   } else {
-    done_frame = pipe_dispatch<F, FMA, T, MODE, NG, 0, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv);
+    done_frame = pipe_dispatch<F, FMA, T, MODE, NG, 0, 0, 0, LastEnv<0, Gs...>::value, Gs...>(wave, sh, a, lane, wave_global, v0, nv, wave_all);
   }
+  if (a.res.bell) return;  // a resident launch has reported call by call (pipe_run_mixer)
   // mark_done of a voice = that of the last node in task order that set one: combine the groups in chain order
   constexpr bool kAnyEnv = (false || ... || GroupInfo<Gs>::has_env);
   if constexpr (kAnyEnv) {

@@ -3,7 +3,7 @@
 // processor.rs:142-179, graph_gen.rs:110-200).
 //   shim_twin_test --cpu                 : what needs no device (the exception guard of the ABI)
 //   shim_twin_test --gpu                 : the call sequences on a MI355X, checked against the oracle / against one launch
-//   shim_twin_test --bench C3|C1 [blocks]: the per-block boundary rate, one JSON line
+//   shim_twin_test --bench C3|C1 [blocks] [batched] [ktime]: the per-block boundary rate, one JSON line
 #include <sys/resource.h>
 
 #include <algorithm>
@@ -199,6 +199,11 @@ static void gpu_partial_blocks() {
       CHECK(legacy_process_block(old.raw(), pctx, view_old.channel_as_slice_mut(0).ptr) == KNH_OK);
     }
     CHECK(std::memcmp(whole.data(), parts.data(), whole.size() * sizeof(float)) == 0);
+    if (std::memcmp(whole.data(), parts.data(), whole.size() * sizeof(float)) != 0) {
+      int first = -1, count = 0;
+      for (int i = 0; i < 2 * B; ++i) if (std::memcmp(&whole[i], &parts[i], 4) != 0) { if (first < 0) first = i; ++count; }
+      std::printf("  block %d: %d of %d samples differ, first at %d: %.9g vs %.9g\n", blk, count, 2 * B, first, whole[first], parts[first]);
+    }
     for (int g = 0; g < GUARD; ++g) CHECK(parts[2 * B + g] == -7.f);  // nothing behind channel 1
     legacy_differs = legacy_differs || std::memcmp(whole.data(), legacy.data(), whole.size() * sizeof(float)) != 0;
     for (int g = 0; g < GUARD; ++g) legacy_overruns = legacy_overruns || legacy[2 * B + g] != -7.f;
@@ -289,9 +294,13 @@ static void gpu_inputs_and_audio_rate_buffer() {
 }
 
 // ---------------------------------------------------------------------------------------------------
-static int bench(const char* name, int blocks) {
+// batched: a block's triggers go through ONE knh_bank_param_apply_many call (what a host that hands its events over in
+// batches does) instead of one knh_bank_param_apply per voice (what GraphGen::apply_parameter_change does per SchedulingEvent)
+// ktime: also measure the voice kernel's device time per call (a timed bank launches a kernel per call: no resident kernel)
+static int bench(const char* name, int blocks, bool batched, bool ktime) {
   const bool c1 = !std::strcmp(name, "C1");
-  const int N = c1 ? 1 : 16384, B = c1 ? 64 : 512, UGENS = c1 ? 3 : 4;
+  const char* nv_env = std::getenv("TWIN_VOICES");  // (diagnostics: the C3 voice at another bank size)
+  const int N = c1 ? 1 : (nv_env ? std::atoi(nv_env) : 16384), B = c1 ? 64 : 512, UGENS = c1 ? 3 : 4;
   std::vector<knh_stage_desc> chain = c1 ? std::vector<knh_stage_desc>{stage(KNH_STAGE_SIN_WT), stage(KNH_STAGE_MUL_CONST)} : c3_chain();
   std::vector<std::vector<double>> ctor = c1 ? std::vector<std::vector<double>>{{440.0}, {0.2}} : c3_ctor(N);
   GpuVoiceBank<float> bank(chain, N, ctor);
@@ -303,36 +312,54 @@ static int bench(const char* name, int blocks) {
   std::vector<float> out(2 * B);
   std::vector<size_t> i_restart, i_release;
   if (!c1) for (int v = 0; v < N; ++v) { i_restart.push_back(bank.index(v, 3, "t_restart")); i_release.push_back(bank.index(v, 3, "t_release")); }
+  std::vector<uint32_t> all_v(N), st3(N, 3u), p_restart(N, 3u), p_release(N, 2u), k_trig(N, KNH_VALUE_TRIGGER);
+  for (int v = 0; v < N; ++v) all_v[v] = uint32_t(v);
   std::vector<double> us;
   us.reserve(blocks);
   double peak = 0;
+  double trace_us[4] = {0, 0, 0, 0};
+  long trace_n = 0;
   auto run = [&](int n, bool timed) {
     for (int blk = 0; blk < n; ++blk) {
       const auto t0 = std::chrono::steady_clock::now();
-      if (!c1 && blk % 64 == 0) for (size_t i : i_restart) bank.param_apply(ctx, i, Value::Trigger);   // one SchedulingEvent per voice
-      if (!c1 && blk % 64 == 32) for (size_t i : i_release) bank.param_apply(ctx, i, Value::Trigger);
+      if (!c1 && batched) {
+        if (blk % 64 == 0) knh_bank_param_apply_many(bank.raw(), N, all_v.data(), st3.data(), p_restart.data(), k_trig.data(), nullptr, nullptr, nullptr);
+        if (blk % 64 == 32) knh_bank_param_apply_many(bank.raw(), N, all_v.data(), st3.data(), p_release.data(), k_trig.data(), nullptr, nullptr, nullptr);
+      } else if (!c1) {
+        if (blk % 64 == 0) for (size_t i : i_restart) bank.param_apply(ctx, i, Value::Trigger);   // one SchedulingEvent per voice
+        if (blk % 64 == 32) for (size_t i : i_release) bank.param_apply(ctx, i, Value::Trigger);
+      }
       bank.process_block(ctx, flags, nullptr, out.data());
       ctx.frame_clock += B;
       const auto t1 = std::chrono::steady_clock::now();
       if (timed) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+      if (timed) {
+        uint64_t tk[5];
+        if (knh_bank_resident_trace(bank.raw(), tk) == KNH_OK && tk[0] && tk[4] >= tk[0]) {
+          for (int k = 0; k < 4; ++k) trace_us[k] += double(int64_t(tk[k + 1] - tk[0])) * 0.01;
+          trace_n += 1;
+        }
+      }
       for (float x : out) peak = std::max(peak, double(std::fabs(x)));
     }
   };
   run(128, false);  // warm-up: clocks, first-use allocations
-  knh_bank_timing_reset(bank.raw(), 1);
+  if (ktime) knh_bank_timing_reset(bank.raw(), 1);
   const auto t0 = std::chrono::steady_clock::now();
   run(blocks, true);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   double kms = 0;
   uint64_t launches = 0;
-  knh_bank_timing_read(bank.raw(), &kms, &launches);
+  if (ktime) knh_bank_timing_read(bank.raw(), &kms, &launches);
   std::sort(us.begin(), us.end());
   const double rate = double(N) * B * UGENS * blocks / secs;
-  std::printf("{\"config\": \"%s\", \"driver\": \"C++ twin of the Rust shim: one knh_bank_process_block per block, single-call param_apply per event\", "
+  std::printf("{\"config\": \"%s\", \"driver\": \"C++ twin of the Rust shim: one knh_bank_process_block_channels per block, %s\", \"kernel_timed\": %s, "
               "\"voices\": %d, \"block_size\": %d, \"blocks\": %d, \"ugen_samples_per_s\": %.6g, \"us_per_block_mean\": %.3f, \"us_per_block_p50\": %.3f, "
-              "\"us_per_block_p99\": %.3f, \"us_per_block_min\": %.3f, \"voice_kernel_us_per_block\": %.3f, \"output_peak\": %.4g}\n",
-              name, N, B, blocks, rate, secs * 1e6 / blocks, us[us.size() / 2], us[size_t(us.size() * 0.99)], us.front(),
-              launches ? kms * 1e3 / double(launches) : 0.0, peak);
+              "\"us_per_block_p99\": %.3f, \"us_per_block_min\": %.3f, \"voice_kernel_us_per_block\": %.3f, \"output_peak\": %.4g, "
+              "\"resident_calls\": %ld, \"device_us_after_the_voice_kernel_saw_the_command\": {\"fold_server_saw_it\": %.2f, \"first_tile_complete\": %.2f, \"last_tile_complete\": %.2f, \"block_and_flags_written\": %.2f}}\n",
+              name, batched ? "a block's triggers in one knh_bank_param_apply_many" : "single-call param_apply per event", ktime ? "true" : "false", N, B, blocks, rate, secs * 1e6 / blocks, us[us.size() / 2], us[size_t(us.size() * 0.99)], us.front(),
+              launches ? kms * 1e3 / double(launches) : 0.0, peak, trace_n, trace_n ? trace_us[0] / trace_n : 0.0, trace_n ? trace_us[1] / trace_n : 0.0,
+              trace_n ? trace_us[2] / trace_n : 0.0, trace_n ? trace_us[3] / trace_n : 0.0);
   return 0;
 }
 
@@ -343,7 +370,9 @@ int main(int argc, char** argv) {
     gpu = gpu || !std::strcmp(argv[i], "--gpu");
     if (!std::strcmp(argv[i], "--bench")) {
       if (knh_device_count() < 1) { std::printf("no gfx950 device\n"); return 2; }
-      return bench(i + 1 < argc ? argv[i + 1] : "C3", i + 2 < argc ? std::atoi(argv[i + 2]) : 1024);
+      bool batched = false, ktime = false;
+      for (int k = i + 1; k < argc; ++k) { batched = batched || !std::strcmp(argv[k], "batched"); ktime = ktime || !std::strcmp(argv[k], "ktime"); }
+      return bench(i + 1 < argc ? argv[i + 1] : "C3", i + 2 < argc && std::atoi(argv[i + 2]) > 0 ? std::atoi(argv[i + 2]) : 1024, batched, ktime);
     }
   }
   if (!cpu && !gpu) cpu = true;

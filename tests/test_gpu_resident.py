@@ -1,0 +1,124 @@
+"""The per-block call on a RESIDENT kernel (voice_chain.hpp `Resident`, knh_bank_resident_stats): knh_bank_process_block is the
+call the reference makes once per block (Task::run, knaster_graph/src/task.rs:25-31); where the bank's kernel form allows it the
+kernel stays on its CUs between calls.  Everything here is held to the launch-per-call path (KNH_RESIDENT=0), bit for bit --
+which the parity suites hold to the oracle."""
+import time
+
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, fire_all, make_gpu
+from knaster_amd import _lib as L
+from knaster_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def _script(bank, w, block, rng_seed=5):
+    """the block's parameter traffic: note on, changes on a few voices, note off, and on again"""
+    n = w.n_voices
+    v = np.arange(n, dtype=np.uint32)
+    if block == 0:
+        fire_all(bank, n, *w.restart)
+    if block == 3 and w.stages[2].kind == L.STAGE_SVF:
+        some = v[::7]
+        bank.param_apply_many(some, 2, 0, L.VALUE_FLOAT, 400.0 + (some % 900))  # SvfFilter cutoffs
+    if block == 4:
+        bank.param_apply(n - 1, 0, 0, 333.0)
+    if block == 6 and w.release:
+        bank.param_apply_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER)
+    if block == 9:
+        fire_all(bank, n, *w.restart)
+
+
+def _render(knh, monkeypatch, name, n, bs, resident, blocks=12, splits=(), pause_after=None, other_calls=False):
+    monkeypatch.setenv("KNH_RESIDENT", "1" if resident else "0")
+    w = configs.config(name, n_voices=n, block_size=bs)
+    g = make_gpu(knh, w, L.MIX_TREE)
+    outs, flags = [], []
+    for b in range(blocks):
+        if w.restart:
+            _script(g, w, b)
+        if b in splits:  # the block in two partial calls (a splitting wrapper around the node)
+            cut = bs // 3 + 1
+            out = np.zeros((w.out_channels, bs), dtype=g.dtype)
+            o1, f1 = g.process_block(cut, 0)
+            o2, f2 = g.process_block(bs - cut, cut)
+            out[:, :cut] = o1[:, :cut]
+            out[:, cut:] = o2[:, cut:]
+            f = f2
+        else:
+            out, f = g.process_block()
+        outs.append(out.copy())
+        flags.append(f)
+        if pause_after is not None and b == pause_after:
+            time.sleep(0.05)
+        if other_calls and b == 5:
+            outs.append(g.read_done_frames().astype(np.float64).reshape(1, -1)[:, :1])  # (an entry point that needs the device state)
+            many, _ = g.process_blocks(3)
+            outs.extend(list(many))
+    done = g.read_done_frames()
+    stats = g.resident_stats()
+    g.close()
+    return outs, flags, done, stats
+
+
+CASES = [("C3", 70, 64), ("C3", 2100, 128), ("C3", 16384, 512), ("C4", 200, 96), ("M1", 600, 64), ("C2", 1024, 256), ("P3", 300, 64)]
+
+
+@pytest.mark.parametrize("name,n,bs", CASES)
+def test_resident_calls_equal_a_launch_per_call(knh, monkeypatch, name, n, bs):
+    """Note cycles, parameter changes and two split blocks, block by block: same samples, flags and done frames with the
+    kernel resident as with a launch per call; and the resident kernel really served the calls from ONE launch."""
+    blocks = 12 if n < 10000 else 6
+    a = _render(knh, monkeypatch, name, n, bs, True, blocks=blocks, splits=(2, 7))
+    b = _render(knh, monkeypatch, name, n, bs, False, blocks=blocks, splits=(2, 7))
+    for k, (x, y) in enumerate(zip(a[0], b[0])):
+        assert_bit_equal(x, y, f"{name} block {k}")
+    assert a[1] == b[1]
+    np.testing.assert_array_equal(a[2], b[2])
+    assert np.abs(np.stack(b[0])).max() > 1e-5
+    assert b[3] == (0, 0)
+    n_split = sum(1 for k in (2, 7) if k < blocks)
+    assert a[3] == (blocks + n_split, 1), a[3]  # every call (the split blocks in two calls each) on one launch
+
+
+def test_an_idle_resident_kernel_leaves_by_itself_and_the_next_call_starts_another(knh, monkeypatch):
+    monkeypatch.setenv("KNH_RESIDENT_IDLE_US", "300")
+    a = _render(knh, monkeypatch, "C3", 700, 64, True, pause_after=4)
+    b = _render(knh, monkeypatch, "C3", 700, 64, False)
+    for k, (x, y) in enumerate(zip(a[0], b[0])):
+        assert_bit_equal(x, y, f"block {k}")
+    np.testing.assert_array_equal(a[2], b[2])
+    assert a[3][0] == 12 and a[3][1] >= 2, a[3]  # the pause outlasted the kernel's patience: a second launch
+
+
+def test_other_entry_points_between_resident_calls(knh, monkeypatch):
+    """read_done_frames and a multi-block launch in the middle: the resident kernel hands the state back, the next per-block
+    call starts a new one."""
+    a = _render(knh, monkeypatch, "C3", 700, 64, True, other_calls=True)
+    b = _render(knh, monkeypatch, "C3", 700, 64, False, other_calls=True)
+    assert len(a[0]) == len(b[0])
+    for k, (x, y) in enumerate(zip(a[0], b[0])):
+        assert_bit_equal(np.asarray(x), np.asarray(y), f"item {k}")
+    assert a[3][1] == 2, a[3]
+
+
+def test_two_banks_take_turns_on_the_device(knh, monkeypatch):
+    """Two banks of one process called alternately: each launch asks the other bank's resident kernel to leave (it holds every
+    CU's LDS); after that the banks stay with a launch per call for a while.  Same samples as ever."""
+    w = configs.config("C3", n_voices=500, block_size=64)
+    g1, g2, ref = make_gpu(knh, w, L.MIX_TREE), make_gpu(knh, w, L.MIX_TREE), make_gpu(knh, w, L.MIX_TREE)
+    for b in range(6):
+        for bank in (g1, g2, ref):
+            _script(bank, w, b)
+        monkeypatch.setenv("KNH_RESIDENT", "0")  # (a bank decides at its first process call)
+        want, _ = ref.process_block()
+        monkeypatch.setenv("KNH_RESIDENT", "1")
+        o1, _ = g1.process_block()
+        o2, _ = g2.process_block()
+        assert_bit_equal(o1, want, f"bank 1 block {b}")
+        assert_bit_equal(o2, want, f"bank 2 block {b}")
+    assert g1.resident_stats()[1] >= 1
+    for bank in (g1, g2, ref):
+        bank.close()
