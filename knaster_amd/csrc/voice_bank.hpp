@@ -356,19 +356,24 @@ struct Bank final : knh_bank {
     if (!h_res_done) return;
     for (int k = 0; k < 5; ++k) std::memcpy(&five[k], h_res_done + 8 + 2 * k, 8);
   }
+  bool jit_pipe = false;  // the run-time fused kernel is a pipeline (mixer form, short tiles), not a one-wavefront kernel
   bool res_possible() const {
-    // the pipelined forms with a mixer wavefront and one voice group per workgroup (each workgroup a CU's LDS to itself: at
-    // most one per CU, so a bank of up to 256 groups), tree mix, no bank inputs (their upload rides in a stream)
-    if (!pipe || pipe_pair || dag || wide_waves != 0 || interp || jit) return false;
-    if (pipe->form == 1 /* PIPE_FOLD: no mixer wavefront */ || pipe->gpw != 1) return false;
-    if (desc.mix_mode != KNH_MIX_TREE || uses_input) return false;
+    // Kernel forms in which every workgroup can be resident at once and the fold server can take the rows: the pipelined forms
+    // with a mixer wavefront and one voice group per workgroup, and the one-wavefront kernel (pre-built or fused at run time);
+    // up to 256 voice groups (the server folds 8 x 32 rows), tree mix, no bank inputs (their upload rides in a stream).
+    if (interp || dag || uses_input || desc.mix_mode != KNH_MIX_TREE) return false;
     if ((nv + 63u) / 64u > 256u || block_size > 4096) return false;
-    return true;
+    if (wide_waves != 0) return false;
+    if (jit) return true;
+    if (pipe) return !pipe_pair && pipe->form != 1 /* PIPE_FOLD: no mixer wavefront */ && pipe->gpw == 1;
+    return entry != nullptr;
   }
   // frames per tile of the bank's pipelined kernel form (voice_pipe.hpp, PipeTile: the forms with the long tiles, and the
   // Fan pipelines, 64 -- f64: 32; the mixer form 32 / 16)
   uint32_t res_tile_frames() const {
-    const bool big = pipe && pipe->long_tiles != 0;
+    if (jit && jit_pipe) return sizeof(F) == 8 ? 16u : 32u;  // (jit.hip fuses pipelines in the mixer form with the short tiles)
+    if (jit || !pipe) return 64u;                             // the one-wavefront kernel hands its rows over in 64-frame tiles
+    const bool big = pipe->long_tiles != 0;
     return sizeof(F) == 8 ? (big ? 32u : 16u) : (big ? 64u : 32u);
   }
   static hipError_t launch_res_server(const knh_dev::ResServerArgs<float>& a, hipStream_t s) { return knh::launch_res_server_f32(a, s); }
@@ -504,9 +509,14 @@ struct Bank final : knh_bank {
     a.res.host_started = h_res_done + 4;
     a.res.first_epoch = first_epoch;
     a.res.max_tiles = res_max_tiles;
+    // (0: only workgroup 0 reads the host's word, also when it lives in device memory.  With every workgroup reading it, a
+    // command that arrives just as workgroup 0 gives up waiting would be taken by some workgroups and not by it: the relay makes
+    // workgroup 0 the one place where "this command" or "leave" is decided.  Costs 0.5 us per call.)
+    a.res.bell_is_device = 0u;
     {  // the fold server first: a handful of wavefronts that will sit beside the voice kernel's workgroups
       knh_dev::ResServerArgs<F> sa{};
       sa.relay = reinterpret_cast<const knh_dev::u64*>(d_res_relay);
+      sa.bell = nullptr;  // (as for the voice kernel: the relay decides)
       sa.rows = reinterpret_cast<const knh_dev::u64*>(d_res_rows);
       sa.wg_flags = reinterpret_cast<const knh_dev::u64*>(d_res_wg_flags);
       sa.group_rows = reinterpret_cast<knh_dev::u64*>(d_res_group_rows);
@@ -876,6 +886,7 @@ struct Bank final : knh_bank {
       unsigned cuts[2];
       const unsigned n_cuts = partition_chain(signature, cuts);
       jit = knh::jit_pipe_kernel(signature.c_str(), cuts, n_cuts, sizeof(F) == 8, desc.allow_fma != 0, &why);
+      jit_pipe = jit != nullptr;
       if (!jit) return fail(why.rfind("JIT_CRASH: ", 0) == 0 ? KNH_ERR_INTERNAL : KNH_ERR_UNSUPPORTED_CHAIN, "run-time fusion of chain '" + signature + "' (pipelined) failed: " + why);
     } else if (!entry && !interp) {  // no pre-built kernel at all
       std::string why;
@@ -1480,6 +1491,26 @@ struct Bank final : knh_bank {
           const uint16_t d = delays ? delays[p] : 0;
           q.push_back(make_qrec(v, stage, param, kind, fvalues ? fvalues[p] : 0.0, ivalues ? ivalues[p] : 0, d, d > 0));
         }
+      } else if (direct && kinds[k] == KNH_VALUE_TRIGGER && (stages[stgs[k]].kind == KNH_STAGE_MUL_ENV_ASR || stages[stgs[k]].kind == KNH_STAGE_MUL_ENV_AR) &&
+                 !(stages[stgs[k]].ar_param != 0 && params[k] + 1u == stages[stgs[k]].ar_param)) {
+        // An envelope trigger for a run of voices (the note-on / note-off of a whole bank): the patch is the same for every voice
+        // (apply_now: EV_SET state = Attacking, or the release op) -- one event template, stamped with each voice's index.
+        const StageInfo& S = stages[stgs[k]];
+        const uint32_t frame = block_offset * static_cast<uint32_t>(block_size);
+        note_frame(frame);
+        const bool release = S.kind == KNH_STAGE_MUL_ENV_ASR && params[k] == 2;
+        HostEvent t{0u, frame, release ? static_cast<uint32_t>(knh_dev::EV_ENV_ASR_RELEASE) : static_cast<uint32_t>(knh_dev::EV_SET), static_cast<uint32_t>(S.slot_base), release ? 0ull : 1ull};
+        const size_t at = pending.size();
+        pending.resize(at + (e - k));
+        HostEvent* out = pending.data() + at;
+        size_t w = 0;
+        for (size_t q = k; q < e; ++q) {
+          const uint32_t v = voices[q];
+          if (v >= nv) { rc = fail(KNH_ERR_OUT_OF_RANGE, "voice out of range"); continue; }
+          t.voice = v;
+          out[w++] = t;
+        }
+        pending.resize(at + w);
       } else if (direct) {
         const uint32_t stage = stgs[k], param = params[k];
         const uint32_t frame = block_offset * static_cast<uint32_t>(block_size);
@@ -1871,9 +1902,26 @@ struct Bank final : knh_bank {
     h_ev_start = h_ev_start2[lb];
     h_events = h_events2[lb];
     list_in_use = static_cast<int>(lb);
+    uint32_t* start = h_ev_start;  // nv + 2 words
+    // Already in voice order (a batch of triggers for voices 0 .. N - 1, the common big list): one pass, no sort.
+    bool in_voice_order = true;
+    {
+      uint32_t prev = 0;
+      for (const HostEvent& e : pending) { if (e.voice < prev) { in_voice_order = false; break; } prev = e.voice; }
+    }
+    if (in_voice_order) {
+      uint32_t v_next = 0, i = 0;
+      for (const HostEvent& e : pending) {
+        while (v_next <= e.voice) start[v_next++] = i;
+        Event& d = h_events[i++];
+        d.frame = e.frame;
+        d.slot_op = (e.slot & 0xFFFFFFu) | (e.op << 24);
+        d.bits = e.bits;
+      }
+      while (v_next <= nv) start[v_next++] = i;
+    } else {
     // counting sort by voice (stable: keeps application order): counts two places up, so that after the prefix sum
     // start[v + 1] is where voice v's events begin, and after the scatter (which advances it) where voice v + 1's do
-    uint32_t* start = h_ev_start;  // nv + 2 words
     std::fill(start, start + nv + 2, 0u);
     for (const HostEvent& e : pending) start[e.voice + 2]++;
     for (uint32_t v = 0; v < nv; ++v) start[v + 2] += start[v + 1];
@@ -1882,6 +1930,7 @@ struct Bank final : knh_bank {
       d.frame = e.frame;
       d.slot_op = (e.slot & 0xFFFFFFu) | (e.op << 24);
       d.bits = e.bits;
+    }
     }
     if (pending_needs_sort) {  // then each voice's few events by frame (stable)
       for (uint32_t v = 0; v < nv; ++v) {

@@ -190,6 +190,7 @@ struct DagChain<F, FMA, BASE, R, LAST, Slots<R2>> {
   __device__ __forceinline__ void on_event(u32, u32, u64, u32) {}
   __device__ __forceinline__ bool last_env_stopped(bool dflt) const { return dflt; }
   __device__ __forceinline__ u32 collect_done(u32 acc) const { return acc; }
+  __device__ __forceinline__ void reset_marks() {}
   template <int J> __device__ __forceinline__ void collect_done_ranked(u64, u32&, u32&) const {}
   __device__ __forceinline__ void begin_block(u32, const Ctx&) {}
 };
@@ -263,6 +264,7 @@ struct DagChain<F, FMA, BASE, R, LAST, N0, Rest...> {
     if constexpr (S0::kIsEnv) acc = mark != 0xFFFFFFFFu ? mark : acc;
     return rest.collect_done(acc);
   }
+  __device__ __forceinline__ void reset_marks() { mark = 0xFFFFFFFFu; rest.reset_marks(); }
   // The same with the envelopes taken in the reference's task order (one UGenFlags for all tasks of a graph: the last
   // mark_done wins, graph_gen.rs:196-200): J = this stage's number among the envelope stages, ranks = VoiceKernelArgs::env_ranks.
   template <int J> __device__ __forceinline__ void collect_done_ranked(u64 ranks, u32& best_rank, u32& best) const {
@@ -332,6 +334,9 @@ struct Resident {
                             // voice kernel and the fold server really run side by side before it relies on them)
   u32 first_epoch;          // the epoch of the first command this launch takes
   u32 max_tiles;
+  u32 bell_is_device;       // the command word lives in device memory (the host writes it through the BAR): every workgroup reads it
+                            // there, a fabric read each; 0: it is in host memory, and only workgroup 0 reads it (256 readers across
+                            // PCIe take 47 us to see a word: profiles/r04_micro_doorbell.txt) and republishes it in `relay`
 };
 // A GRANULE is one naturally aligned 8-byte word {32 bits of data, 32-bit tag} written by ONE store and read by ONE load
 // (8-byte device-scope atomics on both sides): whoever reads the tag it is waiting for has the data that was stored with it --
@@ -363,6 +368,31 @@ __device__ __forceinline__ ResCall res_unpack(u64 c) {
   r.leave = (c & RES_LEAVE) != 0ull;
   return r;
 }
+// A call's events into LDS: the workgroup's piece of the call's list (its voices are neighbours, the list is sorted by voice),
+// fetched from pinned host memory by all threads together, 16 bytes each -- a lane that fetched its own events one by one paid
+// three PCIe round trips per event, and 16 384 lanes doing so at once took 100 us over it.  Every wavefront of the workgroup
+// calls it (it ends in a barrier); `count` 0: nothing staged (no events, or more than fit), the list is read where it is.
+struct ResStaged { u32 first, count; };
+__device__ __forceinline__ ResStaged res_stage_events(const Resident& r, const ResCall& call, Event* stage, u32 cap, u32 gv0, u32 gnv, u32 tid, u32 n_threads) {
+  ResStaged st{0u, 0u};
+  if (!call.has_events || cap == 0u) return st;  // uniform
+  const u32* evs = r.ev_start[call.list];
+  st.first = __hip_atomic_load(&evs[gv0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  st.count = __hip_atomic_load(&evs[gv0 + gnv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - st.first;
+  if (st.count > cap) st.count = 0u;
+  const u64* src = reinterpret_cast<const u64*>(r.events[call.list] + st.first);
+  u64* dst = reinterpret_cast<u64*>(stage);
+  for (u32 i = tid; i < st.count; i += n_threads) {
+    const u64 w0 = __hip_atomic_load(&src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const u64 w1 = __hip_atomic_load(&src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    dst[2 * i] = w0;
+    dst[2 * i + 1] = w1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return st;
+}
 // Every wavefront of the workgroup calls this between two calls; `slot` = two words of LDS.  Wavefront 0's lane 0 waits for
 // the command with epoch `expect` (workgroup 0: from the host's word, and passes it on; the others: from the relay), bounded.
 __device__ __forceinline__ ResCall res_wait(const Resident& r, u32 expect, u32* slot, int wave_all, int lane) {
@@ -371,10 +401,15 @@ __device__ __forceinline__ ResCall res_wait(const Resident& r, u32 expect, u32* 
     if (leader && expect == r.first_epoch) __hip_atomic_store(r.host_started, r.first_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
     const u64 patience = leader ? r.idle_ticks : 2ull * r.idle_ticks + 5000000ull;  // (the others outwait workgroup 0: they hear of its leaving through the relay)
+    const bool from_bell = leader || r.bell_is_device != 0u;
     u64 c;
     for (;;) {
-      c = leader ? __hip_atomic_load(r.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c = from_bell ? __hip_atomic_load(r.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((u32)(c & RES_EPOCH_MASK) == expect) break;
+      if (!leader && from_bell) {  // workgroup 0 gave up waiting and said so (the only word of its leaving the others get)
+        const u64 l = __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((l & RES_LEAVE) && (u32)(l & RES_EPOCH_MASK) == expect) { c = l; break; }
+      }
       if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { c = RES_LEAVE | (u64)expect; break; }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -509,6 +544,7 @@ struct ResServerArgs {
   u64* group_rows;       // [tile][plane][8][64][W]
   u64* group_flags;      // [8]
   F* host_out;           // mapped pinned host memory: [channels][block_size]
+  const u64* bell;       // the command word itself when it lives in device memory (Resident::bell_is_device), else null: the relay is read
   u32* host_done;        // mapped pinned: [0] epoch of the last finished call, [1] voices that marked done, [2] voices still running,
                          // [5] first_epoch once the server's first workgroup runs; [8..9] the voice kernel saw the call's command,
                          // [10..11] the root did, [12..13] tile 0's rows (root: nodes) had all arrived, [14..15] the last tile's,
@@ -554,8 +590,12 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
     {
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
       for (;;) {
-        c = __hip_atomic_load(a.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c = a.bell ? __hip_atomic_load(a.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(a.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((u32)(c & RES_EPOCH_MASK) == expect) break;
+        if (a.bell) {  // (the voice kernel's workgroup 0 gave up waiting: it says so in the relay)
+          const u64 l = __hip_atomic_load(a.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((l & RES_LEAVE) && (u32)(l & RES_EPOCH_MASK) == expect) { c = l; break; }
+        }
         if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { c = RES_LEAVE; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -590,7 +630,8 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
         // workgroups added to became hot lines in the memory system.  Each probed line is written by one workgroup and read
         // by one lane.  A row's other frames may land a moment later: the tags decide, below.
         if (writes_host && lane == 0u) __hip_atomic_store(&a.host_done[20 + wv], 0x100u | (t << 16) | (p << 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (diagnostics: where each wavefront is)
-        if (p == 0u) {
+        // (the root has at most 8 granules per frame to read: it reads them all, napping in between, and needs no probe)
+        if (p == 0u && !root) {
           const u64 tc = __builtin_amdgcn_s_memrealtime();
           for (;;) {
             bool there = true;
@@ -622,6 +663,11 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
             all = ok;
           }
           if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { gave_up = true; break; }
+          if (root && __builtin_amdgcn_ballot_w64(!all) != 0ull) __builtin_amdgcn_s_sleep(3);
+        }
+        if (root && p == 0u && !gave_up) {
+          if (tracer && t == 0u) __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 12), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (tracer && t + 1u == n_tiles) __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 14), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (gave_up) break;
         if (!mine) continue;
@@ -813,6 +859,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   struct Lds {
     float sine[ChainT::kUsesSine ? 16384 : 4];
     __attribute__((aligned(16))) F slow[WAVES][kTile][64];  // the sample-by-sample path's samples, [frame][lane]
+    u32 res_slot[4];                                        // a resident launch's command word
   };
   __shared__ Lds lds;
   auto& sine = lds.sine;
@@ -859,12 +906,29 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ChainT chain;
   chain.load(a.state + voice, a.stride);
 
+  // A resident launch (Resident, above): one pass of the loop below per command -- the frame range and the event list are the
+  // call's, the sums leave as granules for the fold server (64-frame tiles from frame_begin on), done frames and flags are
+  // reported per call.  An ordinary launch makes one pass.
+  const bool resident = a.res.bell != nullptr;
+  u32 res_expect = a.res.first_epoch, res_epoch = 0u;
+  u32 fbeg = a.frame_begin, fend = a.frame_end;
+  const u32* evs = a.ev_start;
+  const Event* evl = a.events;
   // the voice's next event waits in registers, whole: one 16-byte read per event (voice_pipe.hpp)
   u32 ev_i = 0, ev_end = 0;
-  if (a.ev_start) { ev_i = a.ev_start[voice]; ev_end = a.ev_start[voice + 1]; }
   Event nxt;
   nxt.frame = 0xFFFFFFFFu; nxt.slot_op = 0u; nxt.bits = 0ull;
-  if (ev_i < ev_end) nxt = a.events[ev_i];
+  auto fetch = [&](u32 i) -> Event {
+    Event e;
+    if (resident) {  // (lists the host has rewritten since the kernel started: past this CU's L1)
+      e.frame = __hip_atomic_load(&evl[i].frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      e.slot_op = __hip_atomic_load(&evl[i].slot_op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      e.bits = __hip_atomic_load(&evl[i].bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      e = evl[i];
+    }
+    return e;
+  };
   u32 base = 0;  // absolute frame of the current block's frame 0
 
   auto apply_events_upto = [&](u32 n_abs) {
@@ -875,7 +939,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
       // (mutable slots are overwritten by their evolved value at the end)
       if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)nxt.bits;
       ++ev_i;
-      if (ev_i < ev_end) nxt = a.events[ev_i];
+      if (ev_i < ev_end) nxt = fetch(ev_i);
       else nxt.frame = 0xFFFFFFFFu;
     }
   };
@@ -886,9 +950,29 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   const u64 st_begin = __builtin_amdgcn_s_memtime();
 #endif
   F pan_l = (F)0, pan_r = (F)0;
+  for (;;) {  // calls
+  if (resident) {
+    const ResCall call = res_wait(a.res, res_expect, lds.res_slot, wave, lane);
+    if (call.leave) break;
+    res_expect = (res_expect + 1u) & (u32)RES_EPOCH_MASK;
+    res_epoch = call.epoch;
+    fbeg = call.frame_begin;
+    fend = call.frame_end;
+    evs = call.has_events ? a.res.ev_start[call.list] : nullptr;
+    evl = a.res.events[call.list];
+    chain.reset_marks();
+  }
+  ev_i = 0; ev_end = 0;
+  nxt.frame = 0xFFFFFFFFu;
+  if (evs) {
+    if (resident) { ev_i = __hip_atomic_load(&evs[voice], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ev_end = __hip_atomic_load(&evs[voice + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    else { ev_i = evs[voice]; ev_end = evs[voice + 1]; }
+  }
+  if (ev_i < ev_end) nxt = fetch(ev_i);
+  base = 0;
   for (u32 b = 0; b < a.n_blocks; ++b, base += a.block_size) {
     ctx.input_block = reinterpret_cast<const F*>(a.input) + (long)b * a.in_channels * a.block_size;
-    chain.begin_block(a.frame_begin, ctx);
+    chain.begin_block(fbeg, ctx);
     // a chain that ends in Pan2 has a left and a right partial row per wavefront: [block][channel][wavefront][frame]
     F* const row0 = a.partials + ((long)b * (ChainT::kPan ? 2 : 1) * n_waves_total + wave_global) * a.block_size;
     F* const row1 = row0 + (long)n_waves_total * a.block_size;
@@ -907,7 +991,14 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
             if ((u32)j < m) a.voices_out[(long)voice * a.block_size + n + j] = x[j];
         }
         const F total = wave_tree_fold<V>(fl, x);
-        if (writer && f < m) row0[n + f] = total;
+        if (writer && f < m) {
+          if (resident) {
+            const u32 rel = n + f - fbeg, tile = rel >> 6;
+            res_put_sample(a.res.rows + (((long)tile * n_waves_total + wave_global) * 64 + (rel & 63u)) * ResWords<F>::value, total, res_tag(res_epoch, tile));
+          } else {
+            row0[n + f] = total;
+          }
+        }
       } else {
         // Pan2 (pan.rs:31-36): each voice's sample times its two gains (the product is rounded), then one sum per channel
         chain.pan_gains(pan_l, pan_r);
@@ -924,7 +1015,15 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
         }
         const F tl = wave_tree_fold<V>(fl, xl);
         const F tr = wave_tree_fold<V>(fl, xr);
-        if (writer && f < m) { row0[n + f] = tl; row1[n + f] = tr; }
+        if (writer && f < m) {
+          if (resident) {
+            const u32 rel = n + f - fbeg, tile = rel >> 6;
+            res_put_sample(a.res.rows + ((((long)tile * 2 + 0) * n_waves_total + wave_global) * 64 + (rel & 63u)) * ResWords<F>::value, tl, res_tag(res_epoch, tile));
+            res_put_sample(a.res.rows + ((((long)tile * 2 + 1) * n_waves_total + wave_global) * 64 + (rel & 63u)) * ResWords<F>::value, tr, res_tag(res_epoch, tile));
+          } else {
+            row0[n + f] = tl; row1[n + f] = tr;
+          }
+        }
       }
 #ifdef KNH_DAG_STAMPS
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -934,8 +1033,8 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
     // visits of KT samples where a whole one fits and no voice of the wavefront has a change inside it, of eight samples
     // where that holds for eight (the rest of a block that is not a multiple of KT long, the neighbourhood of a change),
     // sample by sample (changes applied in front of their frame) for what is left
-    for (u32 n = a.frame_begin; n < a.frame_end;) {
-      const u32 left = a.frame_end - n;
+    for (u32 n = fbeg; n < fend;) {
+      const u32 left = fend - n;
       apply_events_upto(base + n);
       if (left >= (u32)KT && !__builtin_amdgcn_ballot_w64(nxt.frame < base + n + KT)) {
         F x[KT];
@@ -978,13 +1077,33 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
     }
     // changes due exactly at the end of the processed range (precise_timing.rs:85-103 runs the
     // change loop once more before breaking out)
-    apply_events_upto(base + a.frame_end);
+    apply_events_upto(base + fend);
+  }
+  if (!resident) break;
+  {  // the call's done frames and flags (an ordinary launch: below, once)
+    u32 d;
+    if constexpr (SlotCount<S...>::value > 0) {
+      d = 0xFFFFFFFFu;
+      if (a.env_ranks != 0ull) { u32 best_rank = 0u; chain.template collect_done_ranked<0>(a.env_ranks, best_rank, d); }
+      else d = chain.collect_done(0xFFFFFFFFu);
+    } else {
+      d = chain.collect_done(0xFFFFFFFFu);
+    }
+    if (live) a.done_frames[voice] = d;
+    const u32 n_done = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && d != 0xFFFFFFFFu));
+    const u32 n_run = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && !chain.last_env_stopped(false)));
+    if (lane == 0) res_put(a.res.wg_flags + wave_global, n_done | (n_run << 8), res_tag(res_epoch, 255u));
+  }
+  }  // calls
+  if (resident) {
+    if (live) chain.store(a.state + voice, a.stride);
+    return;
   }
 #ifdef KNH_DAG_STAMPS
   if (wave_global == 0u && lane == 0) {
     // cycles per 64 samples of one voice group: [4 .. 11] the stages in chain order, [13] the folds (partial-row stores
     // included), [14] everything
-    const u64 samples = (u64)a.n_blocks * (a.frame_end - a.frame_begin);
+    const u64 samples = (u64)a.n_blocks * (fend - fbeg);
     const u64 d = samples > 0 ? samples : 1;
     for (int k = 0; k < 8; ++k) a.flags[4 + k] = (u32)(st_stage[k] * 64 / d);
     a.flags[12] = 0u;

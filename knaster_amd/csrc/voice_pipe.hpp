@@ -110,6 +110,8 @@ template <typename F> struct PipeShared {
   // mixer wavefront reports per call: [group wavefront][lane] the group's done mark, then [lane] "the voice's last envelope is running"
   u32* res_slot;
   u32* res_marks;
+  Event* ev_stage;       // ... and the LDS its events are staged in, call by call (ev_cap of them; the workgroup has n_threads threads)
+  u32 ev_cap, n_threads;
 };
 
 template <typename F, bool FMA, int T, bool PAN>
@@ -162,14 +164,15 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   u32 ev_i = 0, ev_end = 0;
   Event nxt;
   nxt.frame = 0xFFFFFFFFu; nxt.slot_op = 0u; nxt.bits = 0ull;
-  const bool ev_staged = sh.ev_lds_n != 0u;  // uniform: two plain loads (LDS / global, spelled with their address spaces), never a flat one
+  bool ev_staged = sh.ev_lds_n != 0u;  // uniform: two plain loads (LDS / global, spelled with their address spaces), never a flat one
+  u32 ev_lds_first = sh.ev_lds_first;
   typedef __attribute__((address_space(3))) const Event* lds_ev_t;
   typedef __attribute__((address_space(1))) const Event* glb_ev_t;
   const lds_ev_t ev_l = (lds_ev_t)sh.ev_lds;
   glb_ev_t ev_g = (glb_ev_t)a.events;
   auto fetch = [&](u32 i) -> Event {
     Event e;
-    if (ev_staged) { e.frame = ev_l[i - sh.ev_lds_first].frame; e.slot_op = ev_l[i - sh.ev_lds_first].slot_op; e.bits = ev_l[i - sh.ev_lds_first].bits; }
+    if (ev_staged) { e.frame = ev_l[i - ev_lds_first].frame; e.slot_op = ev_l[i - ev_lds_first].slot_op; e.bits = ev_l[i - ev_lds_first].bits; }
     else if (resident) {
       // a resident launch reads lists the host has rewritten since the kernel started: no kernel boundary has emptied this
       // CU's L1, so the loads say "system scope" themselves
@@ -210,6 +213,9 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
     evs = call.has_events ? a.res.ev_start[call.list] : nullptr;
     ev_g = (glb_ev_t)a.res.events[call.list];
     chain.reset_marks();
+    const ResStaged st = res_stage_events(a.res, call, sh.ev_stage, sh.ev_cap, v0, nv, (u32)(wave_all * 64 + lane), sh.n_threads);
+    ev_staged = st.count != 0u;
+    ev_lds_first = st.first;
   }
   ev_i = 0; ev_end = 0;
   nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu;
@@ -521,6 +527,7 @@ __device__ __forceinline__ void pipe_run_mixer(const PipeShared<F>& sh, const Vo
     res_expect = (res_expect + 1u) & (u32)RES_EPOCH_MASK;
     fbeg = call.frame_begin;
     fend = call.frame_end;
+    (void)res_stage_events(a.res, call, sh.ev_stage, sh.ev_cap, v0, nv, (u32)(wave_all * 64 + lane), sh.n_threads);  // (its share of the copy, and the barrier)
   }
   const u32 n_frames = fend - fbeg;
   const int tpb = (int)((n_frames + T - 1) / T);
@@ -673,6 +680,9 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
   sh.ev_lds_n = ev_count;
   sh.res_slot = lds.res_slot;
   sh.res_marks = lds.res_marks;
+  sh.ev_stage = ev_stage;
+  sh.ev_cap = (u32)(kEvCap > 0 ? kEvCap : 0);
+  sh.n_threads = (u32)(GPW * WAVES * 64);
   const u32 wave_global = blockIdx.x * (u32)GPW + (u32)grp;  // the 64-voice group of the bank
   const u32 v0 = wave_global * 64u;
   const bool dead = GPW > 1 && v0 >= a.n_voices;  // the last workgroup of a bank with an odd number of voice groups

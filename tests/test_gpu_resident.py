@@ -63,7 +63,9 @@ def _render(knh, monkeypatch, name, n, bs, resident, blocks=12, splits=(), pause
     return outs, flags, done, stats
 
 
-CASES = [("C3", 70, 64), ("C3", 2100, 128), ("C3", 16384, 512), ("C4", 200, 96), ("M1", 600, 64), ("C2", 1024, 256), ("P3", 300, 64)]
+# (C1 and the graph voice run on the one-wavefront kernel, the others on pipelines: pre-built in-place and mixer forms, a Fan pipeline, f64, Pan2)
+CASES = [("C3", 70, 64), ("C3", 2100, 128), ("C3", 16384, 512), ("C4", 200, 96), ("M1", 600, 64), ("C2", 1024, 256), ("P3", 300, 64), ("C1", 1, 64),
+         ("C1", 130, 200)]
 
 
 @pytest.mark.parametrize("name,n,bs", CASES)
