@@ -60,6 +60,30 @@ BLOCKS_PER_STEP = BLOCKS_PER_LAUNCH * LAUNCHES_PER_STEP
 PREWARM_MS = 150.0             # untimed launches before the warm-up steps: the shader clock needs a few ms of load to come up
 
 
+def c4_issue(voices_per_gpu, block_size, kernel_us_per_block):
+    """c4_strong.issue: the issue floor of a rank's share of C4 from profiles/r04_c4_floors.json (tools/c4_floors.py)."""
+    out = {"regime": "pipeline: one 64-voice group per CU" if voices_per_gpu <= 16384 else "one whole-chain wavefront per SIMD",
+           "kernel_us_per_block": kernel_us_per_block, "floor_cycles_per_sample": None, "floor_us_per_block": None, "frac_of_floor": None,
+           "note": "strong scaling of this bank: per-GPU time per block is flat from 65 536 down to 16 385 voices per GPU (fewer "
+                   "SIMDs busy, not faster ones), drops once a GPU's share fits the pipeline (16 384 voices or fewer: a 64-voice "
+                   "group per CU) and is flat again below that"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_c4_floors.json")) as f:
+            fl = json.load(f)
+    except (OSError, ValueError):
+        out["source"] = "profiles/r04_c4_floors.json missing: no floor quoted"
+        return out
+    reg = fl["pipeline"] if voices_per_gpu <= 16384 else fl["wide"]
+    cyc = reg["floor_cycles_per_sample"]
+    if voices_per_gpu > 65536:  # more than one wavefront per SIMD: their instructions share the SIMD's issue
+        cyc *= voices_per_gpu / 65536.0
+    out["floor_cycles_per_sample"] = cyc
+    out["floor_us_per_block"] = cyc * block_size / (fl["shader_clock_ghz"] * 1e3)
+    out["frac_of_floor"] = out["floor_us_per_block"] / kernel_us_per_block if kernel_us_per_block > 0 else None
+    out["source"] = "profiles/r04_c4_floors.json <- " + reg["source"]
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,54 +343,77 @@ def measure(env: Env, args, name: str, total_voices: int, bs: int, steps: int, w
     return out
 
 
-def per_block_boundary(name: str, blocks: int = 512):
+def per_block_boundary(name: str, blocks: int = 2048):
     """The call the reference makes: UGen::process_block once per block (Task::run, knaster_graph/src/task.rs:25-31, under
-    AudioProcessor::run_without_inputs, processor.rs:142-179) = one knh_bank_process_block per block, the mixed block in
-    HOST memory when it returns; the block's parameter events in front of it (graph_gen.rs:110-166) as one batched call per
-    trigger.  Driven from Python through ctypes with everything preallocated (tests/cpp/shim_twin_test --bench is the same
-    loop from C++ with one param_apply per event, profiles/).  Returns a dict."""
+    AudioProcessor::run_without_inputs, processor.rs:142-179) = one knh_bank_process_block[_channels] per block, the mixed block
+    in HOST memory when it returns; the block's parameter events in front of it (graph_gen.rs:110-166), a block's triggers as
+    one batched call.  Served by a resident kernel since round 4 (knh_bank_resident_stats).
+    Two drivers: `twin` = tests/cpp/bin/shim_twin_test --bench, the C++ twin of the Rust shim making the shim's exact calls
+    (what the round's targets are quoted on); `python` = this process through ctypes, everything preallocated.  Per-call wall
+    time: median, mean and 99th percentile.  Returns a dict."""
     import ctypes as C
+    import subprocess
 
     import knaster_amd
     from knaster_amd import _lib as L
     from knaster_amd import configs
 
     w = configs.config(name)
+    bs = w.block_size
+    ugens = knaster_amd.chain_ugen_count(w.stages)
+    res = {"config": name, "voices": w.n_voices, "block_size": bs, "blocks": blocks, "unit": "UGen-samples/s"}
+    twin = os.path.join(ROOT, "tests", "cpp", "bin", "shim_twin_test")
+    if os.path.exists(twin):
+        for label, extra_env in (("twin", {}), ("twin_launch_per_call", {"KNH_RESIDENT": "0"})):
+            try:
+                p = subprocess.run([twin, "--bench", name, str(blocks), "batched"], capture_output=True, text=True, timeout=120,
+                                   env=dict(os.environ, **extra_env))
+                d = json.loads(p.stdout.strip().splitlines()[-1])
+                res[label] = {k: d[k] for k in ("us_per_block_p50", "us_per_block_mean", "us_per_block_p99", "us_per_block_min", "ugen_samples_per_s",
+                                                "resident_calls", "device_us_after_the_voice_kernel_saw_the_command", "driver") if k in d}
+            except Exception as e:  # noqa: BLE001 -- a bench must not die of its side leg
+                res[label] = {"error": repr(e)[:200]}
     bank = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE)
     for s, a in w.ctor.items():
         bank.set_ctor_args(s, a)
-    bank.init(configs.SAMPLE_RATE, w.block_size)
-    ugens = knaster_amd.chain_ugen_count(w.stages)
+    bank.init(configs.SAMPLE_RATE, bs)
     v = np.arange(w.n_voices, dtype=np.uint32)
     restart = bank.prepare_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER) if w.restart else None
     release = bank.prepare_many(v, w.release[0], w.release[1], L.VALUE_TRIGGER) if w.release else None
-    out = np.zeros((w.out_channels, w.block_size), dtype=np.float32)
+    out = np.zeros((w.out_channels, bs), dtype=np.float32)
     flags = C.c_uint32(0)
-    fn, h, outp, fp, bs = bank._lib.knh_bank_process_block, bank._h, out.ctypes.data_as(C.c_void_p), C.byref(flags), w.block_size
+    fn, h, outp, fp = bank._lib.knh_bank_process_block, bank._h, out.ctypes.data_as(C.c_void_p), C.byref(flags)
+    us = np.zeros(blocks)
 
-    def run(n, clock0):
+    def run(n, clock0, timed):
         for blk in range(n):
+            t0 = time.perf_counter()
             if restart is not None and blk % 64 == 0:
                 bank.param_apply_prepared(restart, 0)
             if release is not None and blk % 64 == 32:
                 bank.param_apply_prepared(release, 0)
             if fn(h, bs, 0, clock0 + blk * bs, outp, fp) != 0:
                 raise RuntimeError("knh_bank_process_block failed")
+            if timed:
+                us[blk] = (time.perf_counter() - t0) * 1e6
 
-    run(128, 0)  # warm-up (clock, first-use allocations)
-    bank.timing_reset(True)
+    run(128, 0, False)  # warm-up (clock, first-use allocations)
     t0 = time.perf_counter()
-    run(blocks, 128 * bs)
+    run(blocks, 128 * bs, True)
     dt = time.perf_counter() - t0
-    kms, n = bank.timing_read()
-    bank.timing_reset(False)
+    calls, launches = bank.resident_stats()
     finite = bool(np.isfinite(out).all())
     bank.close()
-    us_call, us_kernel = dt * 1e6 / blocks, kms * 1e3 / max(n, 1)
-    return {"config": name, "voices": w.n_voices, "block_size": bs, "blocks": blocks,
-            "per_block_value": float(w.n_voices) * bs * ugens * blocks / dt, "unit": "UGen-samples/s",
-            "us_per_call": us_call, "voice_kernel_us_per_call": us_kernel, "overhead_over_voice_kernel": us_call / us_kernel if us_kernel > 0 else None,
-            "output_finite": finite}
+    res["python"] = {"us_per_block_p50": float(np.median(us)), "us_per_block_mean": float(us.mean()), "us_per_block_p99": float(np.percentile(us, 99)),
+                     "ugen_samples_per_s": float(w.n_voices) * bs * ugens * blocks / dt, "resident_calls": calls, "resident_launches": launches,
+                     "output_finite": finite}
+    best = res["twin"] if "twin" in res and "us_per_block_mean" in res.get("twin", {}) else res["python"]
+    res["per_block_value"] = float(w.n_voices) * bs * ugens / (best["us_per_block_mean"] * 1e-6)
+    res["us_per_call"] = best["us_per_block_mean"]
+    res["us_per_call_p50"] = best["us_per_block_p50"]
+    res["us_per_call_p99"] = best["us_per_block_p99"]
+    res["driver_of_per_block_value"] = "twin" if best is res.get("twin") else "python"
+    return res
 
 
 def config_leg(name: str, launches: int = 16, blocks: int = 32):
@@ -542,12 +589,14 @@ def main():
                         "(profiles/r03_pipe_wave_busy_cycles.txt, _filter_alone.txt)",
             }
         if world == 1 and not args.no_configs:
-            pb = [per_block_boundary("C3"), per_block_boundary("C1", 2048)]
+            pb = [per_block_boundary("C3"), per_block_boundary("C1")]
             if line["host_output"] is not None:
                 line["host_output"]["per_block_value"] = pb[0]["per_block_value"]
                 line["host_output"]["per_block"] = pb
                 line["host_output"]["note"] += ("; per_block_value: ONE knh_bank_process_block call per block (what the reference's Task::run "
-                                                "does, task.rs:25-31), the block in host memory when the call returns -- C3, and C1 beside it")
+                                                "does, task.rs:25-31), the block in host memory when the call returns -- C3, and C1 beside it; "
+                                                "served by a resident kernel (no launch per call); per_block[i].twin = the C++ twin of the Rust shim, "
+                                                ".twin_launch_per_call = the same with KNH_RESIDENT=0, .python = this process's ctypes loop")
             line["configs"] = [config_leg("C1"), config_leg("C2"), config_leg("C5")]
         if secondary is not None:
             s = secondary
@@ -562,24 +611,13 @@ def main():
                 "roofline_achieved_gbs": float(s["bytes_per_voice_block"]) * s["voices_rank0"] * BLOCKS_PER_LAUNCH / (s["kernel_avg_ms"] * 1e-3) / 1e9
                 if s["kernel_avg_ms"] > 0 else 0.0,
                 "ranks_seen_by_rccl": s["ranks_seen"], "output_finite": s["sane"],
-                # What bounds a rank's share (profiles/r03_c4_pipe_wave_busy_cycles.txt, tools/micro/exec_mask_f64.hip): an f64
-                # instruction holds its SIMD for four cycles, so f64 wavefronts are throughput-bound.  Up to 256 voice groups per
-                # GPU (the pipeline, a group per CU) the filter wavefront's 11 f64 instructions per sample of a low-pass filter
-                # (46 cycles; 15 = 63 for the other types) plus its tile's way through LDS (30) are the floor of a block's time
-                # WHATEVER the number of voices -- a GPU with 8 192 voices takes as long per block as one with 16 384; beyond
-                # that (whole-chain wavefronts, four voice groups per workgroup = one wavefront per SIMD up to 65 536 voices) it
-                # is the f64 work of all stages: 23.6 VALU instructions per voice-sample (SQ counters), ~15 of them f64 at four
-                # SIMD cycles each.  A second wavefront per SIMD buys almost nothing there (eight groups per workgroup at twice
-                # the voices: 168 cycles per wavefront-sample against 178): the SIMD is saturated by one.
-                "issue": {
-                    "regime": "pipeline: one 64-voice group per CU" if s["voices_rank0"] <= 16384 else "one whole-chain wavefront per SIMD",
-                    "floor_cycles_per_sample": 76.0 if s["voices_rank0"] <= 16384 else 90.0,
-                    "floor_us_per_block": (76.0 if s["voices_rank0"] <= 16384 else 90.0 * max(1.0, s["voices_rank0"] / 65536.0)) * bs / (SHADER_CLOCK_GHZ * 1e3),
-                    "kernel_us_per_block": s["kernel_avg_ms"] * 1e3 / BLOCKS_PER_LAUNCH,
-                    "note": "strong scaling of this bank: per-GPU time per block is flat from 65 536 down to 16 385 voices per GPU (fewer "
-                            "SIMDs busy, not faster ones), drops once a GPU's share fits the pipeline (16 384 voices or fewer: a 64-voice "
-                            "group per CU) and is flat again below that",
-                },
+                # What bounds a rank's share: an f64 wavefront alone on its SIMD issues an instruction every ~4.4 cycles.  Up to 256
+                # voice groups per GPU (the pipeline, a group per CU) the filter wavefront -- its arithmetic plus its tile's way
+                # through LDS -- sets a block's time WHATEVER the number of voices; beyond that (whole-chain wavefronts, one per
+                # SIMD up to 65 536 voices) it is every stage's instructions.  Both floors come from measurements committed under
+                # profiles/ (tools/c4_floors.py -> profiles/r04_c4_floors.json: per-wavefront stamps of the pipeline, SQ counters
+                # of the whole-chain kernel), not from literals here.
+                "issue": c4_issue(s["voices_rank0"], bs, s["kernel_avg_ms"] * 1e3 / BLOCKS_PER_LAUNCH),
                 "per_rank": {"kernel_ms_per_launch": [r[0] for r in s["per_rank"]], "reduce_ms_per_launch": [r[1] for r in s["per_rank"]],
                              "voices": [r[2] for r in s["per_rank"]]},
             }

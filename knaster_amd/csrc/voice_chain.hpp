@@ -854,7 +854,12 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   // wavefronts per workgroup have 128 registers each: 16 samples in f32, 8 in f64
   // (a voice of more than sixteen stages -- a graph, as a rule -- keeps the eight-sample visits: every stage's tile code is
   // unrolled per visit length, and hiprtc needs minutes for a 200-stage voice at 32 + 8 samples where it needs seconds at 8)
-  constexpr int KT = sizeof...(S) > 16 ? kTile : (WAVES >= 16 ? (sizeof(F) == 4 ? 16 : 8) : 32);
+  // Up to four wavefronts per workgroup (a SIMD's registers to themselves) visit 64 samples at a time in f32: 65 536 voices
+  // 26.1 -> 22.7 us per block (profiles/r04_wide_visit_length.txt); f64 gains nothing from it (36.6 -> 36.4) and keeps 32.
+#ifndef KNH_WIDE_KT8
+#define KNH_WIDE_KT8 32  // (A/B: eight wavefronts per workgroup, two per SIMD)
+#endif
+  constexpr int KT = sizeof...(S) > 16 ? kTile : (WAVES >= 16 ? (sizeof(F) == 4 ? 16 : 8) : (WAVES <= 4 ? (sizeof(F) == 4 ? 64 : 32) : (sizeof(F) == 4 ? KNH_WIDE_KT8 : 32)));
   // (one LDS object with the table first: the table at LDS address 0, a table read's address is the masked phase itself)
   struct Lds {
     float sine[ChainT::kUsesSine ? 16384 : 4];
