@@ -28,6 +28,7 @@ struct Chain<F, FMA, BASE> {
   static constexpr bool kPan = false;
   static constexpr u64 kParamBits = 0ull, kNopOkBits = 0ull;
   static constexpr bool kBinds = false;
+  static constexpr bool kUsesRing = false;
   template <int T> __device__ __forceinline__ void tick_tile_sw(const Chain&, u32, u64, F (&)[T], const Ctx&, u32) {}
   __device__ __forceinline__ void pan_gains(F&, F&) const {}
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
@@ -56,6 +57,7 @@ struct Chain<F, FMA, BASE, S0, Rest...> {
   static constexpr u64 kParamBits = (BASE + S0::kSlots <= 64 ? (u64)S0::kParamMask << (BASE < 64 ? BASE : 0) : 0ull) | RestT::kParamBits;
   static constexpr u64 kNopOkBits = ((S0::kParamMask != 0u || !S0::kHasSeg) && BASE < 64 ? (u64)1 << (BASE < 64 ? BASE : 0) : 0ull) | RestT::kNopOkBits;
   static constexpr bool kBinds = S0::kNeedsBind || RestT::kBinds;  // a stage with memory behind it (delay ring, segment table, buffer)
+  static constexpr bool kUsesRing = S0::kUsesRing || RestT::kUsesRing;
   typename S0::template Regs<F> r;
   // The frame this stage last passed to mark_done (UGenFlags::mark_done, ugen.rs:199-202), 0xFFFFFFFF: never.  The
   // reference hands one UGenFlags to every task of a block in node order (graph_gen.rs:196-200), so the mark a voice
@@ -182,6 +184,7 @@ struct DagChain<F, FMA, BASE, R, LAST, Slots<R2>> {
   static constexpr bool kUsesSine = false;
   static constexpr bool kPan = false;
   static constexpr int kOut = LAST;
+  static constexpr bool kUsesRing = false;
   __device__ __forceinline__ void pan_gains(F&, F&) const {}
   template <typename W> __device__ __forceinline__ void load(const W*, long) {}
   template <typename W> __device__ __forceinline__ void store(W*, long) const {}
@@ -206,6 +209,7 @@ struct DagChain<F, FMA, BASE, R, LAST, N0, Rest...> {
   static constexpr bool kUsesSine = S0::kUsesSine || RestT::kUsesSine;
   static constexpr bool kPan = IsPan<S0>::value || RestT::kPan;
   static constexpr int kOut = RestT::kOut;
+  static constexpr bool kUsesRing = S0::kUsesRing || RestT::kUsesRing;
   typename S0::template Regs<F> r;
   u32 mark = 0xFFFFFFFFu;
   RestT rest;
@@ -857,13 +861,18 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   // Up to four wavefronts per workgroup (a SIMD's registers to themselves) visit 64 samples at a time in f32: 65 536 voices
   // 26.1 -> 22.7 us per block (profiles/r04_wide_visit_length.txt); f64 gains nothing from it (36.6 -> 36.4) and keeps 32.
 #ifndef KNH_WIDE_KT8
-#define KNH_WIDE_KT8 32  // (A/B: eight wavefronts per workgroup, two per SIMD)
+#define KNH_WIDE_KT8 64  // (eight wavefronts per workgroup, two per SIMD: 262 144 voices 76.2 -> 73.9 us per block; 32 for an A/B build)
 #endif
-  constexpr int KT = sizeof...(S) > 16 ? kTile : (WAVES >= 16 ? (sizeof(F) == 4 ? 16 : 8) : (WAVES <= 4 ? (sizeof(F) == 4 ? 64 : 32) : (sizeof(F) == 4 ? KNH_WIDE_KT8 : 32)));
+  constexpr int KT = sizeof...(S) > 16 ? kTile : (WAVES >= 16 ? (sizeof(F) == 4 ? 16 : 8) : (WAVES <= 4 ? (sizeof(F) == 4 ? 64 : 32) : (sizeof(F) == 4 && !ChainT::kUsesRing ? KNH_WIDE_KT8 : 32)));  // (a delay's tile, its lines and the lines read ahead: 64 samples of each spill at 256 registers)
   // (one LDS object with the table first: the table at LDS address 0, a table read's address is the masked phase itself)
+  constexpr bool kRingTile = ChainT::kUsesRing && WAVES <= 8 && KT * (int)sizeof(F) >= RingLines<F>::kLine;  // (sixteen tiles do not fit beside the table)
+  constexpr int kSlowBytes = kTile * 64 * (int)sizeof(F);
+  constexpr int kScratch = kRingTile && RingLines<F>::kTileBytes > kSlowBytes ? RingLines<F>::kTileBytes : kSlowBytes;
   struct Lds {
     float sine[ChainT::kUsesSine ? 16384 : 4];
-    __attribute__((aligned(16))) F slow[WAVES][kTile][64];  // the sample-by-sample path's samples, [frame][lane]
+    // per wavefront: the sample-by-sample path's samples, [frame][lane] -- and, in the same bytes, the tile through which a
+    // delay moves its ring as whole lines (RingLines; visits of a line's samples or more, so never while the other is in use)
+    __attribute__((aligned(16))) char scratch[WAVES][kScratch];
     u32 res_slot[4];                                        // a resident launch's command word
   };
   __shared__ Lds lds;
@@ -896,6 +905,8 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ctx.input_block = a.input;
   ctx.in_stride = a.block_size;
   ctx.sample_rate = a.sample_rate;
+  ctx.ring_tile = nullptr;
+  if constexpr (kRingTile) ctx.ring_tile = (__attribute__((address_space(3))) char*)lds.scratch[wave];
 
   const u32 wave_global = blockIdx.x * WAVES + wave;
   const u32 v0 = wave_global * 64u;
@@ -1066,7 +1077,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
         // (through eight rows of LDS, written with a run-time index: the register tile is never indexed dynamically, which
         // would put it -- the fast path's too -- in scratch memory; same-wave LDS traffic, program order is enough)
         const u32 m = left < (u32)kTile ? left : (u32)kTile;
-        F(*rows)[64] = lds.slow[wave];
+        F(*rows)[64] = reinterpret_cast<F(*)[64]>(lds.scratch[wave]);
         for (u32 j = 0; j < m; ++j) {
           apply_events_upto(base + n + j);
           rows[j][lane] = chain.tick((F)0, ctx, n + j);

@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
   const int n_steps = n_tiles + 3;
   const u32 n_waves_total = (a.n_voices + 63u) / 64u;
   Ctx ctx;
+  ctx.ring_tile = nullptr;  // (RingLines: the whole-chain kernels)
   ctx.sine = sine;
   ctx.f2pi = a.f2pi;
   ctx.seg_table = a.seg_table;

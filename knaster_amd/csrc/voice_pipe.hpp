@@ -143,6 +143,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   constexpr u32 SLOT_LO = (u32)BASE, SLOT_HI = (u32)(BASE + GroupInfo<G>::slots);
 
   Ctx ctx;
+  ctx.ring_tile = nullptr;  // (RingLines: the whole-chain kernels)
   ctx.sine = sh.sine;
   ctx.f2pi = a.f2pi;
   ctx.seg_table = a.seg_table;

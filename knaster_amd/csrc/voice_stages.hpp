@@ -75,6 +75,7 @@ struct StageDefaults {
   // >= 0: the node is pushed as `.ar_params()` and this float parameter is linked to a second signal of the voice
   // (WrArParams, audio_rate.rs:11-85: every sample `param_apply(p, buf[i])`, then one sample of the node): ArP<S, P> below
   static constexpr int kArParam = -1;
+  static constexpr bool kUsesRing = false;  // a delay: the stage moves tiles of a per-voice ring in HBM (RingLines)
 };
 // A stage whose parameter P is driven at audio rate by another signal of the voice (graph-shaped voices: DagChain reads the
 // driver through the stage's second operand and calls S::ar_set<F, P> in front of every sample).  What the setter of each
@@ -107,6 +108,7 @@ struct Ctx {
   const void* input_block;  // the bank node's input channels for the block being processed: [in_channels][in_stride] of F
   u32 in_stride;            // = block_size
   u32 sample_rate;          // ctx.sample_rate(), for setters that run on the device (audio-rate parameters)
+  __attribute__((address_space(3))) char* ring_tile;  // this wavefront's RingLines tile in LDS (whole-chain kernels of up to eight wavefronts), or null
 };
 
 // ---------------------------------------------------------------------------
@@ -1687,6 +1689,134 @@ struct MulSegEnv : StageDefaults {
   }
 };
 
+// Ring traffic as whole lines (round 4).  A voice's ring is contiguous, so the T samples of a tile are T * sizeof(F)
+// contiguous bytes of it -- but with a voice per lane, a 16-byte access of the wavefront touches 64 different lines and
+// uses 16 bytes of each: the memory system sees eight requests per line where one would do, and the delay chains ran at
+// 2.0-2.1 TB/s of ring traffic whatever the size of the bank (tools/micro/ring_lines.hip: the same pattern without any
+// arithmetic 3.2 TB/s, whole lines 4.9-5.5).  Here the wavefront moves a tile as lines: in instruction i, i = 0..7, lane l
+// moves chunk (l & 7) -- 16 bytes -- of the voice in lane slot 8 i + (l >> 3): eight lanes to one voice's 128 contiguous
+// bytes.  Between the two layouts (a voice's samples in its own lane's registers / a line across eight lanes) sits a tile
+// in LDS private to the wavefront: 64 rows of 128 + 16 bytes (144 = 9 x 16: 16-byte accesses of 64 lanes at that stride
+// spread evenly over the banks); the 16 bytes behind a row hold the voice's ring row, its two positions and the ring's
+// length for the lanes that move its lines.  Longer tiles go 128 bytes per voice at a time.  A tile may cross the end of its
+// ring: every chunk wraps by itself, and the one chunk of a lap that straddles the end goes sample
+// by sample (rounds 1-3 sent the whole wavefront to the sample-by-sample path whenever any of its 64 voices crossed the
+// end of its ring inside the tile: with 64 different delays that was every third 64-sample tile of the D3 bank).
+// LDS executes a wavefront's instructions in order, so the tile needs no waits between its phases -- only the compiler
+// must be kept from reordering them.
+template <typename F>
+struct RingLines {
+  static constexpr int kLine = 128;
+  static constexpr int TS = kLine / (int)sizeof(F);  // samples of a voice per line
+  static constexpr int kRow = kLine + 16;
+  static constexpr int kTileBytes = 64 * kRow;        // 9 216 per wavefront
+  static constexpr int VW = 16 / (int)sizeof(F);
+  typedef typename WordOf<F>::type W;
+  typedef u32 U4 __attribute__((ext_vector_type(4)));
+  typedef u32 U4u __attribute__((ext_vector_type(4), aligned(4)));  // (a ring position is sample-aligned, no more)
+  typedef __attribute__((address_space(3))) char* tile_t;
+  typedef __attribute__((address_space(3))) U4* lds_u4;
+  typedef __attribute__((address_space(1))) U4u* glb_u4;
+  typedef __attribute__((address_space(1))) W* glb_w;
+  struct Lines { U4 v[8]; };
+  struct Where { u64 ring; u32 pos, len; bool live; };
+  static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+  // what the lanes that move this lane's voice's lines need: its ring's row (live = false: no voice here), its positions
+  // and the ring's length, in samples
+  static __device__ __forceinline__ void put_header(tile_t tile, int lane, bool live, u32 row, u32 wp, u32 rp, u32 len) {
+    U4 h;
+    h[0] = live ? row : 0xFFFFFFFFu; h[1] = wp; h[2] = rp; h[3] = len;
+    *reinterpret_cast<lds_u4>(tile + lane * kRow + kLine) = h;
+    fence();
+  }
+  // chunk (lane & 7) of instruction i: whose ring, and where in it (STORE: from the write position, else the read position)
+  template <bool STORE>
+  static __device__ __forceinline__ Where where(tile_t tile, int lane, int i, u32 sample_offset, const Ctx& c) {
+    const U4 h = *reinterpret_cast<lds_u4>(tile + (8 * i + (lane >> 3)) * kRow + kLine);
+    const u32 row = h[0], wp = h[1], rp = h[2], len = h[3];
+    Where w;
+    w.live = row != 0xFFFFFFFFu;
+    w.ring = reinterpret_cast<u64>(c.delay_ring) + (u64)row * ((u64)c.delay_stride * sizeof(F));
+    const u32 pos = (STORE ? wp : rp) + sample_offset + (u32)((lane & 7) * VW);  // < 2 len: the callers' conditions
+    w.pos = pos - len < pos ? pos - len : pos;                                     // (pos - len wraps to a huge number below len)
+    w.len = len;
+    return w;
+  }
+  static __device__ __forceinline__ u32 wrapped(u32 pos, u32 len) { return pos - len < pos ? pos - len : pos; }
+  // the lines at read position + sample_offset, requested (the loads are in flight when this returns)
+  static __device__ __forceinline__ void load(tile_t tile, int lane, u32 sample_offset, const Ctx& c, Lines& l) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const Where w = where<false>(tile, lane, i, sample_offset, c);
+      U4 v = {0u, 0u, 0u, 0u};
+      if (w.live) {
+        if (w.pos + (u32)VW <= w.len) {
+          v = *reinterpret_cast<glb_u4>(w.ring + (u64)w.pos * sizeof(F));
+        } else {  // the chunk that straddles the end of the ring: sample by sample
+#pragma unroll
+          for (int e = 0; e < VW; ++e) {
+            const W q = reinterpret_cast<glb_w>(w.ring)[wrapped(w.pos + (u32)e, w.len)];
+            if constexpr (sizeof(F) == 4) v[e] = (u32)q;
+            else { v[2 * e] = (u32)q; v[2 * e + 1] = (u32)((u64)q >> 32); }
+          }
+        }
+      }
+      l.v[i] = v;
+    }
+  }
+  // lines -> this lane's voice's TS samples
+  static __device__ __forceinline__ void to_samples(tile_t tile, int lane, const Lines& l, F* y) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<lds_u4>(tile + (8 * i + (lane >> 3)) * kRow + (lane & 7) * 16) = l.v[i];
+    fence();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const U4 q = *reinterpret_cast<lds_u4>(tile + lane * kRow + j * 16);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        // (a copy of the element first: __builtin_bit_cast of a vector element reads element 0, voice_chain.hpp res_get)
+        if constexpr (sizeof(F) == 4) { const u32 e = q[k]; y[j * VW + k] = __builtin_bit_cast(F, e); }
+        else { const u32 lo = q[2 * k], hi = q[2 * k + 1]; const u64 e = (u64)lo | ((u64)hi << 32); y[j * VW + k] = __builtin_bit_cast(F, e); }
+      }
+    }
+    fence();
+  }
+  // this lane's voice's TS samples -> lines, stored at write position + sample_offset
+  static __device__ __forceinline__ void store(tile_t tile, int lane, const F* x, u32 sample_offset, const Ctx& c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      U4 q;
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        const F e = x[j * VW + k];
+        if constexpr (sizeof(F) == 4) q[k] = __builtin_bit_cast(u32, e);
+        else { const u64 b = __builtin_bit_cast(u64, e); q[2 * k] = (u32)b; q[2 * k + 1] = (u32)(b >> 32); }
+      }
+      *reinterpret_cast<lds_u4>(tile + lane * kRow + j * 16) = q;
+    }
+    fence();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const U4 v = *reinterpret_cast<lds_u4>(tile + (8 * i + (lane >> 3)) * kRow + (lane & 7) * 16);
+      const Where w = where<true>(tile, lane, i, sample_offset, c);
+      if (w.live) {
+        if (w.pos + (u32)VW <= w.len) {
+          *reinterpret_cast<glb_u4>(w.ring + (u64)w.pos * sizeof(F)) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) {
+            W q;
+            if constexpr (sizeof(F) == 4) { const u32 t = v[e]; q = (W)t; }
+            else { const u32 lo = v[2 * e], hi = v[2 * e + 1]; q = (W)((u64)lo | ((u64)hi << 32)); }
+            reinterpret_cast<glb_w>(w.ring)[wrapped(w.pos + (u32)e, w.len)] = q;
+          }
+        }
+      }
+    }
+    fence();
+  }
+};
+
 // SampleDelay -- delay.rs:14-50.  process: buffer[wp] = x; out = buffer[(wp + len - delay) % len]; wp = (wp + 1) % len.
 // Each voice's ring is a contiguous run of HBM ([voice][delay_stride]); slots: 0 write_position, 1 off = len - delay_samples
 // (0..len), 2 len, 3 the voice's ring row.  A tile whose reads cannot meet its own writes (delay >= T) and that does not
@@ -1699,12 +1829,15 @@ struct SampleDelay : StageDefaults {
   static constexpr bool kIsEnv = false;
   static constexpr bool kNeedsBind = true;
   static constexpr bool kHasSeg = false;
+  static constexpr bool kUsesRing = true;
   static constexpr int kPrefetch = 32;  // largest tile that is read one tile ahead
+  static constexpr int kLinesAhead = 2; // ... as whole lines (RingLines): 256 bytes per voice
   template <typename F> struct Regs {
     u32 wp, off, len, row;
     F* ring;
-    u32 pre_pos;       // ring position the tile in `pre` was read from, 0xFFFFFFFF: none
+    u32 pre_pos;       // ring position the tile in `pre` / `lines` was read from, 0xFFFFFFFF: none
     F pre[kPrefetch];  // the next tile's samples, requested while this tile is being processed
+    typename RingLines<F>::Lines lines[kLinesAhead];  // the same where the wavefront moves its rings as lines: this lane's share of them
   };
   template <typename F, typename W>
   static __device__ __forceinline__ void load(Regs<F>& r, const W* s, long st) {
@@ -1737,8 +1870,61 @@ struct SampleDelay : StageDefaults {
     typedef F Vec __attribute__((ext_vector_type(VW), aligned(sizeof(F))));
     u32 rp = r.wp + r.off;
     if (rp >= r.len) rp -= r.len;
-    // delay >= T  <=>  off <= len - T;  neither the T stores nor the T loads may cross the end of the ring
     const bool dead = r.len == 0u;  // a lane past the last voice: takes part in nothing
+    {
+      typedef RingLines<F> RL;
+      if constexpr (T % RL::TS == 0 && T / RL::TS <= kLinesAhead) {
+        if (c.ring_tile != nullptr) {  // (known per kernel: the other vector path is not in its code then)
+          // The tile as whole lines (RingLines): wherever every voice of the wavefront has a delay of a tile or more (the
+          // reads cannot meet this tile's writes; off == 0 is a delay of 0 or of the whole ring: tick() forwards that
+          // sample) -- either pointer may cross the end of its ring.  The next tile's lines are requested before this
+          // tile's are stored and wait in registers through everything the other stages do in between, if no voice's delay
+          // is shorter than two tiles (those loads cannot meet this tile's stores then).
+          const bool lines_ok = dead || (r.len >= (u32)T && r.off != 0u && r.off <= r.len - (u32)T);
+          if (__builtin_amdgcn_ballot_w64(!lines_ok) == 0) {
+            constexpr int NS = T / RL::TS;
+            const int lane = (int)(threadIdx.x & 63u);
+            u32 np = rp + (u32)T;
+            if (np >= r.len) np -= r.len;
+            const bool have = !dead && r.pre_pos == rp;
+            const bool ahead = !dead && r.len >= 2u * (u32)T && r.off <= r.len - 2u * (u32)T;
+            const bool all_have = __builtin_amdgcn_ballot_w64(!(have || dead)) == 0;
+            const bool all_ahead = __builtin_amdgcn_ballot_w64(!(ahead || dead)) == 0;
+            RL::put_header(c.ring_tile, lane, !dead, r.row, r.wp, rp, r.len);
+            F y[T];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              if (all_have) {
+                RL::to_samples(c.ring_tile, lane, r.lines[s], &y[s * RL::TS]);
+              } else {
+                typename RL::Lines l;
+                RL::load(c.ring_tile, lane, (u32)(s * RL::TS), c, l);
+                RL::to_samples(c.ring_tile, lane, l, &y[s * RL::TS]);
+              }
+            }
+            if (all_ahead) {
+#pragma unroll
+              for (int s = 0; s < NS; ++s) RL::load(c.ring_tile, lane, (u32)(T + s * RL::TS), c, r.lines[s]);
+            }
+            r.pre_pos = all_ahead && !dead ? np : 0xFFFFFFFFu;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) RL::store(c.ring_tile, lane, &x[s * RL::TS], (u32)(s * RL::TS), c);
+            if (!dead) {
+#pragma unroll
+              for (int j = 0; j < T; ++j) x[j] = y[j];
+              r.wp += (u32)T;
+              if (r.wp >= r.len) r.wp -= r.len;
+            }
+            return;
+          }
+          r.pre_pos = 0xFFFFFFFFu;
+#pragma unroll
+          for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+          return;
+        }
+      }
+    }
+    // delay >= T  <=>  off <= len - T;  neither the T stores nor the T loads may cross the end of the ring
     // (off == 0 is a delay of 0 or of the whole ring: the sample just stored comes straight back -- tick() forwards it)
     const bool vec_ok = dead || (r.len >= (u32)T && r.off != 0u && r.off <= r.len - (u32)T && r.wp <= r.len - (u32)T && rp <= r.len - (u32)T);
     if (__builtin_amdgcn_ballot_w64(!vec_ok) == 0) {
@@ -1781,6 +1967,8 @@ struct SampleDelay : StageDefaults {
             }
           }
           r.pre_pos = ahead ? np : 0xFFFFFFFFu;
+        } else {
+          r.pre_pos = 0xFFFFFFFFu;
         }
         Vec* dst = reinterpret_cast<Vec*>(r.ring + r.wp);
 #pragma unroll
@@ -1819,6 +2007,7 @@ struct SampleDelay : StageDefaults {
 template <bool FB>
 struct AllpassDelayT : StageDefaults {
   static constexpr int kSlots = FB ? 8 : 7;
+  static constexpr bool kUsesRing = true;
   static constexpr u32 kMutableMask = 0b1100011u;
   static constexpr bool kUsesSine = false;
   static constexpr bool kIsEnv = false;
@@ -1865,6 +2054,49 @@ struct AllpassDelayT : StageDefaults {
     const bool dead = r.len == 0u;
     // a read meets a store of the same tile only when the write pointer is 1 .. T-1 frames ahead of the read pointer
     const u32 ahead = r.wp >= r.rp ? r.wp - r.rp : r.wp + r.len - r.rp;
+    {
+      typedef RingLines<F> RL;
+      if constexpr (T % RL::TS == 0) {
+        if (c.ring_tile != nullptr) {  // the tile as whole lines (RingLines, above): either pointer may cross the end of the ring
+          const bool lines_ok = dead || (r.len >= (u32)T && (ahead == 0u || ahead >= (u32)T));
+          if (__builtin_amdgcn_ballot_w64(!lines_ok) == 0) {
+            constexpr int NS = T / RL::TS;
+            const int lane = (int)(threadIdx.x & 63u);
+            RL::put_header(c.ring_tile, lane, !dead, r.row, r.wp, r.rp, r.len);
+            F y[T];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              typename RL::Lines l;
+              RL::load(c.ring_tile, lane, (u32)(s * RL::TS), c, l);
+              RL::to_samples(c.ring_tile, lane, l, &y[s * RL::TS]);
+            }
+            F wr[T];  // what goes into the ring: the input, or the input plus the fed-back delayed signal
+#pragma unroll
+            for (int j = 0; j < T; ++j) wr[j] = x[j];
+            if (!dead) {
+#pragma unroll
+              for (int j = 0; j < T; ++j) {
+                const F d = allpass<F>(r, y[j]);
+                wr[j] = FB ? d * r.fb + x[j] : x[j];
+                x[j] = FB ? d - r.fb * wr[j] : d;
+              }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) RL::store(c.ring_tile, lane, &wr[s * RL::TS], (u32)(s * RL::TS), c);
+            if (!dead) {
+              r.rp += (u32)T;
+              if (r.rp >= r.len) r.rp -= r.len;
+              r.wp += (u32)T;
+              if (r.wp >= r.len) r.wp -= r.len;
+            }
+            return;
+          }
+#pragma unroll
+          for (int j = 0; j < T; ++j) x[j] = tick<F, FMA>(r, x[j], c, frame0 + j, done_frame);
+          return;
+        }
+      }
+    }
     const bool vec_ok = dead || (r.len >= (u32)T && (ahead == 0u || ahead >= (u32)T) && r.wp <= r.len - (u32)T && r.rp <= r.len - (u32)T);
     if (__builtin_amdgcn_ballot_w64(!vec_ok) == 0) {
       if (!dead) {

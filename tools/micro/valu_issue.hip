@@ -60,6 +60,12 @@ __global__ void k(float* out, int iters) {
     } else if (MODE == 13) {  // v_add_f32 (VOP2) independent
 #pragma unroll
       for (int u = 0; u < 16; ++u) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[u & 7]) : "v"(b));
+    } else if (MODE == 14) {  // packed fma, independent
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[u & 7]) : "v"(pb));
+    } else if (MODE == 15) {  // packed add, independent
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[u & 7]) : "v"(pb));
     } else if (MODE == 7) {  // f64 mul dependent
       double d = a[0];
 #pragma unroll
@@ -97,7 +103,7 @@ void run(const char* name, float* d, int waves) {
 int main() {
   float* d;
   (void)hipMalloc(&d, 256 * 1024 * 4);
-  for (int waves : {1, 8}) {
+  for (int waves : {1, 4, 8, 16}) {
     run<0>("v_mul_f32 dependent", d, waves);
     run<5>("v_mul_f32 two chains", d, waves);
     run<1>("v_mul_f32 eight chains", d, waves);
@@ -107,6 +113,8 @@ int main() {
     run<2>("v_pk_mul_f32 dependent", d, waves);
     run<6>("v_pk_mul_f32 two chains", d, waves);
     run<3>("v_pk_mul_f32 eight chains", d, waves);
+    run<15>("v_pk_add_f32 eight chains", d, waves);
+    run<14>("v_pk_fma_f32 eight chains", d, waves);
     run<9>("v_mul_f32 eight chains + s_nop 0", d, waves);
     run<10>("v_pk_mul_f32 dependent + s_nop 0", d, waves);
     run<11>("8-instr pk/scalar mix (per instr)", d, waves);
