@@ -416,14 +416,14 @@ def per_block_boundary(name: str, blocks: int = 2048):
     return res
 
 
-def config_leg(name: str, launches: int = 16, blocks: int = 32):
+def config_leg(name: str, launches: int = 16, blocks: int = 32, n_voices: int | None = None):
     """A short leg of another BASELINE.json configuration at its full size: `launches` launches of `blocks` blocks, outputs
     left in HBM; wall and kernel-only.  UGens per voice as SURVEY.md 8(d) counts them."""
     import knaster_amd
     from knaster_amd import _lib as L
     from knaster_amd import configs
 
-    w = configs.config(name)
+    w = configs.config(name, n_voices=n_voices)
     b = knaster_amd.VoiceBank(w.stages, w.n_voices, w.sample_type, w.out_channels, L.MIX_TREE)
     for s, a in w.ctor.items():
         b.set_ctor_args(s, a)
@@ -431,6 +431,8 @@ def config_leg(name: str, launches: int = 16, blocks: int = 32):
     v = np.arange(w.n_voices, dtype=np.uint32)
     if w.restart:
         b.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+    if w.delay_times is not None:  # D3: every voice its own delay
+        b.param_apply_many(v, 3, 0, L.VALUE_FLOAT, w.delay_times)
     # the application's own work of deciding what changes when is not the engine's: C5's event arrays are made up front
     c5 = {}
     if name == "C5":
@@ -457,9 +459,12 @@ def config_leg(name: str, launches: int = 16, blocks: int = 32):
     b.synchronize()
     dt = time.perf_counter() - t0
     kms, n = b.timing_read()
-    ugens = {"C1": 3, "C2": 2, "C3": 4, "C4": 4, "C5": 3}[name]
+    ugens = {"C1": 3, "C2": 2, "C3": 4, "C4": 4, "C5": 3, "D3": 5}[name]
     work = float(w.n_voices) * w.block_size * ugens * blocks * launches
     rd, wr = b.algorithmic_bytes_per_voice_block()
+    if w.delay_times is not None:  # the ring: one sample read and one written per frame
+        rd += (8 if w.sample_type else 4) * w.block_size
+        wr += (8 if w.sample_type else 4) * w.block_size
     b.close()
     return {"config": name, "workload": w.description, "voices": w.n_voices, "block_size": w.block_size, "dtype": "f64" if w.sample_type else "f32",
             "ugens_per_voice": ugens, "blocks_per_launch": blocks, "launches": launches, "value": work / dt, "unit": "UGen-samples/s",
@@ -598,6 +603,22 @@ def main():
                                                 "served by a resident kernel (no launch per call); per_block[i].twin = the C++ twin of the Rust shim, "
                                                 ".twin_launch_per_call = the same with KNH_RESIDENT=0, .python = this process's ctypes loop")
             line["configs"] = [config_leg("C1"), config_leg("C2"), config_leg("C5")]
+            # Banks beyond the headline size (not BASELINE.json configs: the same C3 voice, more of them; D3 = C3 with a
+            # SampleDelay of 0.25 s per voice behind the filter, the path's HBM-bound regime): whole-chain wavefronts, four or
+            # eight to a workgroup.  valu = the headline's measure (OPS_PER_UGEN_SAMPLE per UGen-sample against the non-fused
+            # FP32 peak); hbm = algorithmic bytes (state + ring) against 8 TB/s.
+            large = []
+            for nm, nv, ln in (("C3", 65536, 8), ("C3", 262144, 4), ("D3", 65536, 6), ("D3", 262144, 4)):
+                try:
+                    leg = config_leg(nm, launches=ln, blocks=32, n_voices=nv)
+                except Exception as e:  # (a box without the memory for 12 GB of rings)
+                    large.append({"config": nm, "voices": nv, "error": str(e)[:200]})
+                    continue
+                ko = leg["kernel_only_value"] or 0.0
+                leg["valu"] = {"achieved_ops_per_s": ko * OPS_PER_UGEN_SAMPLE, "peak_ops_per_s": VALU_PEAK_OPS, "frac": ko * OPS_PER_UGEN_SAMPLE / VALU_PEAK_OPS}
+                leg["hbm"] = {"achieved_gbs": leg["roofline_achieved_gbs"], "peak_gbs": HBM_PEAK_GBS, "frac": (leg["roofline_achieved_gbs"] or 0.0) / HBM_PEAK_GBS}
+                large.append(leg)
+            line["large_banks"] = large
         if secondary is not None:
             s = secondary
             s_blocks = s["steps"] * BLOCKS_PER_STEP

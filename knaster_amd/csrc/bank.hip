@@ -93,9 +93,12 @@ knh_bank* make_bank(const knh_bank_desc& d, const knh::KernelEntry* entry, const
       const unsigned pipe_max = d.sample_type == KNH_F64 ? 256u : 512u;
       int ww = groups <= pipe_max && b->pipe ? 0 : (groups <= 1024 ? 4 : 8);
       if (!b->pipe && groups <= 256) ww = 0;
-      // a delay line wants the pipeline's 32-sample tiles (whole 128-byte lines per visit, reads one tile ahead):
-      // measured 1.37e12 against 0.88e12 UGen-samples/s at 262 144 voices
-      if (b->pipe && sig.find_first_of("DYZ") != std::string::npos) ww = 0;
+      // A chain with a delay (rings in HBM, moved as whole lines: voice_stages.hpp RingLines) is bound by memory, and the
+      // pipeline has one wavefront per voice group to keep requests in flight: beyond one round of it the whole-chain forms
+      // win (D3, us per block, profiles/r04_delay_forms.txt: 20 480 voices 57.8 / 51.8, 65 536 117 / 67.9 for four per
+      // workgroup, 131 072 233 / 126 / 118 for eight).  (Rounds 1-3 kept every delay chain on the pipeline: a lane per
+      // voice's 16-byte pieces ran at 2.0 TB/s in any form.)
+      if (b->pipe && sig.find_first_of("DYZ") != std::string::npos) ww = groups <= 256 ? 0 : (groups <= 1024 ? 4 : 8);
       const char* wenv = std::getenv("KNH_WIDE");
       if (wenv) ww = std::atoi(wenv);
       if (ww == 4 || ww == 8 || ww == 16) b->wide_waves = ww;

@@ -1158,7 +1158,8 @@ struct Bank final : knh_bank {
       uint32_t mx = 0;
       for (uint32_t l : delay_len) mx = std::max(mx, l);
       delay_stride = (mx + 3u) & ~3u;
-      const size_t bytes = static_cast<size_t>(nv) * delay_stride * sizeof(F);
+      // (+ a spare ring behind the last voice's: where lanes without a voice move their lines, voice_stages.hpp RingLines)
+      const size_t bytes = (static_cast<size_t>(nv) + 1) * delay_stride * sizeof(F) + 4096;
       size_t free_b = 0, total_b = 0;
       KNH_HIP(hipMemGetInfo(&free_b, &total_b));
       if (bytes > free_b) return fail(KNH_ERR_DEVICE, "SampleDelay: the delay rings do not fit in device memory");

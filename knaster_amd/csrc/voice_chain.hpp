@@ -900,6 +900,7 @@ __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a)
   ctx.seg_max = a.seg_max;
   ctx.delay_ring = a.delay_ring;
   ctx.delay_stride = a.delay_stride;
+  ctx.ring_sink_row = a.n_voices;
   ctx.buffer = a.buffer;
   ctx.buffer_frames = a.buffer_frames;
   ctx.input_block = a.input;

@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(320) voice_dag_kernel(VoiceKernelArgs<F> a) {
   ctx.seg_max = a.seg_max;
   ctx.delay_ring = a.delay_ring;
   ctx.delay_stride = a.delay_stride;
+  ctx.ring_sink_row = a.n_voices;
   ctx.buffer = a.buffer;
   ctx.buffer_frames = a.buffer_frames;
 

@@ -26,6 +26,7 @@ template <typename G> struct GroupInfo;
 template <typename... S> struct GroupInfo<Group<S...>> {
   static constexpr int slots = (0 + ... + S::kSlots);
   static constexpr bool uses_sine = (false || ... || S::kUsesSine);
+  static constexpr bool uses_ring = (false || ... || S::kUsesRing);  // a delay: the group's wavefront moves ring tiles as lines (RingLines)
   static constexpr bool has_env = (false || ... || S::kIsEnv);
   static constexpr bool pan = (false || ... || IsPan<S>::value);  // the group ends the chain with a Pan2
   static constexpr int fan_for(int) { return 1; }
@@ -33,6 +34,7 @@ template <typename... S> struct GroupInfo<Group<S...>> {
 template <int K, typename... S> struct GroupInfo<Fan<K, S...>> {
   static constexpr int slots = (0 + ... + S::kSlots);
   static constexpr bool uses_sine = (false || ... || S::kUsesSine);
+  static constexpr bool uses_ring = false;
   static constexpr bool has_env = false;
   static constexpr bool pan = false;
   // wavefronts for tiles of T samples: K, or as many as leave every one a window of eight samples (f64 tiles are shorter)
@@ -112,6 +114,7 @@ template <typename F> struct PipeShared {
   u32* res_marks;
   Event* ev_stage;       // ... and the LDS its events are staged in, call by call (ev_cap of them; the workgroup has n_threads threads)
   u32 ev_cap, n_threads;
+  __attribute__((address_space(3))) char* ring_tile_of[4];  // per stage group: its RingLines tile (voice_stages.hpp), null for a group without a delay
 };
 
 template <typename F, bool FMA, int T, bool PAN>
@@ -143,13 +146,15 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   constexpr u32 SLOT_LO = (u32)BASE, SLOT_HI = (u32)(BASE + GroupInfo<G>::slots);
 
   Ctx ctx;
-  ctx.ring_tile = nullptr;  // (RingLines: the whole-chain kernels)
+  ctx.ring_tile = nullptr;
+  if constexpr (GroupInfo<G>::uses_ring && KF == 1 && T * (int)sizeof(F) >= RingLines<F>::kLine && I < 4) ctx.ring_tile = sh.ring_tile_of[I];
   ctx.sine = sh.sine;
   ctx.f2pi = a.f2pi;
   ctx.seg_table = a.seg_table;
   ctx.seg_max = a.seg_max;
   ctx.delay_ring = a.delay_ring;
   ctx.delay_stride = a.delay_stride;
+  ctx.ring_sink_row = a.n_voices;
   ctx.buffer = a.buffer;
   ctx.buffer_frames = a.buffer_frames;
   ctx.input_block = a.input;
@@ -623,7 +628,10 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
   // (the edge before it has three buffers instead)
   constexpr long kEdgeElems = (long)EdgeMap<MODE, NG>::tiles * EdgeLayout<F, T>::tile;  // per voice group
   // what is left of the CU's 160 KiB holds the workgroup's events (16 bytes each), up to 2 048 of them
-  constexpr long kLdsFree = 160 * 1024 - 1024 - 4096 - 64 - (long)sizeof(float) * (kSine ? 16384 : 4) - (long)sizeof(F) * GPW * kEdgeElems;
+  // a stage group with a delay moves its ring tiles as whole lines through a tile of its own (RingLines)
+  constexpr int kRingTiles = T * (int)sizeof(F) >= RingLines<F>::kLine ? (0 + ... + (GroupInfo<Gs>::uses_ring ? 1 : 0)) : 0;
+  constexpr long kLdsFree = 160 * 1024 - 1024 - 4096 - 64 - (long)sizeof(float) * (kSine ? 16384 : 4) - (long)sizeof(F) * GPW * kEdgeElems
+                            - (long)GPW * kRingTiles * RingLines<F>::kTileBytes;
 #ifndef KNH_EVCAP_MAX
 #define KNH_EVCAP_MAX 2048
 #endif
@@ -634,6 +642,7 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
     float sine[kSine ? 16384 : 4];
     __attribute__((aligned(16))) F edge[GPW * kEdgeElems];
     __attribute__((aligned(16))) Event ev_stage[kEvCap > 0 ? kEvCap : 1];
+    __attribute__((aligned(16))) char ring_tiles[GPW * kRingTiles > 0 ? GPW * kRingTiles * RingLines<F>::kTileBytes : 16];
     u32 res_marks[16 * 64];  // a resident launch: the groups' done marks and running flags of the call (PipeShared)
     u32 res_slot[16];        // ... and its command word
   };
@@ -684,6 +693,16 @@ __global__ void __launch_bounds__((GPW * PipeWaves<T, MODE, Gs...>::value * 64))
   sh.ev_stage = ev_stage;
   sh.ev_cap = (u32)(kEvCap > 0 ? kEvCap : 0);
   sh.n_threads = (u32)(GPW * WAVES * 64);
+  {
+    constexpr bool ring_groups[] = {GroupInfo<Gs>::uses_ring...};
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool u = i < NG && kRingTiles > 0 && ring_groups[i < NG ? i : 0];
+      sh.ring_tile_of[i] = u ? (__attribute__((address_space(3))) char*)(lds.ring_tiles + ((long)grp * kRingTiles + k) * RingLines<F>::kTileBytes) : nullptr;
+      k += u ? 1 : 0;
+    }
+  }
   const u32 wave_global = blockIdx.x * (u32)GPW + (u32)grp;  // the 64-voice group of the bank
   const u32 v0 = wave_global * 64u;
   const bool dead = GPW > 1 && v0 >= a.n_voices;  // the last workgroup of a bank with an odd number of voice groups

@@ -109,6 +109,7 @@ struct Ctx {
   u32 in_stride;            // = block_size
   u32 sample_rate;          // ctx.sample_rate(), for setters that run on the device (audio-rate parameters)
   __attribute__((address_space(3))) char* ring_tile;  // this wavefront's RingLines tile in LDS (whole-chain kernels of up to eight wavefronts), or null
+  u32 ring_sink_row;        // the spare ring behind the last voice's (= the number of voices): where lanes without a voice move their lines
 };
 
 // ---------------------------------------------------------------------------
@@ -1719,46 +1720,46 @@ struct RingLines {
   typedef __attribute__((address_space(1))) U4u* glb_u4;
   typedef __attribute__((address_space(1))) W* glb_w;
   struct Lines { U4 v[8]; };
-  struct Where { u64 ring; u32 pos, len; bool live; };
+  // The eight voices whose lines this lane moves, for the tile at hand: ring address, positions, length.
+  struct Owned { u64 ring[8]; u32 wp[8], rp[8], len[8]; };
   static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
-  // what the lanes that move this lane's voice's lines need: its ring's row (live = false: no voice here), its positions
-  // and the ring's length, in samples
-  static __device__ __forceinline__ void put_header(tile_t tile, int lane, bool live, u32 row, u32 wp, u32 rp, u32 len) {
+  static __device__ __forceinline__ u32 wrapped(u32 pos, u32 len) { return pos - len < pos ? pos - len : pos; }  // pos < 2 len (pos - len wraps to a huge number below len)
+  // Every lane posts its voice's ring row, positions (samples) and ring length; then reads those of the voices it moves
+  // lines for.  A lane without a voice posts the bank's sink row (one spare ring behind the last voice's: Ctx::ring_sink_row),
+  // so that no access below needs to ask whether its voice exists.
+  static __device__ __forceinline__ void exchange(tile_t tile, int lane, bool live, u32 row, u32 wp, u32 rp, u32 len, const Ctx& c, Owned& o) {
     U4 h;
-    h[0] = live ? row : 0xFFFFFFFFu; h[1] = wp; h[2] = rp; h[3] = len;
+    h[0] = live ? row : c.ring_sink_row; h[1] = live ? wp : 0u; h[2] = live ? rp : 0u; h[3] = live ? len : 0x7FFFFFFFu;
     *reinterpret_cast<lds_u4>(tile + lane * kRow + kLine) = h;
     fence();
-  }
-  // chunk (lane & 7) of instruction i: whose ring, and where in it (STORE: from the write position, else the read position)
-  template <bool STORE>
-  static __device__ __forceinline__ Where where(tile_t tile, int lane, int i, u32 sample_offset, const Ctx& c) {
-    const U4 h = *reinterpret_cast<lds_u4>(tile + (8 * i + (lane >> 3)) * kRow + kLine);
-    const u32 row = h[0], wp = h[1], rp = h[2], len = h[3];
-    Where w;
-    w.live = row != 0xFFFFFFFFu;
-    w.ring = reinterpret_cast<u64>(c.delay_ring) + (u64)row * ((u64)c.delay_stride * sizeof(F));
-    const u32 pos = (STORE ? wp : rp) + sample_offset + (u32)((lane & 7) * VW);  // < 2 len: the callers' conditions
-    w.pos = pos - len < pos ? pos - len : pos;                                     // (pos - len wraps to a huge number below len)
-    w.len = len;
-    return w;
-  }
-  static __device__ __forceinline__ u32 wrapped(u32 pos, u32 len) { return pos - len < pos ? pos - len : pos; }
-  // the lines at read position + sample_offset, requested (the loads are in flight when this returns)
-  static __device__ __forceinline__ void load(tile_t tile, int lane, u32 sample_offset, const Ctx& c, Lines& l) {
+    U4 g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = *reinterpret_cast<lds_u4>(tile + (8 * i + (lane >> 3)) * kRow + kLine);
+    const u64 row_bytes = (u64)c.delay_stride * sizeof(F);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const Where w = where<false>(tile, lane, i, sample_offset, c);
-      U4 v = {0u, 0u, 0u, 0u};
-      if (w.live) {
-        if (w.pos + (u32)VW <= w.len) {
-          v = *reinterpret_cast<glb_u4>(w.ring + (u64)w.pos * sizeof(F));
-        } else {  // the chunk that straddles the end of the ring: sample by sample
+      const u32 r0 = g[i][0], r1 = g[i][1], r2 = g[i][2], r3 = g[i][3];
+      o.ring[i] = reinterpret_cast<u64>(c.delay_ring) + (u64)r0 * row_bytes;
+      o.wp[i] = r1 + (u32)((lane & 7) * VW);  // (this lane's chunk of the line)
+      o.rp[i] = r2 + (u32)((lane & 7) * VW);
+      o.len[i] = r3;
+    }
+    fence();
+  }
+  // the lines at read position + sample_offset, requested (the loads are in flight when this returns)
+  static __device__ __forceinline__ void load(const Owned& o, u32 sample_offset, Lines& l) {
 #pragma unroll
-          for (int e = 0; e < VW; ++e) {
-            const W q = reinterpret_cast<glb_w>(w.ring)[wrapped(w.pos + (u32)e, w.len)];
-            if constexpr (sizeof(F) == 4) v[e] = (u32)q;
-            else { v[2 * e] = (u32)q; v[2 * e + 1] = (u32)((u64)q >> 32); }
-          }
+    for (int i = 0; i < 8; ++i) {
+      const u32 len = o.len[i], pos = wrapped(o.rp[i] + sample_offset, len);
+      U4 v;
+      if (pos + (u32)VW <= len) {
+        v = *reinterpret_cast<glb_u4>(o.ring[i] + (u64)pos * sizeof(F));
+      } else {  // the chunk that straddles the end of the ring: sample by sample
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          const W q = reinterpret_cast<glb_w>(o.ring[i])[wrapped(pos + (u32)e, len)];
+          if constexpr (sizeof(F) == 4) v[e] = (u32)q;
+          else { v[2 * e] = (u32)q; v[2 * e + 1] = (u32)((u64)q >> 32); }
         }
       }
       l.v[i] = v;
@@ -1782,7 +1783,7 @@ struct RingLines {
     fence();
   }
   // this lane's voice's TS samples -> lines, stored at write position + sample_offset
-  static __device__ __forceinline__ void store(tile_t tile, int lane, const F* x, u32 sample_offset, const Ctx& c) {
+  static __device__ __forceinline__ void store(tile_t tile, int lane, const Owned& o, const F* x, u32 sample_offset) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       U4 q;
@@ -1795,21 +1796,21 @@ struct RingLines {
       *reinterpret_cast<lds_u4>(tile + lane * kRow + j * 16) = q;
     }
     fence();
+    U4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<lds_u4>(tile + (8 * i + (lane >> 3)) * kRow + (lane & 7) * 16);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const U4 v = *reinterpret_cast<lds_u4>(tile + (8 * i + (lane >> 3)) * kRow + (lane & 7) * 16);
-      const Where w = where<true>(tile, lane, i, sample_offset, c);
-      if (w.live) {
-        if (w.pos + (u32)VW <= w.len) {
-          *reinterpret_cast<glb_u4>(w.ring + (u64)w.pos * sizeof(F)) = v;
-        } else {
+      const u32 len = o.len[i], pos = wrapped(o.wp[i] + sample_offset, len);
+      if (pos + (u32)VW <= len) {
+        *reinterpret_cast<glb_u4>(o.ring[i] + (u64)pos * sizeof(F)) = v[i];
+      } else {
 #pragma unroll
-          for (int e = 0; e < VW; ++e) {
-            W q;
-            if constexpr (sizeof(F) == 4) { const u32 t = v[e]; q = (W)t; }
-            else { const u32 lo = v[2 * e], hi = v[2 * e + 1]; q = (W)((u64)lo | ((u64)hi << 32)); }
-            reinterpret_cast<glb_w>(w.ring)[wrapped(w.pos + (u32)e, w.len)] = q;
-          }
+        for (int e = 0; e < VW; ++e) {
+          W q;
+          if constexpr (sizeof(F) == 4) { const u32 t = v[i][e]; q = (W)t; }
+          else { const u32 lo = v[i][2 * e], hi = v[i][2 * e + 1]; q = (W)((u64)lo | ((u64)hi << 32)); }
+          reinterpret_cast<glb_w>(o.ring[i])[wrapped(pos + (u32)e, len)] = q;
         }
       }
     }
@@ -1890,7 +1891,8 @@ struct SampleDelay : StageDefaults {
             const bool ahead = !dead && r.len >= 2u * (u32)T && r.off <= r.len - 2u * (u32)T;
             const bool all_have = __builtin_amdgcn_ballot_w64(!(have || dead)) == 0;
             const bool all_ahead = __builtin_amdgcn_ballot_w64(!(ahead || dead)) == 0;
-            RL::put_header(c.ring_tile, lane, !dead, r.row, r.wp, rp, r.len);
+            typename RL::Owned own;
+            RL::exchange(c.ring_tile, lane, !dead, r.row, r.wp, rp, r.len, c, own);
             F y[T];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -1898,17 +1900,17 @@ struct SampleDelay : StageDefaults {
                 RL::to_samples(c.ring_tile, lane, r.lines[s], &y[s * RL::TS]);
               } else {
                 typename RL::Lines l;
-                RL::load(c.ring_tile, lane, (u32)(s * RL::TS), c, l);
+                RL::load(own, (u32)(s * RL::TS), l);
                 RL::to_samples(c.ring_tile, lane, l, &y[s * RL::TS]);
               }
             }
             if (all_ahead) {
 #pragma unroll
-              for (int s = 0; s < NS; ++s) RL::load(c.ring_tile, lane, (u32)(T + s * RL::TS), c, r.lines[s]);
+              for (int s = 0; s < NS; ++s) RL::load(own, (u32)(T + s * RL::TS), r.lines[s]);
             }
             r.pre_pos = all_ahead && !dead ? np : 0xFFFFFFFFu;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) RL::store(c.ring_tile, lane, &x[s * RL::TS], (u32)(s * RL::TS), c);
+            for (int s = 0; s < NS; ++s) RL::store(c.ring_tile, lane, own, &x[s * RL::TS], (u32)(s * RL::TS));
             if (!dead) {
 #pragma unroll
               for (int j = 0; j < T; ++j) x[j] = y[j];
@@ -2062,12 +2064,13 @@ struct AllpassDelayT : StageDefaults {
           if (__builtin_amdgcn_ballot_w64(!lines_ok) == 0) {
             constexpr int NS = T / RL::TS;
             const int lane = (int)(threadIdx.x & 63u);
-            RL::put_header(c.ring_tile, lane, !dead, r.row, r.wp, r.rp, r.len);
+            typename RL::Owned own;
+            RL::exchange(c.ring_tile, lane, !dead, r.row, r.wp, r.rp, r.len, c, own);
             F y[T];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
               typename RL::Lines l;
-              RL::load(c.ring_tile, lane, (u32)(s * RL::TS), c, l);
+              RL::load(own, (u32)(s * RL::TS), l);
               RL::to_samples(c.ring_tile, lane, l, &y[s * RL::TS]);
             }
             F wr[T];  // what goes into the ring: the input, or the input plus the fed-back delayed signal
@@ -2082,7 +2085,7 @@ struct AllpassDelayT : StageDefaults {
               }
             }
 #pragma unroll
-            for (int s = 0; s < NS; ++s) RL::store(c.ring_tile, lane, &wr[s * RL::TS], (u32)(s * RL::TS), c);
+            for (int s = 0; s < NS; ++s) RL::store(c.ring_tile, lane, own, &wr[s * RL::TS], (u32)(s * RL::TS));
             if (!dead) {
               r.rp += (u32)T;
               if (r.rp >= r.len) r.rp -= r.len;
