@@ -91,6 +91,31 @@ struct Bank final : knh_bank {
   // arrive, then (at process time) block 0's queued changes, block 1's immediate ones, ...
   std::vector<HostEvent> pending;
   bool pending_needs_sort = false;   // some voice may have events out of frame order
+  // The same change for a run of neighbouring voices (a whole bank's note-on or note-off in one knh_bank_param_apply_many):
+  // one record instead of an event per voice.  `at` = how many events `pending` held when it arrived (its place in the
+  // application order).  A resident call whose events are nothing but a few of these passes them on as they are (ResCall,
+  // voice_chain.hpp: 32 bytes each over PCIe instead of 16 per voice); anything else turns them into per-voice events first.
+  struct RangeEvent { uint32_t v0, v1, frame, op, slot; uint64_t bits; size_t at; };
+  std::vector<RangeEvent> pending_ranges, sent_ranges;
+  uint32_t res_n_ranges = 0;         // the list upload_events has just made holds this many range events (0: per-voice lists)
+  void expand_ranges() {
+    if (pending_ranges.empty()) return;
+    size_t extra = 0;
+    for (const RangeEvent& r : pending_ranges) extra += r.v1 - r.v0;
+    std::vector<HostEvent> out;
+    out.reserve(pending.size() + extra);
+    size_t k = 0;
+    auto emit = [&](const RangeEvent& r) { for (uint32_t v = r.v0; v < r.v1; ++v) out.push_back(HostEvent{v, r.frame, r.op, r.slot, r.bits}); };
+    for (size_t i = 0; i < pending.size(); ++i) {
+      while (k < pending_ranges.size() && pending_ranges[k].at <= i) emit(pending_ranges[k++]);
+      out.push_back(pending[i]);
+    }
+    while (k < pending_ranges.size()) emit(pending_ranges[k++]);
+    pending.swap(out);
+    pending_ranges.clear();
+  }
+  // the bank's resident kernel form walks range events: the pipelined kernels (voice_pipe.hpp), not the one-wavefront kernel
+  bool res_ranges_ok() const { return jit ? jit_pipe : pipe != nullptr; }
   uint32_t frame_base = 0;           // absolute frame of frame 0 of the block being assembled
   // param_apply / set_delay calls addressed to later blocks of the next multi-block launch
   struct Call { uint8_t is_delay; uint16_t delay; uint32_t voice, stage, param, kind; double f; int64_t i; };
@@ -455,8 +480,8 @@ struct Bank final : knh_bank {
       (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
       if (hipStreamCreateWithPriority(&res_stream, hipStreamNonBlocking, prio_high) != hipSuccess) KNH_HIP(hipStreamCreateWithFlags(&res_stream, hipStreamNonBlocking));
     }
-    KNH_HIP(hipMalloc(&d_res_relay, 64));
-    KNH_HIP(hipMemset(d_res_relay, 0xFF, 64));
+    KNH_HIP(hipMalloc(&d_res_relay, 1024));  // the command word, and (words 16 ..) a call's range events (voice_chain.hpp RES_RELAY_RANGES)
+    KNH_HIP(hipMemset(d_res_relay, 0xFF, 1024));
     KNH_HIP(hipHostMalloc(&h_res_out, desc.out_channels * block_size * sizeof(F), hipHostMallocMapped | hipHostMallocCoherent));
     KNH_HIP(hipHostMalloc(&h_res_done, 256, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h_res_done, 0, 256);
@@ -563,7 +588,7 @@ struct Bank final : knh_bank {
     KNH_HIP(hipSetDevice(device));
     if (device >= 0 && device < 64 && rs.owner[device] && rs.owner[device] != this) rs.leave[device](rs.owner[device]);
     const uint64_t payload = (static_cast<uint64_t>(fb) << 24) | (static_cast<uint64_t>(fe) << 40) | (have_events ? 1ull << 56 : 0ull) |
-                             (have_events && list_in_use == 1 ? 1ull << 57 : 0ull);
+                             (have_events && list_in_use == 1 ? 1ull << 57 : 0ull) | (have_events ? static_cast<uint64_t>(res_n_ranges & 15u) << 59 : 0ull);
     if (have_events && list_in_use >= 0) { list_busy[list_in_use] = false; list_in_use = -1; }  // (no stream order to keep: the call is over when this returns)
     uint32_t epoch = 0;
     auto ring = [&]() -> int {  // the next epoch's command; a kernel to take it if there is none
@@ -1501,6 +1526,15 @@ struct Bank final : knh_bank {
         note_frame(frame);
         const bool release = S.kind == KNH_STAGE_MUL_ENV_ASR && params[k] == 2;
         HostEvent t{0u, frame, release ? static_cast<uint32_t>(knh_dev::EV_ENV_ASR_RELEASE) : static_cast<uint32_t>(knh_dev::EV_SET), static_cast<uint32_t>(S.slot_base), release ? 0ull : 1ull};
+        {  // neighbouring voices in rising order (the usual way to address a bank): one range event
+          bool run = voices[e - 1] < nv && pending_ranges.size() < 64;
+          for (size_t q = k + 1; q < e && run; ++q) run = voices[q] == voices[q - 1] + 1u;
+          if (run) {
+            pending_ranges.push_back(RangeEvent{voices[k], voices[e - 1] + 1u, frame, t.op, t.slot, t.bits, pending.size()});
+            k = e;
+            continue;
+          }
+        }
         const size_t at = pending.size();
         pending.resize(at + (e - k));
         HostEvent* out = pending.data() + at;
@@ -1862,10 +1896,16 @@ struct Bank final : knh_bank {
   // Events addressed past the blocks of this launch (a call for block k of a later launch, turned into patches at once):
   // they stay in `pending`, k launches' worth of blocks earlier, for the next launch.
   std::vector<HostEvent> later;
-  int upload_events(hipStream_t s, bool* have_events, uint32_t n_blocks) {
+  int upload_events(hipStream_t s, bool* have_events, uint32_t n_blocks, bool allow_ranges = false) {
     *have_events = false;
     later.clear();
+    res_n_ranges = 0;
     const uint64_t horizon = static_cast<uint64_t>(n_blocks) * block_size;
+    if (!pending_ranges.empty()) {
+      bool as_ranges = allow_ranges && pending.empty() && pending_ranges.size() <= 15;
+      for (const RangeEvent& r : pending_ranges) as_ranges = as_ranges && r.frame < horizon;
+      if (!as_ranges) expand_ranges();
+    }
     if (pending_max_frame >= horizon && !pending.empty()) {
       size_t w = 0;
       for (const HostEvent& e : pending) {
@@ -1874,7 +1914,7 @@ struct Bank final : knh_bank {
       }
       pending.resize(w);
     }
-    const size_t total = pending.size();
+    const size_t total = pending.empty() ? 2 * pending_ranges.size() : pending.size();
     auto finish = [&] {
       pending.clear();
       pending_needs_sort = false;
@@ -1903,6 +1943,25 @@ struct Bank final : knh_bank {
     h_ev_start = h_ev_start2[lb];
     h_events = h_events2[lb];
     list_in_use = static_cast<int>(lb);
+    if (!pending_ranges.empty()) {  // (pending is empty: see above) the call's events as range events, two records each
+      for (size_t j = 0; j < pending_ranges.size(); ++j) {
+        const RangeEvent& r = pending_ranges[j];
+        Event& d = h_events[2 * j];
+        d.frame = r.frame;
+        d.slot_op = (r.slot & 0xFFFFFFu) | (r.op << 24);
+        d.bits = r.bits;
+        Event& w = h_events[2 * j + 1];
+        w.frame = r.v0;
+        w.slot_op = r.v1;
+        w.bits = 0;
+      }
+      res_n_ranges = static_cast<uint32_t>(pending_ranges.size());
+      sent_ranges.swap(pending_ranges);
+      pending_ranges.clear();
+      finish();
+      *have_events = true;
+      return KNH_OK;
+    }
     uint32_t* start = h_ev_start;  // nv + 2 words
     // Already in voice order (a batch of triggers for voices 0 .. N - 1, the common big list): one pass, no sort.
     bool in_voice_order = true;
@@ -1983,8 +2042,15 @@ struct Bank final : knh_bank {
         for (size_t k = qfuture.size() - n_blocks; k < qfuture.size(); ++k) qfuture[k].clear();
       }
     }
+    // (whether this call goes to a resident launch -- below -- decides what its events may look like)
+    if (res_policy < 0) {
+      const char* e = std::getenv("KNH_RESIDENT");
+      res_policy = e && e[0] == '0' ? 0 : 1;
+    }
+    const bool res_ok = res_policy == 1 && sync && out_host && !out_device && !voices_host && !stream && n_blocks == 1 && fe > fb && mapped_out &&
+                        !accumulate && !timing && !(dev_events && n_recs > 0) && res_possible();
     bool have_events = false;
-    int rc = upload_events(s, &have_events, n_blocks);
+    int rc = upload_events(s, &have_events, n_blocks, res_ok && res_cooldown == 0 && res_ranges_ok());
     if (rc != KNH_OK) return rc;
     if (!future.empty()) {  // calls addressed beyond this launch move up; those now due for the next
                             // block are applied right away, ahead of anything that arrives later
@@ -2003,12 +2069,6 @@ struct Bank final : knh_bank {
     // bank's kernel form has one (res_possible); anything else first asks a resident kernel (this bank's, or another bank's
     // on this device) to leave: it would be in the way of the launch, and it holds the voices' state in its registers.
     {
-      if (res_policy < 0) {
-        const char* e = std::getenv("KNH_RESIDENT");
-        res_policy = e && e[0] == '0' ? 0 : 1;
-      }
-      const bool res_ok = res_policy == 1 && sync && out_host && !out_device && !voices_host && !stream && n_blocks == 1 && fe > fb && mapped_out &&
-                          !accumulate && !timing && !(dev_events && n_recs > 0) && res_possible();
       if (res_ok && res_cooldown == 0) {
         rc = res_alloc();
         if (rc != KNH_OK) return rc;
@@ -2017,6 +2077,12 @@ struct Bank final : knh_bank {
         if (rc != KNH_ERR_UNSUPPORTED_CHAIN) return rc;
         list_in_use = held_list;  // the kernels would not run side by side: this call, and the bank from now on, takes the launch per call
         if (held_list >= 0) list_busy[held_list] = false;
+        if (res_n_ranges) {  // the launch per call reads per-voice lists: the call's range events once more, spelled out
+          pending_ranges.swap(sent_ranges);
+          for (RangeEvent& r : pending_ranges) r.at = 0;
+          rc = upload_events(s, &have_events, n_blocks, false);
+          if (rc != KNH_OK) return rc;
+        }
       }
       if (res_cooldown) --res_cooldown;
       rc = res_leave();

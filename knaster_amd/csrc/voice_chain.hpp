@@ -356,11 +356,17 @@ __device__ __forceinline__ void res_put_sample(u64* g, double v, u32 tag) {
   res_put(g, (u32)b, tag);
   res_put(g + 1, (u32)(b >> 32), tag);
 }
-enum : u64 { RES_EPOCH_MASK = 0xFFFFFFull, RES_HAS_EVENTS = 1ull << 56, RES_LIST = 1ull << 57, RES_LEAVE = 1ull << 58 };
+enum : u32 { RES_RELAY_RANGES = 16 };  // the relay buffer: word 0 the command, words 16 .. 16 + 4 * 15 a call's range events (below)
+enum : u64 { RES_EPOCH_MASK = 0xFFFFFFull, RES_HAS_EVENTS = 1ull << 56, RES_LIST = 1ull << 57, RES_LEAVE = 1ull << 58, RES_RANGES_SHIFT = 59, RES_RANGES_MASK = 0xFull };
+// A call's events come as per-voice lists (ev_start + events, sorted by voice) or -- bits 59..62 = n > 0 -- as n RANGE events:
+// the same change for every voice of [v_begin, v_end), a whole bank's note-on in 32 bytes instead of 16 bytes per voice
+// fetched over PCIe.  A range event is two Event-sized records at events[2 j], events[2 j + 1] of the call's list:
+// {frame, slot_op, bits} and {v_begin, v_end, -}; every voice walks the n of them in order and takes those that cover it.
 struct ResCall {  // one command, unpacked
   u32 epoch, frame_begin, frame_end;
   bool has_events, leave;
   u32 list;
+  u32 n_ranges;
 };
 __device__ __forceinline__ ResCall res_unpack(u64 c) {
   ResCall r;
@@ -370,6 +376,7 @@ __device__ __forceinline__ ResCall res_unpack(u64 c) {
   r.has_events = (c & RES_HAS_EVENTS) != 0ull;
   r.list = (c & RES_LIST) ? 1u : 0u;
   r.leave = (c & RES_LEAVE) != 0ull;
+  r.n_ranges = (u32)((c >> RES_RANGES_SHIFT) & RES_RANGES_MASK);
   return r;
 }
 // A call's events into LDS: the workgroup's piece of the call's list (its voices are neighbours, the list is sorted by voice),
@@ -380,18 +387,30 @@ struct ResStaged { u32 first, count; };
 __device__ __forceinline__ ResStaged res_stage_events(const Resident& r, const ResCall& call, Event* stage, u32 cap, u32 gv0, u32 gnv, u32 tid, u32 n_threads) {
   ResStaged st{0u, 0u};
   if (!call.has_events || cap == 0u) return st;  // uniform
-  const u32* evs = r.ev_start[call.list];
-  st.first = __hip_atomic_load(&evs[gv0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  st.count = __hip_atomic_load(&evs[gv0 + gnv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - st.first;
-  if (st.count > cap) st.count = 0u;
-  const u64* src = reinterpret_cast<const u64*>(r.events[call.list] + st.first);
-  u64* dst = reinterpret_cast<u64*>(stage);
-  for (u32 i = tid; i < st.count; i += n_threads) {
-    const u64 w0 = __hip_atomic_load(&src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const u64 w1 = __hip_atomic_load(&src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    dst[2 * i] = w0;
-    dst[2 * i + 1] = w1;
+  if (call.n_ranges) {  // range events: the same 2 n records for every workgroup -- workgroup 0 has put them beside the relay
+    st.count = 2u * call.n_ranges;
+    if (st.count > cap) { st.count = 0u; return st; }  // (the voices then read them where the host left them)
+    const u64* src = r.relay + RES_RELAY_RANGES;
+    u64* dst = reinterpret_cast<u64*>(stage);
+    for (u32 i = tid; i < 2u * st.count; i += n_threads) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return st;
+  } else {
+    const u32* evs = r.ev_start[call.list];
+    st.first = __hip_atomic_load(&evs[gv0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    st.count = __hip_atomic_load(&evs[gv0 + gnv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - st.first;
   }
+  if (st.count > cap) st.count = 0u;
+  // The list is in host memory the host has rewritten since this kernel started, so the loads must not be served by this
+  // CU's L1: VOLATILE 16-byte loads (system-scope cache bypass in the instruction itself, neighbouring lanes neighbouring
+  // events).  As 8-byte atomic loads, which nothing can merge, a bank's worth of single events was 65 536 reads over PCIe,
+  // 40 us of a call; a system-scope acquire fence in front of plain loads cost every call with events 7 us.
+  typedef u32 U4 __attribute__((ext_vector_type(4)));
+  const volatile U4* src = reinterpret_cast<const volatile U4*>(r.events[call.list] + st.first);
+  U4* dst = reinterpret_cast<U4*>(stage);
+  for (u32 i = tid; i < st.count; i += n_threads) { const U4 e = src[i]; dst[i] = e; }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -400,30 +419,48 @@ __device__ __forceinline__ ResStaged res_stage_events(const Resident& r, const R
 // Every wavefront of the workgroup calls this between two calls; `slot` = two words of LDS.  Wavefront 0's lane 0 waits for
 // the command with epoch `expect` (workgroup 0: from the host's word, and passes it on; the others: from the relay), bounded.
 __device__ __forceinline__ ResCall res_wait(const Resident& r, u32 expect, u32* slot, int wave_all, int lane) {
-  if (wave_all == 0 && lane == 0) {
+  if (wave_all == 0) {
     const bool leader = blockIdx.x == 0u;
-    if (leader && expect == r.first_epoch) __hip_atomic_store(r.host_started, r.first_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const u64 t0 = __builtin_amdgcn_s_memrealtime();
-    const u64 patience = leader ? r.idle_ticks : 2ull * r.idle_ticks + 5000000ull;  // (the others outwait workgroup 0: they hear of its leaving through the relay)
-    const bool from_bell = leader || r.bell_is_device != 0u;
-    u64 c;
-    for (;;) {
-      c = from_bell ? __hip_atomic_load(r.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((u32)(c & RES_EPOCH_MASK) == expect) break;
-      if (!leader && from_bell) {  // workgroup 0 gave up waiting and said so (the only word of its leaving the others get)
-        const u64 l = __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((l & RES_LEAVE) && (u32)(l & RES_EPOCH_MASK) == expect) { c = l; break; }
+    u64 c = 0ull;
+    if (lane == 0) {
+      if (leader && expect == r.first_epoch) __hip_atomic_store(r.host_started, r.first_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const u64 t0 = __builtin_amdgcn_s_memrealtime();
+      const u64 patience = leader ? r.idle_ticks : 2ull * r.idle_ticks + 5000000ull;  // (the others outwait workgroup 0: they hear of its leaving through the relay)
+      const bool from_bell = leader || r.bell_is_device != 0u;
+      for (;;) {
+        c = from_bell ? __hip_atomic_load(r.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((u32)(c & RES_EPOCH_MASK) == expect) break;
+        if (!leader && from_bell) {  // workgroup 0 gave up waiting and said so (the only word of its leaving the others get)
+          const u64 l = __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((l & RES_LEAVE) && (u32)(l & RES_EPOCH_MASK) == expect) { c = l; break; }
+        }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { c = RES_LEAVE | (u64)expect; break; }
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { c = RES_LEAVE | (u64)expect; break; }
-      __builtin_amdgcn_s_sleep(1);
     }
     if (leader) {
-      __hip_atomic_store(r.relay, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // (diagnostics, knh_bank_resident_trace: when the command was seen, on the device's 100 MHz clock)
-      __hip_atomic_store(reinterpret_cast<u64*>(r.host_started + 4), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // A call's range events travel with the command: the whole wavefront fetches them from the host's list (a few 8-byte
+      // reads over PCIe, side by side) and leaves them beside the relay, BEFORE the command appears there -- 256 workgroups
+      // fetching the same 32 bytes from host memory themselves took 47 us over it (the doorbell's lesson once more).
+      const u32 lo = __builtin_amdgcn_readfirstlane((u32)c), hi = __builtin_amdgcn_readfirstlane((u32)(c >> 32));
+      const u64 cw = (u64)lo | ((u64)hi << 32);
+      const ResCall call = res_unpack(cw);
+      if (!call.leave && call.has_events && call.n_ranges) {
+        const u64* src = reinterpret_cast<const u64*>(r.events[call.list]);
+        if ((u32)lane < 4u * call.n_ranges)
+          __hip_atomic_store(r.relay + RES_RELAY_RANGES + lane, __hip_atomic_load(&src[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      }
+      if (lane == 0) {
+        __hip_atomic_store(r.relay, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (diagnostics, knh_bank_resident_trace: when the command was seen, on the device's 100 MHz clock)
+        __hip_atomic_store(reinterpret_cast<u64*>(r.host_started + 4), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
-    slot[0] = (u32)c;
-    slot[1] = (u32)(c >> 32);
+    if (lane == 0) {
+      slot[0] = (u32)c;
+      slot[1] = (u32)(c >> 32);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_barrier();
@@ -638,9 +675,12 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
         if (p == 0u && !root) {
           const u64 tc = __builtin_amdgcn_s_memrealtime();
           for (;;) {
-            bool there = true;
+            // (until the FIRST row is there: the workgroups run in step, the others are then a fraction of a microsecond
+            // behind, and the loads of the whole tile that follow are in flight while they land -- waiting for the last row
+            // here cost every tile one more trip through the memory system, 0.7 us of each call)
+            bool there = false;
             if (lane < in_g) there = (u32)(res_get(base + (long)lane * stride) >> 32) == tag;
-            if (__builtin_amdgcn_ballot_w64(!there) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(there) != 0ull) break;
             if (__builtin_amdgcn_s_memrealtime() - tc > patience) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(4);
           }
@@ -667,7 +707,7 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
             all = ok;
           }
           if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { gave_up = true; break; }
-          if (root && __builtin_amdgcn_ballot_w64(!all) != 0ull) __builtin_amdgcn_s_sleep(3);
+          if (__builtin_amdgcn_ballot_w64(!all) != 0ull) { if (root) __builtin_amdgcn_s_sleep(3); else __builtin_amdgcn_s_sleep(1); }
         }
         if (root && p == 0u && !gave_up) {
           if (tracer && t == 0u) __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 12), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -195,6 +195,20 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
   // tile reads that were just issued; the wait belongs where the event is fetched, not where its frame is looked at).
   u32 next_frame = 0xFFFFFFFFu;
   auto note_next = [&]() { asm volatile("v_mov_b32 %0, %1" : "=v"(next_frame) : "v"(nxt.frame)); };
+  // a resident call whose events are range events (ResCall): event i is record 2 i of the list, record 2 i + 1 says which
+  // voices it is for; ev_i walks all of them and stops at those that cover this lane's voice
+  bool ev_ranged = false;
+  auto take_next = [&]() {  // ev_i: the next candidate
+    if (ev_ranged) {
+      while (ev_i < ev_end) {
+        const Event who = fetch(2u * ev_i + 1u);
+        if (who.frame <= voice && voice < who.slot_op) break;
+        ++ev_i;
+      }
+    }
+    if (ev_i < ev_end) { nxt = fetch(ev_ranged ? 2u * ev_i : ev_i); note_next(); }
+    else { nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu; }
+  };
   u32 base = 0;  // absolute frame of the current block's frame 0
   auto apply_events_upto = [&](u32 n_abs) {
     while (__builtin_expect(next_frame <= n_abs, 0)) {
@@ -204,8 +218,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
         if (live && (op & 0x7Fu) == EV_SET) a.state[(long)slot * a.stride + voice] = (W)nxt.bits;
       }
       ++ev_i;
-      if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
-      else { nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu; }
+      take_next();
     }
   };
   u32 done_frame = 0xFFFFFFFFu;
@@ -222,14 +235,20 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
     const ResStaged st = res_stage_events(a.res, call, sh.ev_stage, sh.ev_cap, v0, nv, (u32)(wave_all * 64 + lane), sh.n_threads);
     ev_staged = st.count != 0u;
     ev_lds_first = st.first;
+    ev_ranged = call.has_events && call.n_ranges != 0u;
+    if (ev_ranged) { evs = nullptr; ev_i = 0; ev_end = call.n_ranges; }
   }
-  ev_i = 0; ev_end = 0;
+  if (!ev_ranged) {
+    ev_i = 0; ev_end = 0;
+    if (evs) {
+      // (a resident call reads lists the host has rewritten since the kernel started: volatile = past this CU's L1, and
+      // unlike atomic loads neighbouring lanes' words travel together)
+      if (resident) { ev_i = *reinterpret_cast<const volatile u32*>(evs + voice); ev_end = *reinterpret_cast<const volatile u32*>(evs + voice + 1); }
+      else { ev_i = evs[voice]; ev_end = evs[voice + 1]; }
+    }
+  }
   nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu;
-  if (evs) {
-    if (resident) { ev_i = __hip_atomic_load(&evs[voice], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ev_end = __hip_atomic_load(&evs[voice + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-    else { ev_i = evs[voice]; ev_end = evs[voice + 1]; }
-  }
-  if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
+  take_next();
   base = 0;
 
   // The pipeline runs continuously over all blocks of the launch: global tile g = (block, tile in block).
@@ -336,8 +355,7 @@ __device__ __forceinline__ u32 pipe_run_group(const PipeShared<F>& sh, const Voi
               }
             }
             ++ev_i;
-            if (ev_i < ev_end) { nxt = fetch(ev_i); note_next(); }
-            else { nxt.frame = 0xFFFFFFFFu; next_frame = 0xFFFFFFFFu; }
+            take_next();
           }
           if (__builtin_amdgcn_ballot_w64(bad) != 0) {
             ev_i = sv_i;

@@ -319,6 +319,9 @@ static int bench(const char* name, int blocks, bool batched, bool ktime) {
   double peak = 0;
   double trace_us[4] = {0, 0, 0, 0};
   long trace_n = 0;
+  // the blocks that carry a bank's worth of triggers, apart: the parameter calls, the process call, the device's side of it
+  double trig_apply_us = 0, trig_process_us = 0, trig_trace_us[4] = {0, 0, 0, 0};
+  long trig_n = 0;
   auto run = [&](int n, bool timed) {
     for (int blk = 0; blk < n; ++blk) {
       const auto t0 = std::chrono::steady_clock::now();
@@ -329,15 +332,23 @@ static int bench(const char* name, int blocks, bool batched, bool ktime) {
         if (blk % 64 == 0) for (size_t i : i_restart) bank.param_apply(ctx, i, Value::Trigger);   // one SchedulingEvent per voice
         if (blk % 64 == 32) for (size_t i : i_release) bank.param_apply(ctx, i, Value::Trigger);
       }
+      const auto tm = std::chrono::steady_clock::now();
       bank.process_block(ctx, flags, nullptr, out.data());
       ctx.frame_clock += B;
       const auto t1 = std::chrono::steady_clock::now();
       if (timed) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+      const bool trig = !c1 && blk % 32 == 0;
+      if (timed && trig) {
+        trig_apply_us += std::chrono::duration<double, std::micro>(tm - t0).count();
+        trig_process_us += std::chrono::duration<double, std::micro>(t1 - tm).count();
+        trig_n += 1;
+      }
       if (timed) {
         uint64_t tk[5];
         if (knh_bank_resident_trace(bank.raw(), tk) == KNH_OK && tk[0] && tk[4] >= tk[0]) {
           for (int k = 0; k < 4; ++k) trace_us[k] += double(int64_t(tk[k + 1] - tk[0])) * 0.01;
           trace_n += 1;
+          if (trig) for (int k = 0; k < 4; ++k) trig_trace_us[k] += double(int64_t(tk[k + 1] - tk[0])) * 0.01;
         }
       }
       for (float x : out) peak = std::max(peak, double(std::fabs(x)));
@@ -356,10 +367,12 @@ static int bench(const char* name, int blocks, bool batched, bool ktime) {
   std::printf("{\"config\": \"%s\", \"driver\": \"C++ twin of the Rust shim: one knh_bank_process_block_channels per block, %s\", \"kernel_timed\": %s, "
               "\"voices\": %d, \"block_size\": %d, \"blocks\": %d, \"ugen_samples_per_s\": %.6g, \"us_per_block_mean\": %.3f, \"us_per_block_p50\": %.3f, "
               "\"us_per_block_p99\": %.3f, \"us_per_block_min\": %.3f, \"voice_kernel_us_per_block\": %.3f, \"output_peak\": %.4g, "
-              "\"resident_calls\": %ld, \"device_us_after_the_voice_kernel_saw_the_command\": {\"fold_server_saw_it\": %.2f, \"first_tile_complete\": %.2f, \"last_tile_complete\": %.2f, \"block_and_flags_written\": %.2f}}\n",
+              "\"resident_calls\": %ld, \"device_us_after_the_voice_kernel_saw_the_command\": {\"fold_server_saw_it\": %.2f, \"first_tile_complete\": %.2f, \"last_tile_complete\": %.2f, \"block_and_flags_written\": %.2f}, "
+              "\"trigger_blocks\": {\"n\": %ld, \"parameter_calls_us\": %.2f, \"process_call_us\": %.2f, \"device_first_tile_complete\": %.2f, \"device_block_and_flags_written\": %.2f}}\n",
               name, batched ? "a block's triggers in one knh_bank_param_apply_many" : "single-call param_apply per event", ktime ? "true" : "false", N, B, blocks, rate, secs * 1e6 / blocks, us[us.size() / 2], us[size_t(us.size() * 0.99)], us.front(),
               launches ? kms * 1e3 / double(launches) : 0.0, peak, trace_n, trace_n ? trace_us[0] / trace_n : 0.0, trace_n ? trace_us[1] / trace_n : 0.0,
-              trace_n ? trace_us[2] / trace_n : 0.0, trace_n ? trace_us[3] / trace_n : 0.0);
+              trace_n ? trace_us[2] / trace_n : 0.0, trace_n ? trace_us[3] / trace_n : 0.0,
+              trig_n, trig_n ? trig_apply_us / trig_n : 0.0, trig_n ? trig_process_us / trig_n : 0.0, trig_n ? trig_trace_us[1] / trig_n : 0.0, trig_n ? trig_trace_us[3] / trig_n : 0.0);
   return 0;
 }
 

@@ -124,3 +124,58 @@ def test_two_banks_take_turns_on_the_device(knh, monkeypatch):
     assert g1.resident_stats()[1] >= 1
     for bank in (g1, g2, ref):
         bank.close()
+
+
+def test_range_events_for_parts_of_the_bank(knh, monkeypatch):
+    """A batch of envelope triggers for neighbouring voices reaches a resident pipeline kernel as ONE range event (ResCall,
+    voice_chain.hpp) instead of an event per voice: ranges that cover parts of the bank, overlap (release, then restart, for
+    the voices in both), arrive beside single changes (before and after them: the whole call is spelled out per voice then),
+    more of them than a command can name, and in a block that is rendered in two partial calls."""
+    def script(bank, w, b):
+        n = w.n_voices
+        v = np.arange(n, dtype=np.uint32)
+        on, off = w.restart, w.release
+        if b == 0:
+            bank.param_apply_many(v[: n // 2], on[0], on[1], L.VALUE_TRIGGER)
+            bank.param_apply_many(v[n // 2:], on[0], on[1], L.VALUE_TRIGGER)
+        if b == 2:
+            bank.param_apply_many(v[100:300], off[0], off[1], L.VALUE_TRIGGER)
+            bank.param_apply_many(v[200:250], on[0], on[1], L.VALUE_TRIGGER)
+        if b == 4:
+            bank.param_apply_many(v, on[0], on[1], L.VALUE_TRIGGER)
+            bank.param_apply(5, 0, 0, 500.0)
+        if b == 5:
+            bank.param_apply(7, 0, 0, 600.0)
+            bank.param_apply_many(v, off[0], off[1], L.VALUE_TRIGGER)
+        if b == 7:
+            for i in range(20):
+                bank.param_apply_many(v[i * 30: i * 30 + 40], on[0] if i % 3 else off[0], on[1] if i % 3 else off[1], L.VALUE_TRIGGER)
+        if b == 8:  # (a split block: the triggers belong to its first part)
+            bank.param_apply_many(v[3:690], on[0], on[1], L.VALUE_TRIGGER)
+        if b == 10:
+            bank.param_apply_many(v[::-1].copy(), off[0], off[1], L.VALUE_TRIGGER)  # falling order: not a range
+
+    def render(resident):
+        monkeypatch.setenv("KNH_RESIDENT", "1" if resident else "0")
+        w = configs.config("C3", n_voices=700, block_size=64)
+        g = make_gpu(knh, w, L.MIX_TREE)
+        outs = []
+        for b in range(12):
+            script(g, w, b)
+            if b == 8:
+                o1, _ = g.process_block(20, 0)
+                o2, _ = g.process_block(44, 20)
+                out = o1.copy()
+                out[:, 20:] = o2[:, 20:]
+            else:
+                out, _ = g.process_block()
+            outs.append(out.copy())
+        done, stats = g.read_done_frames(), g.resident_stats()
+        g.close()
+        return outs, done, stats
+    a, b = render(True), render(False)
+    for k, (x, y) in enumerate(zip(a[0], b[0])):
+        assert_bit_equal(x, y, f"block {k}")
+    np.testing.assert_array_equal(a[1], b[1])
+    assert np.abs(np.stack(b[0])).max() > 1e-5
+    assert a[2] == (13, 1), a[2]

@@ -17,8 +17,9 @@ cp $N/pair_form.jsonl profiles/${R}_pair_form.jsonl
 for c in C3 C1; do
   l=$(echo $c | tr A-Z a-z)
   cp $N/per_block_twin_$c.json profiles/${R}_per_block_twin_$l.json
-  cp $N/per_block_twin_${c}_copy_path.json profiles/${R}_per_block_twin_${l}_copy_path.json
+  cp $N/per_block_twin_${c}_launch_per_call.json profiles/${R}_per_block_twin_${l}_launch_per_call.json
 done
+cp $N/per_block_twin_C3_single_call_events.json profiles/${R}_per_block_twin_c3_single_call_events.json
 python3 tools/pmc_summary.py $N > profiles/${R}_hbm_traffic.json
 python3 tools/sq_summary.py $N/pmc_SQ.csv > profiles/${R}_sq_counters.json
 git status --short profiles | head -30
