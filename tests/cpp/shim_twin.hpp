@@ -175,6 +175,22 @@ class GpuVoiceBank {
     const uint32_t k = kind == Value::Float ? KNH_VALUE_FLOAT : kind == Value::Trigger ? KNH_VALUE_TRIGGER : kind == Value::Integer ? KNH_VALUE_INTEGER : KNH_VALUE_BOOL;
     return knh_bank_param_apply(h_, static_cast<uint32_t>(rest / n_stages_), static_cast<uint32_t>(rest % n_stages_), static_cast<uint32_t>(param), k, f, i);
   }
+  // lib.rs: GpuVoiceBank::param_apply_many -> knh_bank_param_apply_many: one parameter of many voices in one call
+  int32_t param_apply_many(const std::vector<size_t>& indices, Value kind, double f = 0.0, int64_t i = 0) {
+    const uint32_t k = kind == Value::Float ? KNH_VALUE_FLOAT : kind == Value::Trigger ? KNH_VALUE_TRIGGER : kind == Value::Integer ? KNH_VALUE_INTEGER : KNH_VALUE_BOOL;
+    const size_t n = indices.size();
+    b_voices_.clear(); b_stages_.clear(); b_params_.clear();  // (the arrays are kept between calls, as the shim's `batch`)
+    for (size_t q = 0; q < n; ++q) {
+      const size_t param = indices[q] % MAX_PARAMS, rest = indices[q] / MAX_PARAMS;
+      b_voices_.push_back(static_cast<uint32_t>(rest / n_stages_));
+      b_stages_.push_back(static_cast<uint32_t>(rest % n_stages_));
+      b_params_.push_back(static_cast<uint32_t>(param));
+    }
+    b_kinds_.assign(n, k);
+    b_f_.assign(n, f);
+    b_i_.assign(n, i);
+    return knh_bank_param_apply_many(h_, n, b_voices_.data(), b_stages_.data(), b_params_.data(), b_kinds_.data(), b_f_.data(), b_i_.data(), nullptr);
+  }
   // lib.rs: UGen::set_ar_param_buffer: the slot's pointer is kept; process_block packs its samples
   void set_ar_param_buffer(AudioCtx&, size_t index, const F* buffer) {
     if (index < n_ar_) ar_bufs_[index] = buffer;
@@ -195,6 +211,9 @@ class GpuVoiceBank {
   std::vector<F> in_pack_;
   size_t block_size_ = 0;
   std::string init_error_;
+  std::vector<uint32_t> b_voices_, b_stages_, b_params_, b_kinds_;
+  std::vector<double> b_f_;
+  std::vector<int64_t> b_i_;
 };
 
 }  // namespace shim_twin

@@ -312,8 +312,6 @@ static int bench(const char* name, int blocks, bool batched, bool ktime) {
   std::vector<float> out(2 * B);
   std::vector<size_t> i_restart, i_release;
   if (!c1) for (int v = 0; v < N; ++v) { i_restart.push_back(bank.index(v, 3, "t_restart")); i_release.push_back(bank.index(v, 3, "t_release")); }
-  std::vector<uint32_t> all_v(N), st3(N, 3u), p_restart(N, 3u), p_release(N, 2u), k_trig(N, KNH_VALUE_TRIGGER);
-  for (int v = 0; v < N; ++v) all_v[v] = uint32_t(v);
   std::vector<double> us;
   us.reserve(blocks);
   double peak = 0;
@@ -326,8 +324,8 @@ static int bench(const char* name, int blocks, bool batched, bool ktime) {
     for (int blk = 0; blk < n; ++blk) {
       const auto t0 = std::chrono::steady_clock::now();
       if (!c1 && batched) {
-        if (blk % 64 == 0) knh_bank_param_apply_many(bank.raw(), N, all_v.data(), st3.data(), p_restart.data(), k_trig.data(), nullptr, nullptr, nullptr);
-        if (blk % 64 == 32) knh_bank_param_apply_many(bank.raw(), N, all_v.data(), st3.data(), p_release.data(), k_trig.data(), nullptr, nullptr, nullptr);
+        if (blk % 64 == 0) bank.param_apply_many(i_restart, Value::Trigger);   // GpuVoiceBank::param_apply_many, lib.rs
+        if (blk % 64 == 32) bank.param_apply_many(i_release, Value::Trigger);
       } else if (!c1) {
         if (blk % 64 == 0) for (size_t i : i_restart) bank.param_apply(ctx, i, Value::Trigger);   // one SchedulingEvent per voice
         if (blk % 64 == 32) for (size_t i : i_release) bank.param_apply(ctx, i, Value::Trigger);

@@ -186,3 +186,45 @@ def test_graph_voice_stage_limits_without_device(knh):
     with pytest.raises(L.KnasterHipError) as e:
         knh.VoiceBank(st, 1, L.F32, 1)
     assert e.value.status == L.ERR_UNSUPPORTED_CHAIN
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference sources are only in the build container")
+def test_rust_sources_name_items_the_reference_has():
+    """bindings/rust/knaster_hip (the shim and examples/dump_golden.rs, which renders the golden cases with the real crate)
+    cannot be compiled here: keep their `use` lines honest by looking every imported item up in the reference's sources, read
+    as text -- the module file must exist and declare the name (`pub struct|enum|trait|fn|type|mod|const X`, or re-export it)."""
+    crates = {"knaster_core": "knaster_core/src", "knaster_core_dsp": "knaster_core_dsp/src", "knaster_graph": "knaster_graph/src"}
+    checked = 0
+    for rel in ("examples/dump_golden.rs", "src/lib.rs"):
+        src = open(os.path.join(ROOT, "bindings", "rust", "knaster_hip", rel)).read()
+        for path, names in re.findall(r"^\s*use ((?:knaster_[a-z_]+)(?:::[a-z_0-9]+)*)::(\{[^}]*\}|[A-Za-z_0-9]+);", src, flags=re.M):
+            parts = path.split("::")
+            crate, mods = parts[0], parts[1:]
+            if crate not in crates:
+                continue
+            items = [n.strip().split(" as ")[0] for n in names.strip("{}").split(",") if n.strip()]
+            base = os.path.join(REFERENCE, crates[crate])
+            # the module's file: src/a/b.rs, src/a/b/mod.rs, or (crate root / re-exported `ugens::*`) anywhere below src/
+            candidates = []
+            if mods and mods[0] != "typenum":
+                for stem in (os.path.join(base, *mods), os.path.join(base, "ugens", *mods)):
+                    candidates += [stem + ".rs", os.path.join(stem, "mod.rs")]
+                candidates = [c for c in candidates if os.path.isfile(c)]
+                assert candidates, f"{rel}: no module file for {path} under {base}"
+            else:
+                # (knaster_core's root re-exports knaster_primitives wholesale: `pub use knaster_primitives::*`, lib.rs:42)
+                for b in [base] + ([os.path.join(REFERENCE, "knaster_primitives/src")] if crate == "knaster_core" else []):
+                    for d, _, files in os.walk(b):
+                        candidates += [os.path.join(d, f) for f in files if f.endswith(".rs")]
+            text = "\n".join(open(c).read() for c in candidates)
+            for item in items:
+                if mods and mods[0] == "typenum":  # a re-exported third-party crate: only that the re-export exists
+                    assert re.search(r"pub use typenum|pub extern crate typenum|pub use [a-z_:]*typenum", text), f"{rel}: {crate} does not re-export typenum"
+                    continue
+                pat = r"pub (?:struct|enum|trait|fn|type|mod|const|use [A-Za-z_0-9:{}, ]*)\s*\b%s\b" % re.escape(item)
+                assert re.search(pat, text), f"{rel}: `{item}` (use {path}::..) is not declared in {[os.path.relpath(c, REFERENCE) for c in candidates][:4]}"
+                checked += 1
+    assert checked >= 10, checked
