@@ -152,6 +152,7 @@ unsafe extern "C" {
     pub fn knh_bank_stage_param_description(bank: *const knh_bank, stage: u32, param: u32) -> *const c_char;
     pub fn knh_bank_param_apply(bank: *mut knh_bank, voice: u32, stage: u32, param: u32, kind: u32, fvalue: f64, ivalue: i64) -> i32;
     pub fn knh_bank_set_delay_within_block_for_param(bank: *mut knh_bank, voice: u32, stage: u32, param: u32, delay: u16) -> i32;
+    pub fn knh_bank_param_apply_range(bank: *mut knh_bank, voice_begin: u32, voice_end: u32, stage: u32, param: u32, kind: u32, fvalue: f64, ivalue: i64) -> i32;
     pub fn knh_bank_param_apply_many(bank: *mut knh_bank, count: usize, voices: *const u32, stages: *const u32, params: *const u32, kinds: *const u32, fvalues: *const f64, ivalues: *const i64, delays: *const u16) -> i32;
     pub fn knh_bank_process_block(bank: *mut knh_bank, frames_to_process: usize, block_start_offset: usize, frame_clock: u64, out: *mut c_void, out_flags: *mut u32) -> i32;
     pub fn knh_jit_stats(memory_hits: *mut u64, disk_hits: *mut u64, helper_compiles: *mut u64, in_process_compiles: *mut u64);

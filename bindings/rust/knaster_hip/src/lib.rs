@@ -228,6 +228,14 @@ impl<F: Float, I: Size> GpuVoiceBank<F, I> {
     pub fn ugens_per_voice(stages: &[Stage]) -> i32 {
         unsafe { knh_chain_ugen_count(stages.as_ptr(), stages.len() as u32) }
     }
+    /// One parameter of the voices `[voice_begin, voice_end)` in ONE call and without an array: a bank's note-on
+    /// (`bank.param_apply_range(0, n, env_stage, t_restart, ParameterValue::Trigger)`).  `param` = the parameter's position in
+    /// the stage's `#[param]` order, as `index()` resolves it from its name.
+    pub fn param_apply_range(&mut self, voice_begin: u32, voice_end: u32, stage: usize, param: usize, value: ParameterValue) -> Result<(), BankError> {
+        let (kind, f, i) = encode_value(value);
+        let rc = unsafe { knh_bank_param_apply_range(self.h, voice_begin, voice_end, stage as u32, param as u32, kind, f, i) };
+        if rc != KNH_OK { Err(last_error(self.h)) } else { Ok(()) }
+    }
     /// One parameter of many voices in ONE call: what a host does with a block's worth of `SchedulingEvent`s for this node
     /// instead of a `param_apply` per event (16 384 single calls cost 170 us of host time, one batched call 11).  `index[k]` as
     /// `index()` gives it; all of them must name the same (stage, parameter).  Envelope triggers for neighbouring voices in

@@ -379,6 +379,14 @@ int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* 
                                   const uint32_t* stages, const uint32_t* params,
                                   const uint32_t* kinds, const double* fvalues,
                                   const int64_t* ivalues, const uint16_t* delays);
+/* knh_bank_param_apply(voice, stage, param, kind, fvalue, ivalue) for every voice of
+ * [voice_begin, voice_end) in rising order -- a bank's note-on, "this cutoff for
+ * all of them" -- without an array per call: the SchedulingEvents a host would
+ * send one by one (graph_gen.rs:269-305), same checks, same result.  An envelope
+ * trigger sent this way (or through knh_bank_param_apply_many with the voices in
+ * rising order) reaches a resident kernel as one 32-byte range event. */
+int32_t knh_bank_param_apply_range(knh_bank* bank, uint32_t voice_begin, uint32_t voice_end, uint32_t stage,
+                                   uint32_t param, uint32_t kind, double fvalue, int64_t ivalue);
 
 /* UGen::process_block(ctx, flags, input, output) -- knaster_core/src/ugen.rs:263-284
  * as called by Task::run (knaster_graph/src/task.rs:25-31).

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "knh_bank_set_delay_within_block_for_param": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint16]),
     "knh_bank_param_apply_many": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "knh_bank_param_apply_range": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int64]),
     "knh_bank_process_block": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]),
     "knh_jit_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "knh_bank_resident_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

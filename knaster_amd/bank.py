@@ -187,6 +187,10 @@ class VoiceBank:
     def param_apply_many(self, voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None, block_offset=0):
         self.param_apply_prepared(self.prepare_many(voices, stages, params, kinds, fvalues, ivalues, delays), block_offset)
 
+    def param_apply_range(self, voice_begin, voice_end, stage, param, kind, fvalue=0.0, ivalue=0):
+        """One parameter of the voices [voice_begin, voice_end), in rising order: knh_bank_param_apply_range."""
+        self._check(self._lib.knh_bank_param_apply_range(self._h, voice_begin, voice_end, stage, param, kind, float(fvalue), int(ivalue)))
+
     @staticmethod
     def prepare_many(voices, stages, params, kinds, fvalues=None, ivalues=None, delays=None):
         """The argument arrays of knh_bank_param_apply_many[_at] in the C layout, made once (a caller that sends the same

@@ -451,6 +451,14 @@ int32_t knh_bank_param_apply_many(knh_bank* bank, size_t count, const uint32_t* 
     return bank->apply_many(0, count, voices, stages, params, kinds, fvalues, ivalues, delays);
   });
 }
+int32_t knh_bank_param_apply_range(knh_bank* bank, uint32_t voice_begin, uint32_t voice_end, uint32_t stage, uint32_t param, uint32_t kind,
+                                   double fvalue, int64_t ivalue) {
+  return guarded(bank, [&]() -> int32_t {
+    if (!bank) return KNH_ERR_INVALID_ARGUMENT;
+    if (voice_end < voice_begin) return bank->fail(KNH_ERR_INVALID_ARGUMENT, "voice_end < voice_begin");
+    return bank->apply_range(voice_begin, voice_end, stage, param, kind, fvalue, ivalue);
+  });
+}
 int32_t knh_bank_process_block(knh_bank* bank, size_t frames_to_process, size_t block_start_offset, uint64_t frame_clock, void* out, uint32_t* out_flags) {
   return guarded(bank, [&]() -> int32_t {
     if (!bank) return KNH_ERR_INVALID_ARGUMENT;

@@ -46,6 +46,23 @@ struct knh_bank {
   virtual int check_call(uint32_t /*voice*/, uint32_t /*stage*/, uint32_t /*param*/, uint32_t /*kind*/) { return KNH_OK; }
   virtual int process(uint32_t n_blocks, size_t ftp, size_t offset, uint64_t clock, void* out_host, void* out_device,
                       void* voices_host, uint32_t* out_flags, void* stream, bool sync, bool accumulate = false) = 0;
+  // knh_bank_param_apply_range: one (stage, parameter, value) for the voices [v0, v1) in rising order -- spelled out as a batch
+  // here; Bank<F> (voice_bank.hpp) keeps an envelope trigger as one range event
+  std::vector<uint32_t> range_scratch[4];
+  std::vector<double> range_f;
+  std::vector<int64_t> range_i;
+  virtual int apply_range(uint32_t v0, uint32_t v1, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t iv) {
+    const size_t n = v1 - v0;
+    if (n == 0) return KNH_OK;
+    range_scratch[0].resize(n);
+    for (size_t k = 0; k < n; ++k) range_scratch[0][k] = v0 + static_cast<uint32_t>(k);
+    range_scratch[1].assign(n, stage);
+    range_scratch[2].assign(n, param);
+    range_scratch[3].assign(n, kind);
+    range_f.assign(n, f);
+    range_i.assign(n, iv);
+    return apply_many(0, n, range_scratch[0].data(), range_scratch[1].data(), range_scratch[2].data(), range_scratch[3].data(), range_f.data(), range_i.data(), nullptr);
+  }
   // knh_bank_param_apply_many[_at]: the calls in array order (block_offset 0 = now); a host-sharded bank spreads them
   // over its threads (host_shards.hpp)
   virtual int apply_many(uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stgs, const uint32_t* params,

@@ -1456,6 +1456,22 @@ struct Bank final : knh_bank {
       default: return true;
     }
   }
+  // knh_bank_param_apply_range: an envelope trigger for the voices [v0, v1) is one range event, in O(1); anything else is the
+  // batch it stands for (bank_base.hpp).
+  int apply_range(uint32_t v0, uint32_t v1, uint32_t stage, uint32_t param, uint32_t kind, double f, int64_t iv) override {
+    if (v1 > v0 && v1 <= nv && v1 - v0 >= 16 && initialised && stage < stages.size() && kind == KNH_VALUE_TRIGGER &&
+        param < static_cast<uint32_t>(stages[stage].n_params) && kind_ok(stages[stage], param, kind) && direct_ok(stages[stage], param) &&
+        (stages[stage].kind == KNH_STAGE_MUL_ENV_ASR || stages[stage].kind == KNH_STAGE_MUL_ENV_AR) &&
+        !(stages[stage].ar_param != 0 && param + 1u == stages[stage].ar_param) && pending_ranges.size() < 64) {
+      const StageInfo& S = stages[stage];
+      note_frame(0u);
+      const bool release = S.kind == KNH_STAGE_MUL_ENV_ASR && param == 2;
+      pending_ranges.push_back(RangeEvent{v0, v1, 0u, release ? static_cast<uint32_t>(knh_dev::EV_ENV_ASR_RELEASE) : static_cast<uint32_t>(knh_dev::EV_SET),
+                                          static_cast<uint32_t>(S.slot_base), release ? 0ull : 1ull, pending.size()});
+      return KNH_OK;
+    }
+    return knh_bank::apply_range(v0, v1, stage, param, kind, f, iv);
+  }
   // knh_bank_param_apply_many[_at]: runs of calls to the same (stage, parameter, kind) -- how a host sends "this parameter
   // of these voices" -- are checked once and turned into patches in one pass; anything else goes call by call.
   int apply_many(uint32_t block_offset, size_t count, const uint32_t* voices, const uint32_t* stgs, const uint32_t* params,
@@ -1496,6 +1512,16 @@ struct Bank final : knh_bank {
         }
       }
       size_t e = k + 1;
+      {  // (64 entries at a time without a branch in between -- the compiler vectorises that -- then the ragged end one by one:
+         // a bank's 16 384 triggers are 200 KB of arrays to look through)
+        const uint32_t s0 = stgs[k], p0 = params[k], k0 = kinds[k];
+        while (e + 64 <= count) {
+          uint32_t d = 0;
+          for (size_t q = e; q < e + 64; ++q) d |= (stgs[q] ^ s0) | (params[q] ^ p0) | (kinds[q] ^ k0);
+          if (d) break;
+          e += 64;
+        }
+      }
       while (e < count && stgs[e] == stgs[k] && params[e] == params[k] && kinds[e] == kinds[k]) ++e;
       bool direct = e - k >= 16 && stgs[k] < stages.size() && params[k] < static_cast<uint32_t>(stages[stgs[k]].n_params) &&
                     kind_ok(stages[stgs[k]], params[k], kinds[k]) && direct_ok(stages[stgs[k]], params[k]);
@@ -1528,7 +1554,13 @@ struct Bank final : knh_bank {
         HostEvent t{0u, frame, release ? static_cast<uint32_t>(knh_dev::EV_ENV_ASR_RELEASE) : static_cast<uint32_t>(knh_dev::EV_SET), static_cast<uint32_t>(S.slot_base), release ? 0ull : 1ull};
         {  // neighbouring voices in rising order (the usual way to address a bank): one range event
           bool run = voices[e - 1] < nv && pending_ranges.size() < 64;
-          for (size_t q = k + 1; q < e && run; ++q) run = voices[q] == voices[q - 1] + 1u;
+          size_t q = k + 1;
+          for (; q + 64 <= e && run; q += 64) {  // (branch-free runs of 64, as above)
+            uint32_t d = 0;
+            for (size_t j = q; j < q + 64; ++j) d |= voices[j] - voices[j - 1] - 1u;
+            run = d == 0;
+          }
+          for (; q < e && run; ++q) run = voices[q] == voices[q - 1] + 1u;
           if (run) {
             pending_ranges.push_back(RangeEvent{voices[k], voices[e - 1] + 1u, frame, t.op, t.slot, t.bits, pending.size()});
             k = e;

@@ -175,6 +175,11 @@ class GpuVoiceBank {
     const uint32_t k = kind == Value::Float ? KNH_VALUE_FLOAT : kind == Value::Trigger ? KNH_VALUE_TRIGGER : kind == Value::Integer ? KNH_VALUE_INTEGER : KNH_VALUE_BOOL;
     return knh_bank_param_apply(h_, static_cast<uint32_t>(rest / n_stages_), static_cast<uint32_t>(rest % n_stages_), static_cast<uint32_t>(param), k, f, i);
   }
+  // lib.rs: GpuVoiceBank::param_apply_range -> knh_bank_param_apply_range: one parameter of the voices [voice_begin, voice_end)
+  int32_t param_apply_range(uint32_t voice_begin, uint32_t voice_end, size_t stage, size_t param, Value kind, double f = 0.0, int64_t i = 0) {
+    const uint32_t k = kind == Value::Float ? KNH_VALUE_FLOAT : kind == Value::Trigger ? KNH_VALUE_TRIGGER : kind == Value::Integer ? KNH_VALUE_INTEGER : KNH_VALUE_BOOL;
+    return knh_bank_param_apply_range(h_, voice_begin, voice_end, static_cast<uint32_t>(stage), static_cast<uint32_t>(param), k, f, i);
+  }
   // lib.rs: GpuVoiceBank::param_apply_many -> knh_bank_param_apply_many: one parameter of many voices in one call
   int32_t param_apply_many(const std::vector<size_t>& indices, Value kind, double f = 0.0, int64_t i = 0) {
     const uint32_t k = kind == Value::Float ? KNH_VALUE_FLOAT : kind == Value::Trigger ? KNH_VALUE_TRIGGER : kind == Value::Integer ? KNH_VALUE_INTEGER : KNH_VALUE_BOOL;

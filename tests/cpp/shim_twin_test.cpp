@@ -297,7 +297,7 @@ static void gpu_inputs_and_audio_rate_buffer() {
 // batched: a block's triggers go through ONE knh_bank_param_apply_many call (what a host that hands its events over in
 // batches does) instead of one knh_bank_param_apply per voice (what GraphGen::apply_parameter_change does per SchedulingEvent)
 // ktime: also measure the voice kernel's device time per call (a timed bank launches a kernel per call: no resident kernel)
-static int bench(const char* name, int blocks, bool batched, bool ktime) {
+static int bench(const char* name, int blocks, bool batched, bool ktime, bool many) {
   const bool c1 = !std::strcmp(name, "C1");
   const char* nv_env = std::getenv("TWIN_VOICES");  // (diagnostics: the C3 voice at another bank size)
   const int N = c1 ? 1 : (nv_env ? std::atoi(nv_env) : 16384), B = c1 ? 64 : 512, UGENS = c1 ? 3 : 4;
@@ -324,8 +324,13 @@ static int bench(const char* name, int blocks, bool batched, bool ktime) {
     for (int blk = 0; blk < n; ++blk) {
       const auto t0 = std::chrono::steady_clock::now();
       if (!c1 && batched) {
-        if (blk % 64 == 0) bank.param_apply_many(i_restart, Value::Trigger);   // GpuVoiceBank::param_apply_many, lib.rs
-        if (blk % 64 == 32) bank.param_apply_many(i_release, Value::Trigger);
+        if (many) {
+          if (blk % 64 == 0) bank.param_apply_many(i_restart, Value::Trigger);   // GpuVoiceBank::param_apply_many, lib.rs
+          if (blk % 64 == 32) bank.param_apply_many(i_release, Value::Trigger);
+        } else {
+          if (blk % 64 == 0) bank.param_apply_range(0, uint32_t(N), 3, 3, Value::Trigger);   // GpuVoiceBank::param_apply_range: t_restart of the EnvAsr stage
+          if (blk % 64 == 32) bank.param_apply_range(0, uint32_t(N), 3, 2, Value::Trigger);  // t_release
+        }
       } else if (!c1) {
         if (blk % 64 == 0) for (size_t i : i_restart) bank.param_apply(ctx, i, Value::Trigger);   // one SchedulingEvent per voice
         if (blk % 64 == 32) for (size_t i : i_release) bank.param_apply(ctx, i, Value::Trigger);
@@ -367,7 +372,7 @@ static int bench(const char* name, int blocks, bool batched, bool ktime) {
               "\"us_per_block_p99\": %.3f, \"us_per_block_min\": %.3f, \"voice_kernel_us_per_block\": %.3f, \"output_peak\": %.4g, "
               "\"resident_calls\": %ld, \"device_us_after_the_voice_kernel_saw_the_command\": {\"fold_server_saw_it\": %.2f, \"first_tile_complete\": %.2f, \"last_tile_complete\": %.2f, \"block_and_flags_written\": %.2f}, "
               "\"trigger_blocks\": {\"n\": %ld, \"parameter_calls_us\": %.2f, \"process_call_us\": %.2f, \"device_first_tile_complete\": %.2f, \"device_block_and_flags_written\": %.2f}}\n",
-              name, batched ? "a block's triggers in one knh_bank_param_apply_many" : "single-call param_apply per event", ktime ? "true" : "false", N, B, blocks, rate, secs * 1e6 / blocks, us[us.size() / 2], us[size_t(us.size() * 0.99)], us.front(),
+              name, batched ? (many ? "a block's triggers in one knh_bank_param_apply_many" : "a block's triggers in one knh_bank_param_apply_range") : "single-call param_apply per event", ktime ? "true" : "false", N, B, blocks, rate, secs * 1e6 / blocks, us[us.size() / 2], us[size_t(us.size() * 0.99)], us.front(),
               launches ? kms * 1e3 / double(launches) : 0.0, peak, trace_n, trace_n ? trace_us[0] / trace_n : 0.0, trace_n ? trace_us[1] / trace_n : 0.0,
               trace_n ? trace_us[2] / trace_n : 0.0, trace_n ? trace_us[3] / trace_n : 0.0,
               trig_n, trig_n ? trig_apply_us / trig_n : 0.0, trig_n ? trig_process_us / trig_n : 0.0, trig_n ? trig_trace_us[1] / trig_n : 0.0, trig_n ? trig_trace_us[3] / trig_n : 0.0);
@@ -381,9 +386,13 @@ int main(int argc, char** argv) {
     gpu = gpu || !std::strcmp(argv[i], "--gpu");
     if (!std::strcmp(argv[i], "--bench")) {
       if (knh_device_count() < 1) { std::printf("no gfx950 device\n"); return 2; }
-      bool batched = false, ktime = false;
-      for (int k = i + 1; k < argc; ++k) { batched = batched || !std::strcmp(argv[k], "batched"); ktime = ktime || !std::strcmp(argv[k], "ktime"); }
-      return bench(i + 1 < argc ? argv[i + 1] : "C3", i + 2 < argc && std::atoi(argv[i + 2]) > 0 ? std::atoi(argv[i + 2]) : 1024, batched, ktime);
+      bool batched = false, ktime = false, many = false;  // "batched": one range call per block's triggers; "many": one array call
+      for (int k = i + 1; k < argc; ++k) {
+        batched = batched || !std::strcmp(argv[k], "batched") || !std::strcmp(argv[k], "many");
+        many = many || !std::strcmp(argv[k], "many");
+        ktime = ktime || !std::strcmp(argv[k], "ktime");
+      }
+      return bench(i + 1 < argc ? argv[i + 1] : "C3", i + 2 < argc && std::atoi(argv[i + 2]) > 0 ? std::atoi(argv[i + 2]) : 1024, batched, ktime, many);
     }
   }
   if (!cpu && !gpu) cpu = true;

@@ -152,6 +152,9 @@ def test_range_events_for_parts_of_the_bank(knh, monkeypatch):
                 bank.param_apply_many(v[i * 30: i * 30 + 40], on[0] if i % 3 else off[0], on[1] if i % 3 else off[1], L.VALUE_TRIGGER)
         if b == 8:  # (a split block: the triggers belong to its first part)
             bank.param_apply_many(v[3:690], on[0], on[1], L.VALUE_TRIGGER)
+        if b == 9:  # knh_bank_param_apply_range: triggers (a range event as it stands) and a float for a run of voices (spelled out)
+            bank.param_apply_range(40, 660, on[0], on[1], L.VALUE_TRIGGER)
+            bank.param_apply_range(100, 200, 0, 0, L.VALUE_FLOAT, 321.0)
         if b == 10:
             bank.param_apply_many(v[::-1].copy(), off[0], off[1], L.VALUE_TRIGGER)  # falling order: not a range
 
@@ -179,3 +182,37 @@ def test_range_events_for_parts_of_the_bank(knh, monkeypatch):
     np.testing.assert_array_equal(a[1], b[1])
     assert np.abs(np.stack(b[0])).max() > 1e-5
     assert a[2] == (13, 1), a[2]
+
+
+def test_param_apply_range_is_the_batch_it_stands_for(knh, monkeypatch):
+    """knh_bank_param_apply_range(v0, v1, ..) against knh_bank_param_apply_many for the same voices: triggers, floats, a filter
+    parameter (per-voice coefficient patches), an empty range, bad ranges and kinds refused with the batch's codes."""
+    monkeypatch.setenv("KNH_RESIDENT", "0")
+    w = configs.config("C3", n_voices=300, block_size=64)
+    a, b = make_gpu(knh, w, L.MIX_TREE), make_gpu(knh, w, L.MIX_TREE)
+    v = np.arange(300, dtype=np.uint32)
+    for blk in range(8):
+        if blk == 0:
+            a.param_apply_range(0, 300, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+            b.param_apply_many(v, w.restart[0], w.restart[1], L.VALUE_TRIGGER)
+        if blk == 2:
+            a.param_apply_range(10, 200, 2, 0, L.VALUE_FLOAT, 1234.5)   # SvfFilter cutoff
+            b.param_apply_many(v[10:200], 2, 0, L.VALUE_FLOAT, 1234.5)
+            a.param_apply_range(5, 5, 0, 0, L.VALUE_FLOAT, 99.0)        # nobody
+        if blk == 4:
+            a.param_apply_range(7, 23, w.release[0], w.release[1], L.VALUE_TRIGGER)  # a short run, and a single voice
+            b.param_apply_many(v[7:23], w.release[0], w.release[1], L.VALUE_TRIGGER)
+            a.param_apply_range(250, 251, 0, 0, L.VALUE_FLOAT, 777.0)
+            b.param_apply(250, 0, 0, 777.0)
+        if blk == 5:
+            for bad in ((290, 301, 0, 0, L.VALUE_FLOAT), (0, 10, 9, 0, L.VALUE_FLOAT), (0, 10, 0, 0, L.VALUE_TRIGGER), (20, 10, 0, 0, L.VALUE_FLOAT)):
+                with pytest.raises(L.KnasterHipError):
+                    a.param_apply_range(*bad, 1.0)
+            b.param_apply_many(v[290:300], 0, 0, L.VALUE_FLOAT, 1.0)  # (the in-range part of the first bad call is applied, as a batch's would be)
+        x, fa = a.process_block()
+        y, fb = b.process_block()
+        assert_bit_equal(x, y, f"block {blk}")
+        assert fa == fb
+    np.testing.assert_array_equal(a.read_done_frames(), b.read_done_frames())
+    a.close()
+    b.close()

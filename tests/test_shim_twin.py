@@ -58,6 +58,7 @@ def test_shim_twin_makes_the_shims_calls():
         "new": (r"pub fn with_options\(", r"GpuVoiceBank\(const std::vector<knh_stage_desc>& stages"),
         "drop": (r"fn drop\(&mut self\)", r"~GpuVoiceBank\(\)"),
         "index": (r"pub fn index\(&self", r"size_t index\(uint32_t voice"),
+        "param_apply_range": (r"pub fn param_apply_range\(&mut self, voice_begin: u32", r"int32_t param_apply_range\(uint32_t voice_begin"),
         "param_apply_many": (r"pub fn param_apply_many\(&mut self, indices: &\[usize\], value: ParameterValue\)", r"int32_t param_apply_many\(const std::vector<size_t>& indices"),
     }
     for method, (r_pat, c_pat) in pairs.items():
