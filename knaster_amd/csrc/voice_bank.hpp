@@ -367,7 +367,7 @@ struct Bank final : knh_bank {
   uint64_t *d_res_rows = nullptr, *d_res_wg_flags = nullptr, *d_res_group_rows = nullptr, *d_res_group_flags = nullptr;  // granules (voice_chain.hpp)
   uint32_t *d_res_arrivals = nullptr, *d_res_group_arrivals = nullptr;
   hipStream_t res_stream = nullptr;    // the fold server runs beside the voice kernel
-  F* h_res_out = nullptr;              // mapped pinned: [channels][block_size]
+  uint64_t* h_res_out = nullptr;       // mapped pinned: the block as the fold server's root leaves it, granules {sample bits, tag}: [plane][block_size][W], then the flags granule
   uint32_t* h_res_done = nullptr;      // mapped pinned: epoch, done count, running count
   uint32_t res_max_tiles = 0;
   uint32_t res_cooldown = 0;           // calls to sit out after another bank asked this one to leave
@@ -482,7 +482,11 @@ struct Bank final : knh_bank {
     }
     KNH_HIP(hipMalloc(&d_res_relay, 1024));  // the command word, and (words 16 ..) a call's range events (voice_chain.hpp RES_RELAY_RANGES)
     KNH_HIP(hipMemset(d_res_relay, 0xFF, 1024));
-    KNH_HIP(hipHostMalloc(&h_res_out, desc.out_channels * block_size * sizeof(F), hipHostMallocMapped | hipHostMallocCoherent));
+    {
+      const size_t n_gran = 2 * static_cast<size_t>(block_size) * (sizeof(F) == 8 ? 2 : 1) + 8;
+      KNH_HIP(hipHostMalloc(&h_res_out, n_gran * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
+      std::memset(h_res_out, 0xFF, n_gran * sizeof(uint64_t));  // (a tag no call carries)
+    }
     KNH_HIP(hipHostMalloc(&h_res_done, 256, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h_res_done, 0, 256);
     h_res_done[0] = 0xFFFFFFFFu; h_res_done[1] = 0u; h_res_done[2] = 0u; h_res_done[4] = 0xFFFFFFFFu; h_res_done[5] = 0xFFFFFFFFu;
@@ -546,7 +550,7 @@ struct Bank final : knh_bank {
       sa.wg_flags = reinterpret_cast<const knh_dev::u64*>(d_res_wg_flags);
       sa.group_rows = reinterpret_cast<knh_dev::u64*>(d_res_group_rows);
       sa.group_flags = reinterpret_cast<knh_dev::u64*>(d_res_group_flags);
-      sa.host_out = h_res_out;
+      sa.host_out = reinterpret_cast<knh_dev::u64*>(h_res_out);
       sa.host_done = h_res_done;
       sa.idle_ticks = res_idle_ticks;
       sa.first_epoch = first_epoch;
@@ -606,54 +610,107 @@ struct Bank final : knh_bank {
     };
     { int rc = ring(); if (rc != KNH_OK) return rc; }
     res_calls += 1;
-    volatile uint32_t* ep = h_res_done;
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t spin = 1;; ++spin) {
-      if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == epoch) break;
-      if ((spin & 0x3FFFu) == 0) {
-        const hipError_t q = hipStreamQuery(own_stream);
-        if (q == hipSuccess) {
-          // The kernel has ended by itself (the host was away for longer than its patience) just as this command was written.
-          // Its workgroup 0 left "leave" in the relay under THIS epoch, so the command goes out again under the next one, to a
-          // new launch.
-          if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == epoch) break;
-          if (res_debug()) std::fprintf(stderr, "[knh resident] the kernel ended without answering epoch %u (done word %u, %.3f ms into the call, server stream %s; root wavefronts at %x %x %x %x)\n", epoch, h_res_done[0],
-                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), hipStreamQuery(res_stream) == hipSuccess ? "idle" : "busy",
-                                        h_res_done[20], h_res_done[21], h_res_done[22], h_res_done[23]);
-          // (its fold server has then heard "leave" over the relay too.  A server that is still busy was in the middle of a
-          // call: the voice kernel took the command, and taking it again would render the block twice.)
-          hipError_t qs = hipStreamQuery(res_stream);
-          for (int k = 0; k < 200 && qs == hipErrorNotReady; ++k) { std::this_thread::sleep_for(std::chrono::microseconds(500)); qs = hipStreamQuery(res_stream); }
-          res_on = false;
-          if (qs != hipSuccess) {
-            res_policy = 0;
-            (void)res_leave_locked(false);
-            return fail(KNH_ERR_DEVICE, "the resident voice kernel ended in the middle of a call (its mix never arrived)");
+    // Waits for something the device stores (`ready`): 0 = there; kRestart = the kernel had ended by itself and the command has
+    // gone out again under a new epoch (whatever was read so far belongs to no call: start over); anything else = an error.
+    constexpr int kRestart = -12345;
+    auto wait_for = [&](auto&& ready) -> int {
+      for (uint64_t spin = 1;; ++spin) {
+        if (ready()) return 0;
+        if ((spin & 0x3FFFu) == 0) {
+          const hipError_t q = hipStreamQuery(own_stream);
+          if (q == hipSuccess) {
+            // The kernel has ended by itself (the host was away for longer than its patience) just as this command was written.
+            // Its workgroup 0 left "leave" in the relay under THIS epoch, so the command goes out again under the next one, to a
+            // new launch.
+            if (ready()) return 0;
+            if (res_debug()) std::fprintf(stderr, "[knh resident] the kernel ended without answering epoch %u (done word %u, %.3f ms into the call, server stream %s; root wavefronts at %x %x %x %x)\n", epoch, h_res_done[0],
+                                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), hipStreamQuery(res_stream) == hipSuccess ? "idle" : "busy",
+                                          h_res_done[20], h_res_done[21], h_res_done[22], h_res_done[23]);
+            // (its fold server has then heard "leave" over the relay too.  A server that is still busy was in the middle of a
+            // call: the voice kernel took the command, and taking it again would render the block twice.)
+            hipError_t qs = hipStreamQuery(res_stream);
+            for (int k = 0; k < 200 && qs == hipErrorNotReady; ++k) { std::this_thread::sleep_for(std::chrono::microseconds(500)); qs = hipStreamQuery(res_stream); }
+            res_on = false;
+            if (qs != hipSuccess) {
+              res_policy = 0;
+              (void)res_leave_locked(false);
+              return fail(KNH_ERR_DEVICE, "the resident voice kernel ended in the middle of a call (its mix never arrived)");
+            }
+            int rc = ring();
+            if (rc != KNH_OK) return rc;
+            return kRestart;
+          } else if (q != hipErrorNotReady) {
+            res_on = false;
+            return fail(KNH_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
           }
-          int rc = ring();
-          if (rc != KNH_OK) return rc;
-        } else if (q != hipErrorNotReady) {
-          res_on = false;
-          return fail(KNH_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+            return fail(KNH_ERR_DEVICE, "the resident kernel did not answer within 10 s");
+          }
         }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
-          return fail(KNH_ERR_DEVICE, "the resident kernel did not answer within 10 s");
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+    };
+    // The block arrives tile by tile as granules {sample bits, tag = epoch << 8 | tile}: every frame is taken the moment its
+    // tag is there (the early tiles while the kernel is still at the later ones), a mono mix copied to every channel; the
+    // call's done / running counts come as one more granule behind the last tile.
+    constexpr size_t W = sizeof(F) == 8 ? 2 : 1;
+    const uint32_t n = fe - fb, tf = res_tile_frames(), planes = fold_planes;
+    F* const out = static_cast<F*>(out_host);
+    uint64_t flag_word = 0;
+    for (bool again = true; again;) {
+      again = false;
+      for (uint32_t rel = 0; rel < n && !again; ++rel) {
+        const uint32_t tag = (epoch << 8) | ((rel / tf) & 0xFFu);
+        for (uint32_t p = 0; p < planes && !again; ++p) {
+          volatile uint64_t* g = h_res_out + (static_cast<size_t>(p) * block_size + fb + rel) * W;
+          // (the device's stores took these lines out of the CPU's caches: a tile that has landed is eight cache misses in a row
+          // unless they are asked for together -- 0.7 us at the end of every call)
+          if ((reinterpret_cast<uintptr_t>(g) & 63u) == 0) {
+            __builtin_prefetch(const_cast<const uint64_t*>(g) + 8, 0, 3);
+            __builtin_prefetch(const_cast<const uint64_t*>(g) + 16, 0, 3);
+            __builtin_prefetch(const_cast<const uint64_t*>(g) + 24, 0, 3);
+            __builtin_prefetch(const_cast<const uint64_t*>(g) + 32, 0, 3);
+          }
+          uint64_t w0 = 0, w1 = 0;
+          auto ready = [&]() -> bool {
+            w0 = __atomic_load_n(g, __ATOMIC_RELAXED);
+            if (static_cast<uint32_t>(w0 >> 32) != tag) return false;
+            if (W == 2) { w1 = __atomic_load_n(g + 1, __ATOMIC_RELAXED); if (static_cast<uint32_t>(w1 >> 32) != tag) return false; }
+            return true;
+          };
+          if (!ready()) {
+            const int rc = wait_for(ready);
+            if (rc == kRestart) { again = true; break; }
+            if (rc != 0) return rc;
+          }
+          F v;
+          if (W == 1) { const uint32_t bits = static_cast<uint32_t>(w0); std::memcpy(&v, &bits, sizeof(F) < 4 ? sizeof(F) : 4); }
+          else { const uint64_t bits = (w0 & 0xFFFFFFFFull) | (w1 << 32); std::memcpy(&v, &bits, sizeof(F)); }
+          if (planes == 2) out[static_cast<size_t>(p) * block_size + fb + rel] = v;
+          else for (uint32_t c = 0; c < desc.out_channels; ++c) out[static_cast<size_t>(c) * block_size + fb + rel] = v;
         }
       }
-#if defined(__x86_64__)
-      __builtin_ia32_pause();
-#endif
+      if (again) continue;
+      volatile uint64_t* gf = h_res_out + static_cast<size_t>(planes) * block_size * W;
+      const uint32_t ftag = (epoch << 8) | 255u;
+      auto fready = [&]() -> bool { flag_word = __atomic_load_n(gf, __ATOMIC_RELAXED); return static_cast<uint32_t>(flag_word >> 32) == ftag; };
+      if (!fready()) {
+        const int rc = wait_for(fready);
+        if (rc == kRestart) { again = true; continue; }
+        if (rc != 0) return rc;
+      }
     }
-    const size_t n = fe - fb;
-    for (uint32_t c = 0; c < desc.out_channels; ++c)
-      std::memcpy(static_cast<F*>(out_host) + c * block_size + fb, h_res_out + c * block_size + fb, n * sizeof(F));
     if (out_flags) {
       uint32_t fl = 0;
-      if (h_res_done[1]) fl |= KNH_FLAG_ANY_DONE;
+      const uint32_t n_done = static_cast<uint32_t>(flag_word) & 0xFFFFu, n_run = (static_cast<uint32_t>(flag_word) >> 16) & 0xFFFFu;
+      if (n_done) fl |= KNH_FLAG_ANY_DONE;
       bool has_env = false;
       for (const StageInfo& st : stages) has_env = has_env || st.kind == KNH_STAGE_MUL_ENV_ASR || st.kind == KNH_STAGE_MUL_ENV_AR || st.kind == KNH_STAGE_MUL_ENVELOPE ||
                           st.kind == KNH_STAGE_BUFFER_READER;
-      if (has_env && h_res_done[2] == 0) fl |= KNH_FLAG_ALL_DONE;
+      if (has_env && n_run == 0) fl |= KNH_FLAG_ALL_DONE;
       *out_flags = fl;
     }
     return KNH_OK;

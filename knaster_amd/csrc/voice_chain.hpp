@@ -349,6 +349,14 @@ struct Resident {
 __device__ __forceinline__ u32 res_tag(u32 epoch, u32 tile) { return (epoch << 8) | (tile & 0xFFu); }
 __device__ __forceinline__ void res_put(u64* g, u32 data, u32 tag) { __hip_atomic_store(g, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 res_get(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... and the same word stored to mapped host memory (the root of the fold server: the host reads a frame's sum the moment its tag is there)
+__device__ __forceinline__ void res_put_host(u64* g, u32 data, u32 tag) { __hip_atomic_store(g, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void res_put_host_sample(u64* g, float v, u32 tag) { res_put_host(g, __builtin_bit_cast(u32, v), tag); }
+__device__ __forceinline__ void res_put_host_sample(u64* g, double v, u32 tag) {
+  const u64 b = __builtin_bit_cast(u64, v);
+  res_put_host(g, (u32)b, tag);
+  res_put_host(g + 1, (u32)(b >> 32), tag);
+}
 template <typename F> struct ResWords { static constexpr int value = sizeof(F) == 8 ? 2 : 1; };
 __device__ __forceinline__ void res_put_sample(u64* g, float v, u32 tag) { res_put(g, __builtin_bit_cast(u32, v), tag); }
 __device__ __forceinline__ void res_put_sample(u64* g, double v, u32 tag) {
@@ -584,7 +592,9 @@ struct ResServerArgs {
   const u64* wg_flags;   // [row]
   u64* group_rows;       // [tile][plane][8][64][W]
   u64* group_flags;      // [8]
-  F* host_out;           // mapped pinned host memory: [channels][block_size]
+  u64* host_out;         // mapped pinned host memory: the block as granules, [plane][block_size][W], then one granule for the call's
+                         // done / running counts: every frame's sum carries its own tag, so the host needs no "everything is there"
+                         // word behind them -- and the device no wait for its stores between the last tile and such a word (1.5 us of a call)
   const u64* bell;       // the command word itself when it lives in device memory (Resident::bell_is_device), else null: the relay is read
   u32* host_done;        // mapped pinned: [0] epoch of the last finished call, [1] voices that marked done, [2] voices still running,
                          // [5] first_epoch once the server's first workgroup runs; [8..9] the voice kernel saw the call's command,
@@ -725,8 +735,7 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
             n_run += root ? (d >> 16) : ((d >> 8) & 0xFFu);
           }
           if (writes_host) {
-            __hip_atomic_store(&a.host_done[1], n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&a.host_done[2], n_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            res_put_host(a.host_out + (long)a.planes * a.block_size * W, n_done | (n_run << 16), tag);
           } else {
             res_put(a.group_flags + g, n_done | (n_run << 16), tag);
           }
@@ -739,10 +748,8 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
           }
           const F node = in_g == 32u ? tree_reduce<F, 32, true>(v, 1u, 32u) : tree_reduce<F, 32, false>(v, 1u, in_g);
           if (writes_host) {
-            // the root, straight into the host's block: a mono mix goes to every channel, a Pan2 chain's planes are the channels
-            F* const out = a.host_out + call.frame_begin + rel + lane;
-            if (a.planes == 2u) __hip_atomic_store(out + (long)p * a.block_size, node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            else for (u32 ch = 0; ch < a.out_channels; ++ch) __hip_atomic_store(out + (long)ch * a.block_size, node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the root, straight into the host's staging block (the host copies a mono mix to every channel; a Pan2 chain's planes are the channels)
+            res_put_host_sample(a.host_out + ((long)p * a.block_size + call.frame_begin + rel + lane) * W, node, tag);
           } else {
             res_put_sample(a.group_rows + ((((long)t * a.planes + p) * 8 + g) * 64 + lane) * W, node, tag);
           }
@@ -750,13 +757,11 @@ __global__ void __launch_bounds__(256, 3) res_fold_server(ResServerArgs<F> a) {
       }
       if (gave_up) return;  // (the voice kernel went away in mid-call: nothing to wait for; a wavefront that has ended no longer counts at the barrier)
     }
-    if (writes_host) {
-      if (lane == 0u) __hip_atomic_store(&a.host_done[20 + wv], 0x300u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what this wavefront wrote to the host's block (and flags) is there
-      __syncthreads();                                   // ... and what the others wrote
-      if (threadIdx.x == 0u) {
+    if (writes_host && lane == 0u) {  // (diagnostics only: nothing waits for these)
+      __hip_atomic_store(&a.host_done[20 + wv], 0x300u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((n_tiles % NW) == wv) {  // the wavefront that had the flags pass, the call's last piece of work
         __hip_atomic_store(reinterpret_cast<u64*>(a.host_done + 16), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&a.host_done[0], call.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.host_done[0], call.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
