@@ -888,6 +888,28 @@ template <int N, typename F> __device__ __forceinline__ F wave_tree_fold(const F
   return FoldLevels<0, N, false, F>::run(cold, x);
 }
 
+// An envelope stage in a kernel whose wavefronts have 256 registers or fewer (eight and more wavefronts per workgroup): a
+// 64-sample visit is two tiles of 32 to it.  The envelope's rarer paths hold a second array of T values, and with 64 of each
+// the eight-wavefront f32 kernel spilled 264 bytes per lane -- in this stage, whose cycles grew fourfold from one wavefront per
+// SIMD to two where the filter's grew 1.8-fold (tools/wide_stamps.py): 262 144 voices 75.8 -> 70.9 us per block on one box.
+// Two tiles in a row are the same samples (every path of the stage is the per-sample sequence, value for value).  The
+// four-wavefront kernels (512 registers) keep the single 64-sample tile: split, they lose 3 %.
+template <typename S, int BYTES> struct TightEnv : S {  // BYTES: the longest tile the stage is given, in bytes of samples
+  template <typename F, bool FMA, int T>
+  static __device__ __forceinline__ void tick_tile(typename S::template Regs<F>& r, F (&x)[T], const Ctx& c, u32 frame0, u32& done_frame) {
+    constexpr int M = BYTES / (int)sizeof(F);
+    if constexpr (T > M && T % M == 0 && M >= 8) {
+#pragma unroll
+      for (int h = 0; h < T / M; ++h) S::template tick_tile<F, FMA, M>(r, *reinterpret_cast<F(*)[M]>(&x[h * M]), c, frame0 + (u32)(h * M), done_frame);
+    } else {
+      S::template tick_tile<F, FMA, T>(r, x, c, frame0, done_frame);
+    }
+  }
+};
+template <int WAVES, typename S> struct ForWaves { typedef S type; };
+template <bool AR> struct ForWaves<8, MulEnvT<AR>> { typedef TightEnv<MulEnvT<AR>, 128> type; };
+template <bool AR> struct ForWaves<16, MulEnvT<AR>> { typedef TightEnv<MulEnvT<AR>, 32> type; };  // (128 registers: eight f32 samples at a time)
+
 // LDS: the sine table (64 KiB, only if a stage uses it) + eight rows of 64 samples per wavefront for the sample-by-sample path.
 // WAVES = wavefronts (64-voice groups) per workgroup sharing the table: 1 for small banks, 4, 8 or 16 when
 // the bank has more 64-voice groups than the chip has SIMDs to give each its own (throughput regime).
@@ -895,7 +917,7 @@ template <int N, typename F> __device__ __forceinline__ F wave_tree_fold(const F
 // voices by wave_tree_fold (above) and the sums go straight to the wavefront's partial row.
 template <typename F, bool FMA, int WAVES, typename... S>
 __global__ void __launch_bounds__(WAVES * 64) voice_kernel(VoiceKernelArgs<F> a) {
-  typedef typename ChainSelect<(SlotCount<S...>::value > 0), F, FMA, S...>::type ChainT;
+  typedef typename ChainSelect<(SlotCount<S...>::value > 0), F, FMA, typename ForWaves<WAVES, S>::type...>::type ChainT;
   typedef typename WordOf<F>::type W;
   // samples evaluated stage by stage in registers per visit: 32 (the per-visit costs -- event test, the filter's choice of step,
   // register set-up around its fixed-register code -- are paid a quarter as often as with the eight of rounds 1-2:
