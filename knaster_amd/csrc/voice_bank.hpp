@@ -961,7 +961,11 @@ struct Bank final : knh_bank {
     const char* jp = std::getenv("KNH_JIT_PIPE");
     // (a single voice group with a pre-built kernel stays on it: nothing to gain, and no compile at init)
     // (a voice that is a graph, not a chain, runs in the single-wave form: the pipeline's edges carry one signal)
-    const bool pipe_jit = !interp && !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= 512 && !(jp && jp[0] == '0') &&
+    // (the pipeline covers two rounds of 256 voice groups in f32; one in f64 and for chains with a delay, whose rings want as
+    // many wavefronts as there are to keep requests in flight: the thresholds of the pre-built chains, bank.hip make_bank)
+    // (a chain with a pre-built one-wavefront kernel but no pre-built wide form keeps the fused pipeline up to 512 groups)
+    const unsigned jit_pipe_max = !entry && (sizeof(F) == 8 || signature.find_first_of("DYZ") != std::string::npos) ? 256u : 512u;
+    const bool pipe_jit = !interp && !pipe && !dag && wide_waves == 0 && pipeline_level >= 1 && n_groups <= jit_pipe_max && !(jp && jp[0] == '0') &&
                           !(entry && n_groups == 1) && !signature_is_dag(signature);
     if (pipe_jit) {
       std::string why;
@@ -977,7 +981,7 @@ struct Bank final : knh_bank {
       // chains (make_bank); round 3 gave every fused voice group a workgroup, and a 64 KiB table staging, of its own.
       // A voice that is a graph keeps the one-wavefront form (its signals' registers leave no room to share a SIMD).
       // KNH_JIT_WAVES=1|4|8|16 overrides (tests: the filter's steps at one, two and four wavefronts per SIMD).
-      unsigned jw = !signature_is_dag(signature) && n_groups > 512 ? (n_groups <= 1024 ? 4u : 8u) : 1u;
+      unsigned jw = !signature_is_dag(signature) && n_groups > jit_pipe_max ? (n_groups <= 1024 ? 4u : 8u) : 1u;
       if (const char* e = std::getenv("KNH_JIT_WAVES")) { const int v = std::atoi(e); if ((v == 1 || v == 4 || v == 8 || v == 16) && !signature_is_dag(signature)) jw = static_cast<unsigned>(v); }
       if (sizeof(F) == 8 && jw == 16) jw = 8;  // (sixteen f64 tiles do not fit beside the table)
       jit = knh::jit_voice_kernel(signature.c_str(), sizeof(F) == 8, desc.allow_fma != 0, &why, jw);

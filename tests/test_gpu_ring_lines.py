@@ -133,3 +133,30 @@ def test_wide_delay_bank_equals_the_pipeline(knh, monkeypatch):
     assert np.abs(outs[0]).max() > 1e-3
     assert_bit_equal(outs[1], outs[0], "eight wavefronts per workgroup against the pipeline")
     assert_bit_equal(outs[2], outs[0], "four wavefronts per workgroup against the pipeline")
+
+
+def test_a_fused_delay_chain_beyond_one_pipeline_round(knh, monkeypatch):
+    """A chain with a delay and no pre-built kernel, 266 voice groups: fused at init as four whole-chain wavefronts per
+    workgroup (one round of the pipeline covers 256 groups; rings want more wavefronts in flight, not a second round) -- the same
+    bits as the one-wavefront form."""
+    n, bs, blocks = 17000, 128, 3
+    p = configs.voice_parameters(n)
+    v = np.arange(n, dtype=np.uint32)
+    w = configs.Workload("allpass_big", [Stage(L.STAGE_SIN_WT), Stage(L.STAGE_WR_MUL), Stage(L.STAGE_ALLPASS_FB_DELAY), Stage(L.STAGE_MUL_CONST)],
+                         n, bs, L.F32, 2)
+    w.ctor = {0: p["freq"].reshape(n, 1), 1: np.full((n, 1), 0.5), 2: np.full((n, 1), 0.0101), 3: np.full((n, 1), 1.0 / n)}
+    outs = []
+    for env in ({}, {"KNH_PIPELINE": "0", "KNH_JIT_WAVES": "1"}):
+        for k in ("KNH_PIPELINE", "KNH_WIDE", "KNH_JIT_WAVES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        b = make_gpu(knh, w)
+        b.param_apply_many(v, 2, 1, L.VALUE_FLOAT, 0.3 + 0.00001 * v)
+        b.param_apply_many(v, 2, 0, L.VALUE_FLOAT, (70.0 + (v * 13 % 380) + 0.37) / 48000.0)
+        out, _ = b.process_blocks(blocks)
+        out2, _ = b.process_blocks(blocks)
+        outs.append(np.concatenate([np.asarray(out), np.asarray(out2)]))
+        b.close()
+    assert np.abs(outs[0]).max() > 1e-4
+    assert_bit_equal(outs[0], outs[1], "four whole-chain wavefronts per workgroup against one")
