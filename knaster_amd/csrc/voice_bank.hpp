@@ -2007,6 +2007,29 @@ struct Bank final : knh_bank {
       }
       pending.resize(w);
     }
+    // A resident call's per-voice events that are the same few changes for a run of neighbouring voices -- a bank's note-on
+    // sent as one param_apply per voice, "this cutoff for all of them" -- are range events too: 32 bytes per change instead of
+    // 16 per voice and change fetched over PCIe (a bank's 16 384 single triggers: 14 us of the call).
+    if (allow_ranges && pending_ranges.empty() && pending.size() >= 32 && later.empty() && !pending_needs_sort) {
+      const uint32_t v_first = pending[0].voice;
+      size_t k = 1;
+      while (k < pending.size() && pending[k].voice == v_first) ++k;  // the first voice's events
+      bool same = k <= 15 && pending.size() % k == 0;
+      const size_t n_v = same ? pending.size() / k : 0;
+      same = same && v_first + n_v <= nv;
+      for (size_t i = k; same && i < pending.size(); ++i) {
+        const HostEvent& e = pending[i];
+        const HostEvent& f = pending[i % k];
+        same = e.voice == v_first + i / k && e.frame == f.frame && e.op == f.op && e.slot == f.slot && e.bits == f.bits;
+      }
+      if (same) {
+        for (size_t j = 0; j < k; ++j) {
+          const HostEvent& f = pending[j];
+          pending_ranges.push_back(RangeEvent{v_first, v_first + static_cast<uint32_t>(n_v), f.frame, f.op, f.slot, f.bits, 0});
+        }
+        pending.clear();
+      }
+    }
     const size_t total = pending.empty() ? 2 * pending_ranges.size() : pending.size();
     auto finish = [&] {
       pending.clear();
