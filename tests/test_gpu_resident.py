@@ -10,6 +10,7 @@ import pytest
 from helpers import assert_bit_equal, fire_all, make_gpu
 from knaster_amd import _lib as L
 from knaster_amd import configs
+from knaster_amd.bank import TRIGGER
 
 pytestmark = pytest.mark.gpu
 
@@ -216,3 +217,63 @@ def test_param_apply_range_is_the_batch_it_stands_for(knh, monkeypatch):
     np.testing.assert_array_equal(a.read_done_frames(), b.read_done_frames())
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KNH_TEST_SEEDS", "10"))))
+def test_random_traffic_on_a_resident_kernel(knh, monkeypatch, seed):
+    """Seeded parameter traffic -- batches on random voices, runs of neighbouring voices, whole-bank triggers through every entry
+    point, single calls, the same change for every voice call by call, blocks rendered in two or three partial calls -- on a
+    resident kernel against a launch per call: same samples, flags and done frames.  (A call's events reach a resident kernel
+    as per-voice lists, as range events, or as lists that turn out to be ranges: all three come up here.)"""
+    rng0 = np.random.default_rng(9000 + seed)
+    name, n, bs = [("C3", 700, 64), ("C3", 1300, 128), ("C4", 260, 96), ("P3", 300, 64)][seed % 4]
+    blocks = 14
+
+    def render(resident):
+        rng = np.random.default_rng(4000 + seed)
+        monkeypatch.setenv("KNH_RESIDENT", "1" if resident else "0")
+        w = configs.config(name, n_voices=n, block_size=bs)
+        g = make_gpu(knh, w, L.MIX_TREE)
+        v = np.arange(n, dtype=np.uint32)
+        outs, flags = [], []
+        for b in range(blocks):
+            for _ in range(int(rng.integers(0, 4))):
+                kind = int(rng.integers(0, 7))
+                on = w.restart if rng.random() < 0.6 else (w.release or w.restart)
+                if kind == 0:
+                    g.param_apply_range(0, n, on[0], on[1], L.VALUE_TRIGGER)
+                elif kind == 1:
+                    a = int(rng.integers(0, n - 20))
+                    g.param_apply_range(a, int(rng.integers(a + 1, n + 1)), on[0], on[1], L.VALUE_TRIGGER)
+                elif kind == 2:
+                    a = int(rng.integers(0, n - 40))
+                    g.param_apply_many(v[a:a + int(rng.integers(16, 200))], on[0], on[1], L.VALUE_TRIGGER)
+                elif kind == 3:
+                    sel = rng.choice(n, size=int(rng.integers(1, 60)), replace=False).astype(np.uint32)
+                    g.param_apply_many(sel, 0, 0, L.VALUE_FLOAT, 100.0 + 900.0 * rng.random(sel.size))
+                elif kind == 4:
+                    for vv in rng.choice(n, size=int(rng.integers(1, 8)), replace=False):
+                        g.param_apply(int(vv), on[0], on[1], TRIGGER)
+                elif kind == 5:  # the same change for every voice, one call each: a list that is a range
+                    f = 200.0 + 50.0 * int(rng.integers(0, 20))
+                    for vv in range(n):
+                        g.param_apply(vv, 0, 0, f)
+                else:
+                    g.param_apply_range(0, n, 0, 1, L.VALUE_FLOAT, float(rng.random()))  # phase offsets, spelled out per voice
+            cuts = sorted(set(int(c) for c in rng.integers(1, bs, size=int(rng.integers(0, 3))))) if rng.random() < 0.3 else []
+            out = np.zeros((w.out_channels, bs), dtype=g.dtype)
+            f = 0
+            for lo, hi in zip([0] + cuts, cuts + [bs]):
+                o, f = g.process_block(hi - lo, lo)
+                out[:, lo:hi] = o[:, lo:hi]
+            outs.append(out)
+            flags.append(f)
+        done = g.read_done_frames()
+        g.close()
+        return outs, flags, done
+    assert rng0 is not None
+    a, b = render(True), render(False)
+    for k, (x, y) in enumerate(zip(a[0], b[0])):
+        assert_bit_equal(x, y, f"seed {seed} block {k}")
+    assert a[1] == b[1]
+    np.testing.assert_array_equal(a[2], b[2])
